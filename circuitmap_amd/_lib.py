@@ -1,0 +1,138 @@
+"""ctypes binding of libcaviar_hip.so (include/caviar_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or no gfx950 device is
+visible, loading / context creation raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcaviar_hip.so")
+
+CM_OK = 0
+CM_MEM_HOST, CM_MEM_DEVICE = 0, 1
+CM_RNG_THREEFRY, CM_RNG_EXPLICIT = 0, 1
+CM_MAX_VALS = 64
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+class CmPriors(C.Structure):
+    _fields_ = [("mu", _dp), ("beta", _dp), ("shape", C.c_double), ("rate", C.c_double), ("phi", _dp), ("phi_cov", _dp)]
+
+
+class CmOptions(C.Structure):
+    _fields_ = [("iters", C.c_int32), ("num_mc_samples", C.c_int32), ("seed", C.c_uint64), ("y_xcorr_thresh", C.c_double),
+                ("minimum_spike_count", C.c_double), ("delay_spont_est", C.c_int32), ("msrmp", C.c_double),
+                ("scale_factor", C.c_double), ("penalty", C.c_double), ("save_histories", C.c_int32),
+                ("max_backtrack_iters", C.c_int32), ("tol", C.c_double), ("spont_orthogonality", C.c_double),
+                ("fn_scan", C.c_int32), ("rng_mode", C.c_int32), ("update_orders", _ip), ("uniforms", _dp),
+                ("verbose", C.c_int32)]
+
+
+class CmResult(C.Structure):
+    _fields_ = [("mu", _dp), ("beta", _dp), ("lam", _dp), ("shape", C.c_double), ("rate", C.c_double), ("phi", _dp),
+                ("phi_cov", _dp), ("z", _dp), ("mu_hist", _dp), ("beta_hist", _dp), ("lam_hist", _dp), ("shape_hist", _dp),
+                ("rate_hist", _dp), ("phi_hist", _dp), ("phi_cov_hist", _dp), ("z_hist", _dp)]
+
+
+class CmTimings(C.Structure):
+    _fields_ = [("total_ms", C.c_double), ("iters_ms", C.c_double), ("fn_scan_ms", C.c_double), ("solve_ms", C.c_double),
+                ("sweep_ms", C.c_double), ("post_ms", C.c_double), ("iters", C.c_int32), ("last_active", C.c_int32)]
+
+
+# every symbol include/caviar_hip.h declares: (restype, argtypes)
+SYMBOLS = {
+    "cm_last_error": (C.c_char_p, []),
+    "cm_version": (C.c_char_p, []),
+    "cm_device_count": (C.c_int, []),
+    "cm_options_default": (None, [C.POINTER(CmOptions)]),
+    "cm_ctx_create": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "cm_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "cm_ctx_synchronize": (C.c_int, [C.c_void_p]),
+    "cm_problem_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "cm_problem_destroy": (C.c_int, [C.c_void_p]),
+    "cm_problem_nnz": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "cm_caviar_run": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CmPriors), C.POINTER(CmOptions), C.POINTER(CmTimings)]),
+    "cm_caviar_fetch": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CmResult)]),
+    "cm_caviar_fit": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _dp, _dp, C.POINTER(CmPriors), C.POINTER(CmOptions),
+                                C.POINTER(CmResult), C.POINTER(CmTimings)]),
+    "cm_k_prologue": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, _dp]),
+    "cm_pava_last": (C.c_int, [_dp, C.c_int32, _dp]),
+    "cm_k_block_update_mu": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, _dp, C.c_double, C.c_double, _dp, _dp, _dp, _dp]),
+    "cm_k_update_phi": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, _dp, _dp, _dp, _dp]),
+    "cm_k_rng_streams": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, _ip, _dp]),
+}
+
+_lib = None
+
+
+class CaviarHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libcaviar_hip.so (built in-tree by __graft_entry__.build()); raises if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CaviarHipError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                                 "(there is no CPU fallback)" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != CM_OK:
+        raise CaviarHipError("libcaviar_hip error %d: %s" % (rc, load().cm_last_error().decode()))
+
+
+def dptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+def f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+class Context:
+    """One GPU + one HIP stream.  `stream` may be a raw hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)."""
+
+    def __init__(self, device_id=0, stream=None):
+        self.lib = load()
+        self.handle = C.c_void_p()
+        check(self.lib.cm_ctx_create(int(device_id), C.c_void_p(stream) if stream else None, C.byref(self.handle)))
+
+    def synchronize(self):
+        check(self.lib.cm_ctx_synchronize(self.handle))
+
+    def close(self):
+        if self.handle:
+            self.lib.cm_ctx_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device_id=0):
+    if device_id not in _default_ctx:
+        _default_ctx[device_id] = Context(device_id)
+    return _default_ctx[device_id]

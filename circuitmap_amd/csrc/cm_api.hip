@@ -1,0 +1,535 @@
+// C ABI of libcaviar_hip.so (include/caviar_hip.h): context / problem lifecycle, the caviar() driver loop
+// (reference circuitmap/optimise/caviar.py:20-100) and the host-side false-negative scan (caviar.py:102-144).
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "cm_internal.h"
+
+int cm_launch_row_stats(cm_ctx* ctx, cm_problem* p);
+int cm_k_rng_streams_impl(cm_ctx* ctx, cm_problem* p, int it, int S, double* d_u);
+
+static thread_local char g_err[512] = "";
+
+void cm_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* cm_last_error(void) { return g_err; }
+extern "C" const char* cm_version(void) { return "caviar_hip 0.1 (gfx950)"; }
+
+extern "C" int cm_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" void cm_options_default(cm_options* o) {   // caviar.py:21-23
+  memset(o, 0, sizeof(*o));
+  o->iters = 50; o->num_mc_samples = 100; o->seed = 0; o->y_xcorr_thresh = 1e-2; o->minimum_spike_count = 3;
+  o->delay_spont_est = 1; o->msrmp = 0.3; o->scale_factor = 0.75; o->penalty = 5e0; o->save_histories = 0;
+  o->max_backtrack_iters = 20; o->tol = 0.05; o->spont_orthogonality = 0.1; o->fn_scan = 1;
+  o->rng_mode = CM_RNG_THREEFRY; o->update_orders = nullptr; o->uniforms = nullptr; o->verbose = 0;
+}
+
+extern "C" int cm_ctx_create(int device_id, void* hip_stream, cm_ctx** out) {
+  if (!out) { cm_set_error("cm_ctx_create: out is NULL"); return CM_ERR_INVALID; }
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+    cm_set_error("no HIP device visible: libcaviar_hip has no CPU fallback");
+    return CM_ERR_NO_DEVICE;
+  }
+  if (device_id < 0 || device_id >= n) { cm_set_error("device_id %d out of range (%d devices)", device_id, n); return CM_ERR_INVALID; }
+  CM_HIP(hipSetDevice(device_id));
+  cm_ctx* c = new cm_ctx();
+  c->device = device_id;
+  if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
+  else { CM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+  for (auto& e : c->ev) CM_HIP(hipEventCreate(&e));
+  CM_HIP(hipHostMalloc((void**)&c->h_pinned, 64 * sizeof(int32_t), hipHostMallocDefault));
+  hipDeviceProp_t prop;
+  CM_HIP(hipGetDeviceProperties(&prop, device_id));
+  c->num_cus = prop.multiProcessorCount;
+  *out = c;
+  return CM_OK;
+}
+
+extern "C" int cm_ctx_destroy(cm_ctx* c) {
+  if (!c) return CM_OK;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  for (auto& e : c->ev) if (e) hipEventDestroy(e);
+  if (c->h_pinned) hipHostFree(c->h_pinned);
+  if (c->own_stream) hipStreamDestroy(c->stream);
+  delete c;
+  return CM_OK;
+}
+
+extern "C" int cm_ctx_synchronize(cm_ctx* c) {
+  if (!c) return CM_ERR_INVALID;
+  CM_HIP(hipStreamSynchronize(c->stream));
+  return CM_OK;
+}
+
+template <typename T>
+static int dmalloc(T** p, size_t n) {
+  CM_HIP(hipMalloc((void**)p, (n ? n : 1) * sizeof(T)));
+  return CM_OK;
+}
+
+static void free_hist(cm_problem* p) {
+  double** h[] = {&p->h_mu, &p->h_beta, &p->h_lam, &p->h_shape, &p->h_rate, &p->h_phi, &p->h_phi_cov, &p->h_z};
+  for (auto q : h) { if (*q) hipFree(*q); *q = nullptr; }
+  p->hist_iters = 0;
+}
+
+extern "C" int cm_problem_destroy(cm_problem* p) {
+  if (!p) return CM_OK;
+  hipSetDevice(p->ctx->device);
+  hipStreamSynchronize(p->ctx->stream);
+  void* ptrs[] = {p->y, p->ss, p->sum_y, p->vals, p->row_ptr, p->col, p->grp, p->rowcnt, p->col_ptr, p->csc_row, p->csc_pos,
+                  p->mask, p->lam, p->mu, p->beta, p->mu_prior, p->beta_prior, p->phi, p->phi_cov, p->phi_prior, p->phi_cov_prior,
+                  p->scal, p->R, p->colany, p->z, p->mcE, p->rs, p->act_idx, p->act_inv, p->n_act, p->order, p->perm_tmp,
+                  p->sort_keys, p->keys, p->uexp, p->orders_exp, p->A, p->X, p->Dinv, p->rhs};
+  for (void* q : ptrs) if (q) hipFree(q);
+  free_hist(p);
+  delete p;
+  return CM_OK;
+}
+
+extern "C" int cm_problem_create(cm_ctx* ctx, int32_t N, int32_t K, int32_t T, const double* psc, const double* stim, int mem_kind,
+                                 cm_problem** out) {
+  if (!ctx || !psc || !stim || !out) { cm_set_error("cm_problem_create: NULL argument"); return CM_ERR_INVALID; }
+  if (N < 2 || K < 1 || T < 1) { cm_set_error("cm_problem_create: need N >= 2, K >= 1, T >= 1 (got %d, %d, %d)", N, K, T); return CM_ERR_INVALID; }
+  CM_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  cm_problem* p = new cm_problem();
+  p->ctx = ctx; p->N = N; p->K = K; p->T = T;
+  int rc = CM_OK;
+  double *d_psc = nullptr, *d_stim = nullptr;
+  auto fail = [&](int code) { if (mem_kind == CM_MEM_HOST) { if (d_psc) hipFree(d_psc); if (d_stim) hipFree(d_stim); } cm_problem_destroy(p); return code; };
+  if (mem_kind == CM_MEM_HOST) {
+    if ((rc = dmalloc(&d_psc, (size_t)K * T)) || (rc = dmalloc(&d_stim, (size_t)N * K))) return fail(rc);
+    if (hipMemcpyAsync(d_psc, psc, (size_t)K * T * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(d_stim, stim, (size_t)N * K * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) {
+      cm_set_error("upload of psc/stim failed");
+      return fail(CM_ERR_HIP);
+    }
+  } else {
+    d_psc = const_cast<double*>(psc);
+    d_stim = const_cast<double*>(stim);
+  }
+  if ((rc = dmalloc(&p->y, K)) || (rc = dmalloc(&p->ss, K)) || (rc = dmalloc(&p->sum_y, 2))) return fail(rc);
+  if ((rc = cm_launch_psc_prologue(ctx, K, T, d_psc, p->y, p->ss))) return fail(rc);
+  if ((rc = cm_encode_stim(ctx, p, d_stim))) return fail(rc);
+  if (mem_kind == CM_MEM_HOST) { hipFree(d_psc); hipFree(d_stim); d_psc = d_stim = nullptr; }
+
+  p->ld = ((N + CM_TILE - 1) / CM_TILE) * CM_TILE;
+  const size_t ld = p->ld;
+  if ((rc = dmalloc(&p->mask, K)) || (rc = dmalloc(&p->lam, (size_t)p->nnz)) || (rc = dmalloc(&p->mu, N)) || (rc = dmalloc(&p->beta, N)) ||
+      (rc = dmalloc(&p->mu_prior, N)) || (rc = dmalloc(&p->beta_prior, N)) || (rc = dmalloc(&p->phi, 2 * (size_t)N)) ||
+      (rc = dmalloc(&p->phi_cov, 4 * (size_t)N)) || (rc = dmalloc(&p->phi_prior, 2 * (size_t)N)) ||
+      (rc = dmalloc(&p->phi_cov_prior, 4 * (size_t)N)) || (rc = dmalloc(&p->scal, CM_S_COUNT)) || (rc = dmalloc(&p->R, K)) ||
+      (rc = dmalloc(&p->colany, K)) || (rc = dmalloc(&p->z, K)) || (rc = dmalloc(&p->mcE, (size_t)N * CM_MAX_VALS)) ||
+      (rc = dmalloc(&p->rs, 4 * (size_t)N)) || (rc = dmalloc(&p->act_idx, N)) || (rc = dmalloc(&p->act_inv, N)) ||
+      (rc = dmalloc(&p->n_act, 4)) || (rc = dmalloc(&p->order, N)) || (rc = dmalloc(&p->perm_tmp, N)) ||
+      (rc = dmalloc(&p->sort_keys, N)) || (rc = dmalloc(&p->A, ld * ld)) || (rc = dmalloc(&p->X, ld * ld)) ||
+      (rc = dmalloc(&p->Dinv, ld * CM_TILE)) || (rc = dmalloc(&p->rhs, 2 * ld)))
+    return fail(rc);
+  if (hipMemsetAsync(p->mcE, 0, (size_t)N * CM_MAX_VALS * sizeof(double), st) != hipSuccess) return fail(CM_ERR_HIP);
+  if (hipStreamSynchronize(st) != hipSuccess) { cm_set_error("prologue failed: %s", hipGetErrorString(hipGetLastError())); return fail(CM_ERR_HIP); }
+  *out = p;
+  return CM_OK;
+}
+
+extern "C" int cm_problem_nnz(const cm_problem* p, int64_t* nnz, int32_t* n_vals) {
+  if (!p) return CM_ERR_INVALID;
+  if (nnz) *nnz = p->nnz;
+  if (n_vals) *n_vals = p->V;
+  return CM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side of the driver
+// ------------------------------------------------------------------------------------------------
+double cm_host_pava_last(const double* y, int n) {   // pava.py:9-88, gamma = 1, literal pool walk
+  if (n <= 0) return 0.0;
+  std::vector<double> v(n), w(n);
+  int i = 0;
+  v[0] = y[0]; w[0] = 1.0;
+  for (int t = 1; t < n; ++t) {
+    ++i;
+    v[i] = y[t]; w[i] = 1.0;
+    while (i > 0 && (v[i - 1] / w[i - 1]) > (v[i] / w[i])) {
+      --i;
+      v[i] += v[i + 1];
+      w[i] += w[i + 1];
+    }
+  }
+  return v[i] / w[i];
+}
+
+extern "C" int cm_pava_last(const double* y, int32_t n, double* out) {
+  if (!y || !out || n < 1) { cm_set_error("cm_pava_last: bad argument"); return CM_ERR_INVALID; }
+  *out = cm_host_pava_last(y, n);
+  return CM_OK;
+}
+
+static int upload_priors(cm_ctx* ctx, cm_problem* p, const cm_priors* pr) {
+  hipStream_t st = ctx->stream;
+  const size_t N = p->N;
+  CM_HIP(hipMemcpyAsync(p->mu_prior, pr->mu, N * sizeof(double), hipMemcpyHostToDevice, st));
+  CM_HIP(hipMemcpyAsync(p->beta_prior, pr->beta, N * sizeof(double), hipMemcpyHostToDevice, st));
+  CM_HIP(hipMemcpyAsync(p->phi_prior, pr->phi, 2 * N * sizeof(double), hipMemcpyHostToDevice, st));
+  CM_HIP(hipMemcpyAsync(p->phi_cov_prior, pr->phi_cov, 4 * N * sizeof(double), hipMemcpyHostToDevice, st));
+  CM_HIP(hipMemcpyAsync(p->phi, pr->phi, 2 * N * sizeof(double), hipMemcpyHostToDevice, st));          // caviar.py:48-49
+  CM_HIP(hipMemcpyAsync(p->phi_cov, pr->phi_cov, 4 * N * sizeof(double), hipMemcpyHostToDevice, st));
+  CM_HIP(hipMemcpyAsync(p->mu, pr->mu, N * sizeof(double), hipMemcpyHostToDevice, st));                // caviar.py:44-45
+  CM_HIP(hipMemcpyAsync(p->beta, pr->beta, N * sizeof(double), hipMemcpyHostToDevice, st));
+  double h[CM_S_COUNT] = {0};
+  h[CM_S_SHAPE] = pr->shape; h[CM_S_RATE] = pr->rate; h[CM_S_SPONT_RATE] = 0.0;
+  h[CM_S_SHAPE_PRIOR] = pr->shape; h[CM_S_RATE_PRIOR] = pr->rate;
+  CM_HIP(hipMemcpyAsync(p->scal, h, sizeof(h), hipMemcpyHostToDevice, st));
+  CM_HIP(hipStreamSynchronize(st));   // h is a stack buffer
+  return CM_OK;
+}
+
+// reconnect_spont_cells, caviar.py:102-144.  Host C++ on the compressed rows (one-off, after the last iteration).
+static void host_reconnect(const cm_problem* p, std::vector<double>& mu, std::vector<double>& beta, std::vector<double>& lam,
+                           std::vector<double>& z, double minimax_spk_prob, double minimum_spike_count, int verbose) {
+  const int N = p->N, K = p->K, V = p->V;
+  const int P = V - 1;
+  std::vector<int> disc;
+  for (int n = 0; n < N; ++n) if (mu[n] == 0.0) disc.push_back(n);           // :103 exact zero test (quirk 7)
+  const size_t init = disc.size();
+  // np.where(stim_matrix[n]) selects NON-ZERO entries; targeted entries (> 0) are the CSR row.  Negative stimulus values
+  // are outside the reference's contract (powers are non-negative) and are treated as untargeted here.
+  while (!disc.empty()) {
+    long nz = 0;
+    for (int k = 0; k < K; ++k) nz += (z[k] != 0.0);
+    if (!((double)nz > minimum_spike_count)) break;                           // :111,141
+    int focus_indx = 0; long best = -1;
+    for (size_t i = 0; i < disc.size(); ++i) {                                // :112-117 (argmax takes the first maximum)
+      const int n = disc[i];
+      long c = 0;
+      for (int e = p->h_row_ptr[n]; e < p->h_row_ptr[n + 1]; ++e) c += (z[p->h_col[e]] != 0.0);
+      if (c > best) { best = c; focus_indx = (int)i; }
+    }
+    const int focus = disc[focus_indx];
+    std::vector<double> srates(P > 0 ? P : 0, 0.0);
+    double spike_count = 0.0;
+    for (int i = 0; i < P; ++i) {                                             // :121-127
+      long cnt = 0, hit = 0;
+      for (int e = p->h_row_ptr[focus]; e < p->h_row_ptr[focus + 1]; ++e)
+        if (p->h_grp[e] == i + 1) { ++cnt; hit += (z[p->h_col[e]] != 0.0); }
+      if (cnt > 0) { srates[i] = (double)hit / (double)cnt; spike_count += (double)hit; }
+    }
+    const double pava = P > 0 ? cm_host_pava_last(srates.data(), P) : 0.0;    // :128
+    if (pava >= minimax_spk_prob && spike_count >= minimum_spike_count) {     // :130
+      std::vector<int> locs;
+      for (int e = p->h_row_ptr[focus]; e < p->h_row_ptr[focus + 1]; ++e) if (z[p->h_col[e]] != 0.0) locs.push_back(e);
+      const size_t m = locs.size();
+      // np.mean: pairwise summation; m is small (a cell's targeted trials), plain left-to-right sum matches for m < 8
+      double s = 0.0;
+      for (int e : locs) s += z[p->h_col[e]];
+      const double mean = s / (double)m;
+      double ssd = 0.0;
+      for (int e : locs) { const double d = z[p->h_col[e]] - mean; ssd += d * d; }
+      mu[focus] = mean;                                                        // :134
+      beta[focus] = m > 1 ? sqrt(ssd / (double)(m - 1)) / sqrt((double)m) : NAN;   // :135 scipy.stats.sem, ddof = 1
+      for (int e : locs) { lam[e] = 1.0; z[p->h_col[e]] = 0.0; }               // :136-137
+      if (verbose) fprintf(stderr, "Reconnecting cell %d with maximal pava spike rate %.2f\n", focus, pava);
+    }
+    disc.erase(disc.begin() + focus_indx);                                     // :139
+  }
+  if (verbose) fprintf(stderr, "Examined %zu/%d cells for false negatives. Cell reconnection complete.\n", init, N);
+}
+
+static int alloc_hist(cm_problem* p, int iters) {
+  free_hist(p);
+  const size_t it = iters, N = p->N, K = p->K;
+  CM_TRY(dmalloc(&p->h_mu, it * N)); CM_TRY(dmalloc(&p->h_beta, it * N)); CM_TRY(dmalloc(&p->h_lam, it * (size_t)p->nnz));
+  CM_TRY(dmalloc(&p->h_shape, it)); CM_TRY(dmalloc(&p->h_rate, it)); CM_TRY(dmalloc(&p->h_phi, it * 2 * N));
+  CM_TRY(dmalloc(&p->h_phi_cov, it * 4 * N)); CM_TRY(dmalloc(&p->h_z, it * K));
+  p->hist_iters = iters;
+  return CM_OK;
+}
+
+static int record_hist(cm_ctx* ctx, cm_problem* p, int it) {
+  hipStream_t st = ctx->stream;
+  const size_t N = p->N, K = p->K, nnz = p->nnz;
+  const hipMemcpyKind k = hipMemcpyDeviceToDevice;
+  CM_HIP(hipMemcpyAsync(p->h_mu + it * N, p->mu, N * 8, k, st));
+  CM_HIP(hipMemcpyAsync(p->h_beta + it * N, p->beta, N * 8, k, st));
+  if (nnz) CM_HIP(hipMemcpyAsync(p->h_lam + it * nnz, p->lam, nnz * 8, k, st));
+  CM_HIP(hipMemcpyAsync(p->h_shape + it, p->scal + CM_S_SHAPE, 8, k, st));
+  CM_HIP(hipMemcpyAsync(p->h_rate + it, p->scal + CM_S_RATE, 8, k, st));
+  CM_HIP(hipMemcpyAsync(p->h_phi + it * 2 * N, p->phi, 2 * N * 8, k, st));
+  CM_HIP(hipMemcpyAsync(p->h_phi_cov + it * 4 * N, p->phi_cov, 4 * N * 8, k, st));
+  CM_HIP(hipMemcpyAsync(p->h_z + it * K, p->z, K * 8, k, st));
+  return CM_OK;
+}
+
+extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, const cm_options* o, cm_timings* tm) {
+  if (!ctx || !p || !pr || !o) { cm_set_error("cm_caviar_run: NULL argument"); return CM_ERR_INVALID; }
+  if (!pr->mu || !pr->beta || !pr->phi || !pr->phi_cov) { cm_set_error("cm_caviar_run: NULL prior array"); return CM_ERR_INVALID; }
+  if (o->iters < 0 || o->num_mc_samples < 1) { cm_set_error("cm_caviar_run: iters >= 0 and num_mc_samples >= 1 required"); return CM_ERR_INVALID; }
+  if (o->rng_mode == CM_RNG_EXPLICIT && (!o->update_orders || !o->uniforms)) {
+    cm_set_error("cm_caviar_run: CM_RNG_EXPLICIT needs update_orders and uniforms"); return CM_ERR_INVALID;
+  }
+  CM_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const int N = p->N, K = p->K, S = o->num_mc_samples, iters = o->iters;
+  p->ran = false;
+  CM_HIP(hipEventRecord(ctx->ev[0], st));
+
+  // RNG streams
+  if (o->rng_mode == CM_RNG_EXPLICIT) {
+    if (p->uexp) { hipFree(p->uexp); p->uexp = nullptr; }
+    if (p->orders_exp) { hipFree(p->orders_exp); p->orders_exp = nullptr; }
+    CM_TRY(dmalloc(&p->uexp, (size_t)iters * N * S * 2));
+    CM_TRY(dmalloc(&p->orders_exp, (size_t)iters * N));
+    CM_HIP(hipMemcpyAsync(p->uexp, o->uniforms, (size_t)iters * N * S * 2 * sizeof(double), hipMemcpyHostToDevice, st));
+    CM_HIP(hipMemcpyAsync(p->orders_exp, o->update_orders, (size_t)iters * N * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  }
+  CM_TRY(upload_priors(ctx, p, pr));
+  CM_TRY(cm_launch_init_state(ctx, p, o->y_xcorr_thresh));
+  CM_HIP(hipMemsetAsync(p->n_act, 0, 4 * sizeof(int), st));
+  CM_TRY(cm_launch_row_stats(ctx, p));          // active set of lam0 for the first solve
+  std::vector<uint32_t> keys;
+  if (o->rng_mode == CM_RNG_THREEFRY && iters > 0) {
+    cm_host_key_schedule(o->seed, iters, N, keys);      // overlaps with the init kernels above
+    if (p->keys_iters < iters) {
+      if (p->keys) hipFree(p->keys);
+      p->keys = nullptr;
+      CM_TRY(dmalloc(&p->keys, keys.size()));
+      p->keys_iters = iters;
+    }
+    CM_HIP(hipMemcpyAsync(p->keys, keys.data(), keys.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  }
+  if (o->save_histories && iters > 0) CM_TRY(alloc_hist(p, iters)); else free_hist(p);
+
+  CM_HIP(hipEventRecord(ctx->ev[1], st));
+  int last_active = 0;
+  for (int it = 0; it < iters; ++it) {                               // caviar.py:79
+    CM_TRY(cm_solve_mu(ctx, p, &last_active));                       // :80  block_update_mu
+    if (ctx->h_pinned[1]) { cm_set_error("iteration %d: weight precision matrix not positive definite", it); return CM_ERR_NOT_SPD; }
+    CM_TRY(cm_launch_rng(ctx, p, it, S, o->rng_mode, nullptr));      // :196 update order
+    CM_TRY(cm_launch_mc_logit(ctx, p, it, S, o->rng_mode));          // :209-215
+    CM_TRY(cm_launch_sweep(ctx, p, it, o));                          // :81  update_lam
+    CM_TRY(cm_launch_row_stats(ctx, p));                             // row sums of the new lam (+ next active set)
+    CM_TRY(cm_launch_post(ctx, p, it, o));                           // :84-88 update_sigma, update_phi, z, spont_rate
+    if (o->save_histories) CM_TRY(record_hist(ctx, p, it));          // :90-92
+    if (o->verbose >= 2) {
+      CM_HIP(hipStreamSynchronize(st));
+      fprintf(stderr, "[caviar_hip] it %d active %d\n", it, last_active);
+    }
+  }
+  CM_HIP(hipEventRecord(ctx->ev[2], st));
+
+  if (o->fn_scan) {                                                  // caviar.py:94-98
+    const size_t nnz = p->nnz;
+    std::vector<double> mu(N), beta(N), lam(nnz ? nnz : 1), z(K);
+    CM_HIP(hipMemcpyAsync(mu.data(), p->mu, (size_t)N * 8, hipMemcpyDeviceToHost, st));
+    CM_HIP(hipMemcpyAsync(beta.data(), p->beta, (size_t)N * 8, hipMemcpyDeviceToHost, st));
+    if (nnz) CM_HIP(hipMemcpyAsync(lam.data(), p->lam, nnz * 8, hipMemcpyDeviceToHost, st));
+    CM_HIP(hipMemcpyAsync(z.data(), p->z, (size_t)K * 8, hipMemcpyDeviceToHost, st));
+    CM_HIP(hipStreamSynchronize(st));
+    host_reconnect(p, mu, beta, lam, z, o->msrmp, o->minimum_spike_count, o->verbose);
+    CM_HIP(hipMemcpyAsync(p->mu, mu.data(), (size_t)N * 8, hipMemcpyHostToDevice, st));
+    CM_HIP(hipMemcpyAsync(p->beta, beta.data(), (size_t)N * 8, hipMemcpyHostToDevice, st));
+    if (nnz) CM_HIP(hipMemcpyAsync(p->lam, lam.data(), nnz * 8, hipMemcpyHostToDevice, st));
+    CM_HIP(hipMemcpyAsync(p->z, z.data(), (size_t)K * 8, hipMemcpyHostToDevice, st));
+    CM_TRY(cm_launch_update_phi(ctx, p));
+    CM_HIP(hipStreamSynchronize(st));   // host vectors go out of scope
+  }
+  CM_HIP(hipEventRecord(ctx->ev[3], st));
+  CM_HIP(hipStreamSynchronize(st));
+  if (iters > 0) {
+    CM_HIP(hipMemcpy(ctx->h_pinned, p->n_act, 4 * sizeof(int), hipMemcpyDeviceToHost));
+    if (ctx->h_pinned[1]) { cm_set_error("weight precision matrix not positive definite"); return CM_ERR_NOT_SPD; }
+  }
+  if (tm) {
+    float a = 0, b = 0, c = 0;
+    hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[3]);
+    hipEventElapsedTime(&b, ctx->ev[1], ctx->ev[2]);
+    hipEventElapsedTime(&c, ctx->ev[2], ctx->ev[3]);
+    memset(tm, 0, sizeof(*tm));
+    tm->total_ms = a; tm->iters_ms = b; tm->fn_scan_ms = c; tm->iters = iters; tm->last_active = last_active;
+  }
+  p->ran = true;
+  return CM_OK;
+}
+
+extern "C" int cm_caviar_fetch(cm_ctx* ctx, cm_problem* p, cm_result* r) {
+  if (!ctx || !p || !r) { cm_set_error("cm_caviar_fetch: NULL argument"); return CM_ERR_INVALID; }
+  if (!p->ran) { cm_set_error("cm_caviar_fetch: no completed cm_caviar_run on this problem"); return CM_ERR_STATE; }
+  CM_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const size_t N = p->N, K = p->K, nnz = p->nnz;
+  const hipMemcpyKind k = hipMemcpyDeviceToHost;
+  if (r->mu) CM_HIP(hipMemcpyAsync(r->mu, p->mu, N * 8, k, st));
+  if (r->beta) CM_HIP(hipMemcpyAsync(r->beta, p->beta, N * 8, k, st));
+  if (r->phi) CM_HIP(hipMemcpyAsync(r->phi, p->phi, 2 * N * 8, k, st));
+  if (r->phi_cov) CM_HIP(hipMemcpyAsync(r->phi_cov, p->phi_cov, 4 * N * 8, k, st));
+  if (r->z) CM_HIP(hipMemcpyAsync(r->z, p->z, K * 8, k, st));
+  double sc[CM_S_COUNT];
+  CM_HIP(hipMemcpyAsync(sc, p->scal, sizeof(sc), k, st));
+  std::vector<double> sp;
+  if (r->lam) {   // compressed rows over PCIe, dense expansion on the host (lam is zero off the targeted trials)
+    sp.resize(nnz ? nnz : 1);
+    if (nnz) CM_HIP(hipMemcpyAsync(sp.data(), p->lam, nnz * 8, k, st));
+  }
+  CM_HIP(hipStreamSynchronize(st));
+  r->shape = sc[CM_S_SHAPE];
+  r->rate = sc[CM_S_RATE];
+  auto expand = [&](const double* src, double* dst) {
+    memset(dst, 0, N * K * sizeof(double));
+    for (size_t n = 0; n < N; ++n)
+      for (int e = p->h_row_ptr[n]; e < p->h_row_ptr[n + 1]; ++e) dst[n * K + p->h_col[e]] = src[e];
+  };
+  if (r->lam) expand(sp.data(), r->lam);
+  if (p->hist_iters > 0) {
+    const size_t H = p->hist_iters;
+    if (r->mu_hist) CM_HIP(hipMemcpy(r->mu_hist, p->h_mu, H * N * 8, k));
+    if (r->beta_hist) CM_HIP(hipMemcpy(r->beta_hist, p->h_beta, H * N * 8, k));
+    if (r->phi_hist) CM_HIP(hipMemcpy(r->phi_hist, p->h_phi, H * 2 * N * 8, k));
+    if (r->phi_cov_hist) CM_HIP(hipMemcpy(r->phi_cov_hist, p->h_phi_cov, H * 4 * N * 8, k));
+    if (r->z_hist) CM_HIP(hipMemcpy(r->z_hist, p->h_z, H * K * 8, k));
+    if (r->shape_hist || r->rate_hist) {                                  // scalars broadcast to [iters, K] (caviar.py:60-61)
+      std::vector<double> a(H), b(H);
+      CM_HIP(hipMemcpy(a.data(), p->h_shape, H * 8, k));
+      CM_HIP(hipMemcpy(b.data(), p->h_rate, H * 8, k));
+      for (size_t i = 0; i < H; ++i)
+        for (size_t j = 0; j < K; ++j) {
+          if (r->shape_hist) r->shape_hist[i * K + j] = a[i];
+          if (r->rate_hist) r->rate_hist[i * K + j] = b[i];
+        }
+    }
+    if (r->lam_hist) {
+      std::vector<double> row(nnz ? nnz : 1);
+      for (size_t i = 0; i < H; ++i) {
+        if (nnz) CM_HIP(hipMemcpy(row.data(), p->h_lam + i * nnz, nnz * 8, k));
+        expand(row.data(), r->lam_hist + i * N * K);
+      }
+    }
+  }
+  return CM_OK;
+}
+
+extern "C" int cm_caviar_fit(cm_ctx* ctx, int32_t N, int32_t K, int32_t T, const double* psc, const double* stim, const cm_priors* pr,
+                             const cm_options* o, cm_result* r, cm_timings* tm) {
+  cm_problem* p = nullptr;
+  CM_TRY(cm_problem_create(ctx, N, K, T, psc, stim, CM_MEM_HOST, &p));
+  int rc = cm_caviar_run(ctx, p, pr, o, tm);
+  if (rc == CM_OK && r) rc = cm_caviar_fetch(ctx, p, r);
+  cm_problem_destroy(p);
+  return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-phase entry points for the parity tests
+// ------------------------------------------------------------------------------------------------
+extern "C" int cm_k_prologue(cm_ctx* ctx, int32_t K, int32_t T, const double* psc, double* y, double* ss) {
+  if (!ctx || !psc || !y || !ss || K < 1 || T < 1) { cm_set_error("cm_k_prologue: bad argument"); return CM_ERR_INVALID; }
+  CM_HIP(hipSetDevice(ctx->device));
+  double *d_psc = nullptr, *d_y = nullptr, *d_ss = nullptr;
+  CM_TRY(dmalloc(&d_psc, (size_t)K * T)); CM_TRY(dmalloc(&d_y, K)); CM_TRY(dmalloc(&d_ss, K));
+  CM_HIP(hipMemcpyAsync(d_psc, psc, (size_t)K * T * 8, hipMemcpyHostToDevice, ctx->stream));
+  CM_TRY(cm_launch_psc_prologue(ctx, K, T, d_psc, d_y, d_ss));
+  CM_HIP(hipMemcpyAsync(y, d_y, (size_t)K * 8, hipMemcpyDeviceToHost, ctx->stream));
+  CM_HIP(hipMemcpyAsync(ss, d_ss, (size_t)K * 8, hipMemcpyDeviceToHost, ctx->stream));
+  CM_HIP(hipStreamSynchronize(ctx->stream));
+  hipFree(d_psc); hipFree(d_y); hipFree(d_ss);
+  return CM_OK;
+}
+
+// builds a problem around a stimulus matrix and a dense lam (psc is not needed by the phase under test)
+static int problem_from_dense(cm_ctx* ctx, int N, int K, const double* stim, const double* lam, const double* y, cm_problem** out) {
+  std::vector<double> psc((size_t)K, 0.0);   // T = 1 placeholder
+  CM_TRY(cm_problem_create(ctx, N, K, 1, psc.data(), stim, CM_MEM_HOST, out));
+  cm_problem* p = *out;
+  double* d_dense = nullptr;
+  CM_TRY(dmalloc(&d_dense, (size_t)N * K));
+  CM_HIP(hipMemcpyAsync(d_dense, lam, (size_t)N * K * 8, hipMemcpyHostToDevice, ctx->stream));
+  CM_TRY(cm_launch_scatter_dense_lam(ctx, p, d_dense));
+  if (y) CM_HIP(hipMemcpyAsync(p->y, y, (size_t)K * 8, hipMemcpyHostToDevice, ctx->stream));
+  CM_HIP(hipStreamSynchronize(ctx->stream));
+  hipFree(d_dense);
+  return CM_OK;
+}
+
+extern "C" int cm_k_block_update_mu(cm_ctx* ctx, int32_t N, int32_t K, const double* stim, const double* lam, const double* y,
+                                    double shape, double rate, const double* mu_prior, const double* beta_prior, double* mu, double* beta) {
+  if (!ctx || !stim || !lam || !y || !mu_prior || !beta_prior || !mu || !beta) { cm_set_error("cm_k_block_update_mu: NULL argument"); return CM_ERR_INVALID; }
+  cm_problem* p = nullptr;
+  CM_TRY(problem_from_dense(ctx, N, K, stim, lam, y, &p));
+  hipStream_t st = ctx->stream;
+  double h[CM_S_COUNT] = {0};
+  h[CM_S_SHAPE] = shape; h[CM_S_RATE] = rate;
+  int rc = CM_OK;
+  if (hipMemcpy(p->scal, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(p->mu_prior, mu_prior, (size_t)N * 8, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(p->beta_prior, beta_prior, (size_t)N * 8, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemset(p->n_act, 0, 4 * sizeof(int)) != hipSuccess) { cm_set_error("upload failed"); rc = CM_ERR_HIP; }
+  int na = 0;
+  if (!rc) rc = cm_launch_row_stats(ctx, p);
+  if (!rc) rc = cm_solve_mu(ctx, p, &na);
+  if (!rc && (hipMemcpyAsync(mu, p->mu, (size_t)N * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+              hipMemcpyAsync(beta, p->beta, (size_t)N * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+              hipMemcpyAsync(ctx->h_pinned, p->n_act, 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
+              hipStreamSynchronize(st) != hipSuccess)) { cm_set_error("download failed: %s", hipGetErrorString(hipGetLastError())); rc = CM_ERR_HIP; }
+  if (!rc && ctx->h_pinned[1]) { cm_set_error("precision matrix not positive definite"); rc = CM_ERR_NOT_SPD; }
+  cm_problem_destroy(p);
+  return rc;
+}
+
+extern "C" int cm_k_update_phi(cm_ctx* ctx, int32_t N, int32_t K, const double* stim, const double* lam, const double* phi_prior,
+                               const double* phi_cov_prior, double* phi, double* phi_cov) {
+  if (!ctx || !stim || !lam || !phi_prior || !phi_cov_prior || !phi || !phi_cov) { cm_set_error("cm_k_update_phi: NULL argument"); return CM_ERR_INVALID; }
+  cm_problem* p = nullptr;
+  CM_TRY(problem_from_dense(ctx, N, K, stim, lam, nullptr, &p));
+  hipStream_t st = ctx->stream;
+  int rc = CM_OK;
+  if (hipMemcpy(p->phi_prior, phi_prior, (size_t)N * 16, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(p->phi_cov_prior, phi_cov_prior, (size_t)N * 32, hipMemcpyHostToDevice) != hipSuccess) { cm_set_error("upload failed"); rc = CM_ERR_HIP; }
+  if (!rc) rc = cm_launch_update_phi(ctx, p);
+  if (!rc && (hipMemcpyAsync(phi, p->phi, (size_t)N * 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
+              hipMemcpyAsync(phi_cov, p->phi_cov, (size_t)N * 32, hipMemcpyDeviceToHost, st) != hipSuccess ||
+              hipStreamSynchronize(st) != hipSuccess)) { cm_set_error("download failed: %s", hipGetErrorString(hipGetLastError())); rc = CM_ERR_HIP; }
+  cm_problem_destroy(p);
+  return rc;
+}
+
+extern "C" int cm_k_rng_streams(cm_ctx* ctx, uint64_t seed, int32_t it, int32_t N, int32_t S, int32_t* order, double* u) {
+  if (!ctx || !order || !u || N < 2 || S < 1 || it < 0) { cm_set_error("cm_k_rng_streams: bad argument"); return CM_ERR_INVALID; }
+  CM_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  cm_problem q;                         // only the RNG buffers are used
+  q.ctx = ctx; q.N = N;
+  std::vector<uint32_t> keys;
+  cm_host_key_schedule(seed, it + 1, N, keys);
+  double* d_u = nullptr;
+  int rc = CM_OK;
+  if ((rc = dmalloc(&q.keys, keys.size())) || (rc = dmalloc(&q.order, N)) || (rc = dmalloc(&q.perm_tmp, N)) ||
+      (rc = dmalloc(&q.sort_keys, N)) || (rc = dmalloc(&q.phi, 2 * (size_t)N)) || (rc = dmalloc(&q.phi_cov, 4 * (size_t)N)) ||
+      (rc = dmalloc(&q.mcE, 1)) || (rc = dmalloc(&q.vals, CM_MAX_VALS)) || (rc = dmalloc(&d_u, (size_t)N * S * 2))) {
+  } else if (hipMemcpyAsync(q.keys, keys.data(), keys.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+             hipMemsetAsync(q.phi, 0, (size_t)N * 16, st) != hipSuccess || hipMemsetAsync(q.phi_cov, 0, (size_t)N * 32, st) != hipSuccess) {
+    cm_set_error("rng upload failed"); rc = CM_ERR_HIP;
+  }
+  if (!rc) rc = cm_launch_rng(ctx, &q, it, S, CM_RNG_THREEFRY, nullptr);
+  if (!rc) rc = cm_k_rng_streams_impl(ctx, &q, it, S, d_u);
+  if (!rc && (hipMemcpyAsync(order, q.order, (size_t)N * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+              hipMemcpyAsync(u, d_u, (size_t)N * S * 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
+              hipStreamSynchronize(st) != hipSuccess)) { cm_set_error("rng download failed: %s", hipGetErrorString(hipGetLastError())); rc = CM_ERR_HIP; }
+  void* ptrs[] = {q.keys, q.order, q.perm_tmp, q.sort_keys, q.phi, q.phi_cov, q.mcE, q.vals, d_u};
+  for (void* x : ptrs) if (x) hipFree(x);
+  return rc;
+}

@@ -1,0 +1,186 @@
+// Internal declarations shared by the HIP translation units of libcaviar_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/caviar_hip.h"
+
+#define CM_WAVE 64
+#define CM_TILE 32          // tile edge of the blocked SPD solve
+
+void cm_set_error(const char* fmt, ...);
+
+#define CM_HIP(call)                                                                          \
+  do {                                                                                        \
+    hipError_t _e = (call);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      cm_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(_e));      \
+      return CM_ERR_HIP;                                                                      \
+    }                                                                                         \
+  } while (0)
+
+#define CM_TRY(expr)              \
+  do {                            \
+    int _s = (expr);              \
+    if (_s != CM_OK) return _s;   \
+  } while (0)
+
+struct cm_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  hipEvent_t ev[8] = {};
+  int32_t* h_pinned = nullptr;   // small pinned host mailbox (active-set size, flags)
+  int num_cus = 256;
+};
+
+// One circuit: encoded stimulus + observations + CAVIaR state.  All pointers are device memory.
+struct cm_problem {
+  cm_ctx* ctx = nullptr;
+  int32_t N = 0, K = 0, T = 0;
+  int64_t nnz = 0;       // number of targeted (stim > 0) entries
+  int32_t V = 0;         // number of distinct stimulus values (sorted ascending; powers = vals[1:])
+  int32_t ld = 0;        // leading dimension of the solve matrices (multiple of CM_TILE), sized for N
+  // --- static encoding (built once by cm_problem_create) ---
+  double* y = nullptr;        // [K]  trapz(psc)
+  double* ss = nullptr;       // [K]  sum psc^2
+  double* sum_y = nullptr;    // [2]  sum(y), sum(y^2)
+  double* vals = nullptr;     // [CM_MAX_VALS] sorted distinct stimulus values
+  int32_t* row_ptr = nullptr; // [N+1] CSR over targeted entries
+  int32_t* col = nullptr;     // [nnz] trial index
+  uint8_t* grp = nullptr;     // [nnz] index into vals
+  int32_t* rowcnt = nullptr;  // [N*CM_MAX_VALS] number of trials of row n with stim == vals[g] (targeted or not)
+  int32_t* col_ptr = nullptr; // [K+1] CSC
+  int32_t* csc_row = nullptr; // [nnz] neuron index
+  int32_t* csc_pos = nullptr; // [nnz] position of the entry in CSR order
+  // host mirror of the CSR (for reconnect_spont_cells and dense expansion)
+  std::vector<int32_t> h_row_ptr, h_col;
+  std::vector<uint8_t> h_grp;
+  std::vector<double> h_vals;
+  // --- CAVIaR state ---
+  uint8_t* mask = nullptr;    // [K] lam_mask
+  double* lam = nullptr;      // [nnz] CSR order
+  double* mu = nullptr;       // [N]
+  double* beta = nullptr;     // [N] posterior variance (reference's "beta")
+  double* mu_prior = nullptr; // [N]
+  double* beta_prior = nullptr; // [N]
+  double* phi = nullptr;      // [N*2]
+  double* phi_cov = nullptr;  // [N*4]
+  double* phi_prior = nullptr;
+  double* phi_cov_prior = nullptr;
+  double* scal = nullptr;     // [16] device scalars, see CM_S_*
+  double* R = nullptr;        // [K]  sum_n mu_n lam_nk
+  uint8_t* colany = nullptr;  // [K]  any_n lam_nk >= spont_orthogonality
+  double* z = nullptr;        // [K]
+  double* mcE = nullptr;      // [N*CM_MAX_VALS] Monte-Carlo logit per (neuron, stimulus value)
+  double* rs = nullptr;       // [N*4] row stats: sum lam, sum lam^2, sum y*lam, (unused)
+  int32_t* act_idx = nullptr; // [N] active neurons (compact list)
+  int32_t* act_inv = nullptr; // [N] neuron -> compact index or -1
+  int32_t* n_act = nullptr;   // [4] device: N_a, flags
+  int32_t* order = nullptr;   // [N] sweep order of the current iteration
+  int32_t* perm_tmp = nullptr;// [N] ping-pong buffer of the shuffle rounds
+  uint32_t* sort_keys = nullptr; // [N] 32-bit sort keys of one shuffle round
+  uint32_t* keys = nullptr;   // [iters*(N+3)*2] threefry key schedule (host computed)
+  double* uexp = nullptr;     // explicit uniforms (device copy) or nullptr
+  int32_t* orders_exp = nullptr;
+  double* A = nullptr;        // [ld*ld] precision matrix / Cholesky factor
+  double* X = nullptr;        // [ld*ld] inverse factor
+  double* Dinv = nullptr;     // [ld*CM_TILE] inverses of the diagonal tiles
+  double* rhs = nullptr;      // [ld*2]
+  // histories
+  int32_t hist_iters = 0;
+  double *h_mu = nullptr, *h_beta = nullptr, *h_lam = nullptr, *h_shape = nullptr, *h_rate = nullptr,
+         *h_phi = nullptr, *h_phi_cov = nullptr, *h_z = nullptr;
+  bool ran = false;
+  int32_t keys_iters = 0;
+};
+
+enum {
+  CM_S_SHAPE = 0, CM_S_RATE = 1, CM_S_SPONT_RATE = 2, CM_S_SHAPE_PRIOR = 3, CM_S_RATE_PRIOR = 4, CM_S_ERR = 5,
+  CM_S_COUNT = 16
+};
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ double cm_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, CM_WAVE);
+  return v;
+}
+__device__ __forceinline__ int cm_wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, CM_WAVE);
+  return v;
+}
+__device__ __forceinline__ double cm_wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, CM_WAVE));
+  return v;
+}
+
+// jax.nn.sigmoid / scipy expit: 1 / (1 + exp(-x))
+__device__ __forceinline__ double cm_sigmoid(double x) { return 1.0 / (1.0 + exp(-x)); }
+
+// numpy nan_to_num for float64: nan -> 0, +-inf -> +-DBL_MAX
+__device__ __forceinline__ double cm_nan_to_num(double x) {
+  if (isnan(x)) return 0.0;
+  if (isinf(x)) return x > 0 ? 1.7976931348623157e308 : -1.7976931348623157e308;
+  return x;
+}
+
+// Threefry-2x32, 20 rounds (Salmon et al. 2011), the block function behind jax.random in the 0.3 series.
+__host__ __device__ __forceinline__ void cm_threefry2x32(uint32_t k0, uint32_t k1, uint32_t& x0, uint32_t& x1) {
+  const uint32_t ks0 = k0, ks1 = k1, ks2 = k0 ^ k1 ^ 0x1BD11BDAu;
+#define CM_TF_R(r)                      \
+  x0 += x1;                             \
+  x1 = (x1 << (r)) | (x1 >> (32 - (r))); \
+  x1 ^= x0;
+  x0 += ks0; x1 += ks1;
+  CM_TF_R(13) CM_TF_R(15) CM_TF_R(26) CM_TF_R(6)
+  x0 += ks1; x1 += ks2 + 1u;
+  CM_TF_R(17) CM_TF_R(29) CM_TF_R(16) CM_TF_R(24)
+  x0 += ks2; x1 += ks0 + 2u;
+  CM_TF_R(13) CM_TF_R(15) CM_TF_R(26) CM_TF_R(6)
+  x0 += ks0; x1 += ks1 + 3u;
+  CM_TF_R(17) CM_TF_R(29) CM_TF_R(16) CM_TF_R(24)
+  x0 += ks1; x1 += ks2 + 4u;
+  CM_TF_R(13) CM_TF_R(15) CM_TF_R(26) CM_TF_R(6)
+  x0 += ks2; x1 += ks0 + 5u;
+#undef CM_TF_R
+}
+#else
+inline void cm_threefry2x32(uint32_t k0, uint32_t k1, uint32_t& x0, uint32_t& x1) {
+  const uint32_t ks[3] = {k0, k1, k0 ^ k1 ^ 0x1BD11BDAu};
+  static const int R[2][4] = {{13, 15, 26, 6}, {17, 29, 16, 24}};
+  x0 += ks[0]; x1 += ks[1];
+  for (int g = 0; g < 5; ++g) {
+    for (int i = 0; i < 4; ++i) { int r = R[g % 2][i]; x0 += x1; x1 = (x1 << r) | (x1 >> (32 - r)); x1 ^= x0; }
+    x0 += ks[(g + 1) % 3]; x1 += ks[(g + 2) % 3] + (uint32_t)(g + 1);
+  }
+}
+#endif
+
+// ------------------------------------------------------------------------------------------------
+// phase launchers (each enqueues kernels on ctx->stream; no host sync unless stated)
+// ------------------------------------------------------------------------------------------------
+int cm_launch_psc_prologue(cm_ctx* ctx, int K, int T, const double* d_psc, double* d_y, double* d_ss);
+int cm_encode_stim(cm_ctx* ctx, cm_problem* p, const double* d_stim);               // syncs (sizes nnz)
+int cm_launch_init_state(cm_ctx* ctx, cm_problem* p, double y_xcorr_thresh);
+int cm_launch_scatter_dense_lam(cm_ctx* ctx, cm_problem* p, const double* d_lam_dense);
+int cm_launch_expand_lam(cm_ctx* ctx, cm_problem* p, const double* d_lam_sparse, double* d_dense);
+
+int cm_solve_mu(cm_ctx* ctx, cm_problem* p, int* n_active_out);                      // syncs once (active-set size)
+int cm_launch_rng(cm_ctx* ctx, cm_problem* p, int it, int S, int rng_mode, double* d_u_out);
+int cm_launch_mc_logit(cm_ctx* ctx, cm_problem* p, int it, int S, int rng_mode);
+int cm_launch_sweep(cm_ctx* ctx, cm_problem* p, int it, const cm_options* o);
+int cm_launch_post(cm_ctx* ctx, cm_problem* p, int it, const cm_options* o);
+int cm_launch_update_phi(cm_ctx* ctx, cm_problem* p);
+int cm_launch_col_stats(cm_ctx* ctx, cm_problem* p, double spont_orthogonality);
+
+void cm_host_key_schedule(uint64_t seed, int iters, int N, std::vector<uint32_t>& keys);
+int cm_perm_rounds(int N);
+double cm_host_pava_last(const double* y, int n);

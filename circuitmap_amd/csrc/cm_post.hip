@@ -1,0 +1,237 @@
+// Post-sweep phases of one CAVIaR iteration:
+//   update_sigma                      reference circuitmap/optimise/caviar.py:238-244
+//   update_phi / _laplace_approx      caviar.py:246-316
+//   estimate_spont_act_soft_thresh    caviar.py:147-163  (+ spont_rate, caviar.py:88)
+#include "cm_internal.h"
+
+// ------------------------------------------------------------------------------------------------
+// column statistics of the new lam: R_k = sum_n mu_n lam_nk (= lam.T @ mu), colany_k = any_n lam_nk >= spont_orthogonality
+// one thread per trial, entries in ascending neuron order (deterministic)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_col_stats(const double* __restrict__ lam, const double* __restrict__ mu,
+                                                    const int* __restrict__ col_ptr, const int* __restrict__ csc_row,
+                                                    const int* __restrict__ csc_pos, int K, double orth,
+                                                    double* __restrict__ R, uint8_t* __restrict__ colany) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  double s = 0.0;
+  int any = 0;
+  for (int ce = col_ptr[k]; ce < col_ptr[k + 1]; ++ce) {
+    const double l = lam[csc_pos[ce]];
+    s = fma(mu[csc_row[ce]], l, s);
+    any |= (l >= orth);
+  }
+  R[k] = s;
+  colany[k] = (uint8_t)any;
+}
+
+int cm_launch_col_stats(cm_ctx* ctx, cm_problem* p, double spont_orthogonality) {
+  hipLaunchKernelGGL(k_col_stats, dim3((p->K + 255) / 256), dim3(256), 0, ctx->stream, p->lam, p->mu, p->col_ptr, p->csc_row,
+                     p->csc_pos, p->K, spont_orthogonality, p->R, p->colany);
+  CM_HIP(hipGetLastError());
+  return CM_OK;
+}
+
+// block-wide sum (1024 threads), result valid in every thread
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+  v = cm_wave_sum(v);
+  __syncthreads();
+  if (threadIdx.x % CM_WAVE == 0) sh[threadIdx.x / CM_WAVE] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int w = 0; w < (int)(blockDim.x / CM_WAVE); ++w) t += sh[w];
+  return t;
+}
+
+// ------------------------------------------------------------------------------------------------
+// update_sigma + soft-threshold + spont_rate in one single-workgroup kernel (all O(K + N) reductions)
+//   rate = rate0 + 1/2 ( sum_k (y_k - R_k)^2 - sum_n mu_n^2 sum_k lam_nk^2 + sum_n (mu_n^2 + beta_n^2) sum_k lam_nk )
+//   z: <= (max_iters - it) penalty steps pen_j = penalty * scale^j while err > tol (loop counter seeded with the OUTER
+//      iteration index and err with sum(y), caviar.py:86; quirk 4: nothing happens once it >= max_iters)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_sigma_spont(const double* __restrict__ y, const double* __restrict__ R,
+                                                       const uint8_t* __restrict__ colany, const uint8_t* __restrict__ mask,
+                                                       const double* __restrict__ mu, const double* __restrict__ beta,
+                                                       const double* __restrict__ rs, const double* __restrict__ sum_y, int N, int K,
+                                                       int it, int max_iters, double penalty, double scale_factor, double tol,
+                                                       double* __restrict__ z, double* __restrict__ scal) {
+  __shared__ double sh[16];
+  // ---- update_sigma
+  double a = 0.0;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) { const double r = y[k] - R[k]; a = fma(r, r, a); }
+  double b = 0.0, c = 0.0;
+  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    const double m = mu[n], be = beta[n];
+    b = fma(m * m, rs[(size_t)n * 4 + 1], b);
+    c = fma(m * m + be * be, rs[(size_t)n * 4 + 0], c);
+  }
+  a = block_sum(a, sh); b = block_sum(b, sh); c = block_sum(c, sh);
+  if (threadIdx.x == 0) {
+    scal[CM_S_SHAPE] = scal[CM_S_SHAPE_PRIOR] + (double)K / 2.0;
+    scal[CM_S_RATE] = scal[CM_S_RATE_PRIOR] + 0.5 * (a - b + c);
+  }
+  // ---- estimate_spont_act_soft_thresh
+  double err = sum_y[0];
+  const double ysq = sum_y[1] + 1e-5;
+  double pen = penalty;
+  int itc = it;
+  bool ran = false;
+  while (itc < max_iters && err > tol) {
+    double e = 0.0;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+      const double resid = y[k] - R[k];
+      double zz = resid < pen ? 0.0 : resid - pen;
+      zz = zz < 0.0 ? 0.0 : zz;
+      zz = colany[k] ? 0.0 : zz;
+      zz *= (double)mask[k];
+      z[k] = zz;
+      const double d = resid - zz;
+      e = fma(d, d, e);
+    }
+    err = block_sum(e, sh) / ysq;
+    ++itc;
+    pen *= scale_factor;
+    ran = true;
+  }
+  (void)ran;
+  // ---- spont_rate = mean(z != 0)
+  __syncthreads();
+  double cnt = 0.0;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) cnt += (z[k] != 0.0) ? 1.0 : 0.0;
+  cnt = block_sum(cnt, sh);
+  if (threadIdx.x == 0) scal[CM_S_SPONT_RATE] = cnt / (double)K;
+}
+
+// ------------------------------------------------------------------------------------------------
+// update_phi: one wavefront per neuron.  The K-sums of the Newton iteration collapse onto per-stimulus-value
+// sufficient statistics because I[n,:] takes <= V distinct values; lane g owns value g.  nan_to_num is applied per
+// ELEMENT in the reference objective (quirk 11) so elements are classed by y == 0, y == 1, 0 < y < 1.
+// ------------------------------------------------------------------------------------------------
+struct Phi2 { double a, b; };
+
+__device__ __forceinline__ void inv2x2(double h11, double h12, double h21, double h22, double o[4]) {
+  // LU with partial pivoting on the 2x2 (what LAPACK getrf/getri do for jnp.linalg.inv)
+  double a = h11, b = h12, c = h21, d = h22;
+  bool sw = fabs(c) > fabs(a);
+  if (sw) { double t = a; a = c; c = t; t = b; b = d; d = t; }
+  const double l = c / a;
+  const double u22 = d - l * b;
+  // solve for unit vectors (with row swap applied to the right-hand side)
+  // column 0 of inverse: rhs = P e0
+  double r0 = sw ? 0.0 : 1.0, r1 = sw ? 1.0 : 0.0;
+  double y1 = r1 - l * r0;
+  double x1 = y1 / u22;
+  double x0 = (r0 - b * x1) / a;
+  o[0] = x0; o[2] = x1;
+  r0 = sw ? 1.0 : 0.0; r1 = sw ? 0.0 : 1.0;
+  y1 = r1 - l * r0;
+  x1 = y1 / u22;
+  x0 = (r0 - b * x1) / a;
+  o[1] = x0; o[3] = x1;
+}
+
+__device__ __forceinline__ double phi_nll(double p0, double p1, double val, double n0, double n1, double smid, double nmid,
+                                          bool lane_on, double pr0, double pr1, const double prec[4], double t) {
+  double tot = 0.0;
+  if (lane_on) {
+    const double s = cm_sigmoid(p0 * val - p1);
+    const double ls = log(s), l1s = log(1.0 - s);
+    if (n0 > 0.0) tot += n0 * cm_nan_to_num(0.0 * ls + 1.0 * l1s);
+    if (n1 > 0.0) tot += n1 * cm_nan_to_num(1.0 * ls + 0.0 * l1s);
+    if (nmid > 0.0) {
+      if (isfinite(ls) && isfinite(l1s)) tot += smid * ls + (nmid - smid) * l1s;
+      else tot += nmid * cm_nan_to_num(0.5 * ls + 0.5 * l1s);
+    }
+  }
+  tot = cm_wave_sum(tot);
+  const double d0 = p0 - pr0, d1 = p1 - pr1;
+  const double quad = d0 * (prec[0] * d0 + prec[1] * d1) + d1 * (prec[2] * d0 + prec[3] * d1);
+  return -tot - (log(p0) + log(p1)) / t + 0.5 * quad;
+}
+
+__global__ __launch_bounds__(256) void k_update_phi(const double* __restrict__ lam, const int* __restrict__ row_ptr,
+                                                     const uint8_t* __restrict__ grp, const int* __restrict__ rowcnt,
+                                                     const double* __restrict__ vals, int V, int N,
+                                                     const double* __restrict__ phi_prior, const double* __restrict__ phi_cov_prior,
+                                                     double* __restrict__ phi, double* __restrict__ phi_cov) {
+  const int n = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE;
+  const int lane = threadIdx.x % CM_WAVE;
+  if (n >= N) return;
+  // sufficient statistics for value `lane`
+  const bool on = lane < V;
+  const double val = on ? vals[lane] : 0.0;
+  const double cnt = on ? (double)rowcnt[(size_t)n * CM_MAX_VALS + lane] : 0.0;
+  double n1 = 0.0, nmid = 0.0, smid = 0.0;
+  const int beg = row_ptr[n], end = row_ptr[n + 1];
+  for (int g = 0; g < V; ++g) {
+    if (!(vals[g] > 0.0)) continue;       // untargeted values carry lam == 0 on every trial
+    double c1 = 0.0, cm = 0.0, sm = 0.0;
+    for (int e = beg + lane; e < end; e += CM_WAVE) {
+      if (grp[e] != g) continue;
+      const double l = lam[e];
+      if (l == 1.0) c1 += 1.0;
+      else if (l > 0.0 && l < 1.0) { cm += 1.0; sm += l; }
+    }
+    c1 = cm_wave_sum(c1); cm = cm_wave_sum(cm); sm = cm_wave_sum(sm);
+    if (lane == g) { n1 = c1; nmid = cm; smid = sm; }
+  }
+  const double n0 = cnt - n1 - nmid;
+  const double sy = n1 + smid;
+
+  const double pr0 = phi_prior[2 * n], pr1 = phi_prior[2 * n + 1];
+  double prec[4];
+  inv2x2(phi_cov_prior[4 * n], phi_cov_prior[4 * n + 1], phi_cov_prior[4 * n + 2], phi_cov_prior[4 * n + 3], prec);   // caviar.py:306
+  const double t = 1e1, alpha = 0.25, bbeta = 0.5;
+  double p0 = pr0, p1 = pr1;                     // caviar.py:305: restart from the prior every call (quirk 3)
+  double cov[4] = {0, 0, 0, 0};
+  for (int stepi = 0; stepi < 10; ++stepi) {     // caviar.py:308
+    double j1 = 0.0, j2 = 0.0, h11 = 0.0, h12 = 0.0, h22 = 0.0;
+    if (on) {
+      const double f = cm_sigmoid(p0 * val - p1);
+      const double r = sy - cnt * f;
+      j1 = -val * r; j2 = r;
+      const double ff = cnt * f * (1.0 - f);
+      h11 = val * val * ff; h12 = -val * ff; h22 = ff;
+    }
+    j1 = cm_wave_sum(j1); j2 = cm_wave_sum(j2);
+    h11 = cm_wave_sum(h11); h12 = cm_wave_sum(h12); h22 = cm_wave_sum(h22);
+    const double d0 = p0 - pr0, d1 = p1 - pr1;
+    const double J0 = j1 + (prec[0] * d0 + prec[1] * d1) - 1.0 / (t * p0);      // caviar.py:278-280
+    const double J1 = j2 + (prec[2] * d0 + prec[3] * d1) - 1.0 / (t * p1);
+    inv2x2(h11 + prec[0] + 1.0 / (t * p0 * p0), h12 + prec[1], h12 + prec[2], h22 + prec[3] + 1.0 / (t * p1 * p1), cov);   // :283-289
+    const double v0 = -(cov[0] * J0 + cov[1] * J1), v1 = -(cov[2] * J0 + cov[3] * J1);
+    const double Jv = J0 * v0 + J1 * v1;
+    double step = 1.0;
+    const double f0 = phi_nll(p0, p1, val, n0, n1, smid, nmid, on, pr0, pr1, prec, t);
+    double lhs = phi_nll(p0 + step * v0, p1 + step * v1, val, n0, n1, smid, nmid, on, pr0, pr1, prec, t);
+    double rhs = f0 + alpha * step * Jv;
+    int bt = 0;
+    while (bt < 40 && (isnan(lhs) || lhs > rhs)) {                                // caviar.py:259-268
+      ++bt;
+      step *= bbeta;
+      lhs = phi_nll(p0 + step * v0, p1 + step * v1, val, n0, n1, smid, nmid, on, pr0, pr1, prec, t);
+      rhs = f0 + alpha * step * Jv;
+    }
+    p0 += step * v0; p1 += step * v1;                                             // caviar.py:301
+  }
+  if (lane == 0) {
+    phi[2 * n] = p0; phi[2 * n + 1] = p1;
+    phi_cov[4 * n] = cov[0]; phi_cov[4 * n + 1] = cov[1]; phi_cov[4 * n + 2] = cov[2]; phi_cov[4 * n + 3] = cov[3];
+  }
+}
+
+int cm_launch_update_phi(cm_ctx* ctx, cm_problem* p) {
+  hipLaunchKernelGGL(k_update_phi, dim3((p->N + 3) / 4), dim3(256), 0, ctx->stream, p->lam, p->row_ptr, p->grp, p->rowcnt, p->vals, p->V,
+                     p->N, p->phi_prior, p->phi_cov_prior, p->phi, p->phi_cov);
+  CM_HIP(hipGetLastError());
+  return CM_OK;
+}
+
+int cm_launch_post(cm_ctx* ctx, cm_problem* p, int it, const cm_options* o) {
+  CM_TRY(cm_launch_col_stats(ctx, p, o->spont_orthogonality));
+  hipLaunchKernelGGL(k_sigma_spont, dim3(1), dim3(1024), 0, ctx->stream, p->y, p->R, p->colany, p->mask, p->mu, p->beta, p->rs, p->sum_y,
+                     p->N, p->K, it, o->max_backtrack_iters, o->penalty, o->scale_factor, o->tol, p->z, p->scal);
+  CM_HIP(hipGetLastError());
+  CM_TRY(cm_launch_update_phi(ctx, p));
+  return CM_OK;
+}

@@ -1,0 +1,328 @@
+// One-off prologue kernels: PSC integrals and the compressed encoding of the stimulus matrix.
+// Replaces reference circuitmap/optimise/caviar.py:28-51 (prologue of caviar()).
+#include "cm_internal.h"
+
+// ------------------------------------------------------------------------------------------------
+// y[k] = trapz(psc[k,:]) (unit spacing), ss[k] = sum_t psc[k,t]^2        caviar.py:28,30
+// One wavefront per trial row; lanes stride the row so every wave-load is 512 contiguous bytes.
+// HBM-bound: reads K*T*8 bytes once.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_psc_prologue(const double* __restrict__ psc, int K, int T,
+                                                       double* __restrict__ y, double* __restrict__ ss) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE;
+  const int lane = threadIdx.x % CM_WAVE;
+  if (wave >= K) return;
+  const double* row = psc + (size_t)wave * T;
+  double tz = 0.0, sq = 0.0;
+  for (int t = lane; t < T; t += CM_WAVE) {
+    const double x = row[t];
+    sq = fma(x, x, sq);
+    if (t + 1 < T) tz += (x + row[t + 1]) * 0.5;   // np.trapz: sum_i (x[i] + x[i+1]) / 2
+  }
+  tz = cm_wave_sum(tz);
+  sq = cm_wave_sum(sq);
+  if (lane == 0) { y[wave] = tz; ss[wave] = sq; }
+}
+
+__global__ __launch_bounds__(1024) void k_sum_y(const double* __restrict__ y, int K, double* __restrict__ out) {
+  __shared__ double s0[16], s1[16];
+  double a = 0.0, b = 0.0;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) { a += y[k]; b = fma(y[k], y[k], b); }
+  a = cm_wave_sum(a); b = cm_wave_sum(b);
+  if (threadIdx.x % CM_WAVE == 0) { s0[threadIdx.x / CM_WAVE] = a; s1[threadIdx.x / CM_WAVE] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ta = 0.0, tb = 0.0;
+    for (int w = 0; w < (int)(blockDim.x / CM_WAVE); ++w) { ta += s0[w]; tb += s1[w]; }
+    out[0] = ta; out[1] = tb;
+  }
+}
+
+int cm_launch_psc_prologue(cm_ctx* ctx, int K, int T, const double* d_psc, double* d_y, double* d_ss) {
+  const int waves_per_block = 256 / CM_WAVE;
+  const int blocks = (K + waves_per_block - 1) / waves_per_block;
+  hipLaunchKernelGGL(k_psc_prologue, dim3(blocks), dim3(256), 0, ctx->stream, d_psc, K, T, d_y, d_ss);
+  CM_HIP(hipGetLastError());
+  return CM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Distinct values of the stimulus matrix (np.unique(I), caviar.py:42).  Append-only set in global
+// memory claimed by 64-bit CAS; each workgroup filters through an LDS copy so that the >99 % zero
+// entries never touch the global table.
+// ------------------------------------------------------------------------------------------------
+#define CM_EMPTY 0xFFFFFFFFFFFFFFFFull
+
+__device__ __forceinline__ bool cm_set_insert(unsigned long long* table, int cap, unsigned long long bits, bool* is_new) {
+  for (int s = 0; s < cap; ++s) {
+    unsigned long long cur = *(volatile unsigned long long*)&table[s];   // plain read first: same-address reads broadcast
+    if (cur == bits) { *is_new = false; return true; }
+    if (cur == CM_EMPTY) {
+      cur = atomicCAS(&table[s], CM_EMPTY, bits);
+      if (cur == CM_EMPTY) { *is_new = true; return true; }
+      if (cur == bits) { *is_new = false; return true; }
+    }
+  }
+  return false;
+}
+
+__global__ __launch_bounds__(256) void k_stim_distinct(const double* __restrict__ stim, size_t n,
+                                                        unsigned long long* __restrict__ table, int* __restrict__ overflow) {
+  __shared__ unsigned long long cache[CM_MAX_VALS];
+  for (int i = threadIdx.x; i < CM_MAX_VALS; i += blockDim.x) cache[i] = CM_EMPTY;
+  __syncthreads();
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    double v = stim[i] + 0.0;   // -0.0 -> +0.0 (np.unique compares by value)
+    unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    bool is_new = false;
+    if (!cm_set_insert(cache, CM_MAX_VALS, bits, &is_new)) { *overflow = 1; continue; }
+    if (is_new) {
+      bool g_new;
+      if (!cm_set_insert(table, CM_MAX_VALS, bits, &g_new)) *overflow = 1;
+    }
+  }
+}
+
+__global__ void k_vals_finalize(const unsigned long long* __restrict__ table, double* __restrict__ vals, int* __restrict__ nvals) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int n = 0;
+  for (int s = 0; s < CM_MAX_VALS; ++s) {
+    if (table[s] == CM_EMPTY) continue;
+    double v = __longlong_as_double((long long)table[s]);
+    int j = n++;
+    while (j > 0 && vals[j - 1] > v) { vals[j] = vals[j - 1]; --j; }
+    vals[j] = v;
+  }
+  for (int s = n; s < CM_MAX_VALS; ++s) vals[s] = 0.0;
+  *nvals = n;
+}
+
+__device__ __forceinline__ int cm_val_index(const double* vals, int V, double v) {
+  for (int g = 0; g < V; ++g) if (vals[g] == v) return g;
+  return 0;
+}
+
+// per-row counts of each distinct value and of targeted (stim > 0) trials; one wave per row
+__global__ __launch_bounds__(256) void k_stim_rowcount(const double* __restrict__ stim, int N, int K, const double* __restrict__ vals_g,
+                                                        const int* __restrict__ nvals, int* __restrict__ rowcnt, int* __restrict__ row_nnz) {
+  __shared__ double vals[CM_MAX_VALS];
+  const int V = *nvals;
+  if (threadIdx.x < CM_MAX_VALS) vals[threadIdx.x] = vals_g[threadIdx.x];
+  __syncthreads();
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE;
+  const int lane = threadIdx.x % CM_WAVE;
+  if (wave >= N) return;
+  const double* row = stim + (size_t)wave * K;
+  int nz = 0;
+  for (int g0 = 0; g0 < V; g0 += 8) {     // count 8 groups per pass over the (cache-resident) row
+    int c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = lane; k < K; k += CM_WAVE) {
+      const double v = row[k];
+      if (g0 == 0) nz += (v > 0.0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) c[j] += (g0 + j < V && v == vals[g0 + j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int t = cm_wave_sum_i(c[j]);
+      if (lane == 0 && g0 + j < V) rowcnt[(size_t)wave * CM_MAX_VALS + g0 + j] = t;
+    }
+  }
+  nz = cm_wave_sum_i(nz);
+  if (lane == 0) row_nnz[wave] = nz;
+}
+
+// exclusive scan of n counts into ptr[0..n]; single workgroup
+__global__ __launch_bounds__(1024) void k_exclusive_scan(const int* __restrict__ cnt, int n, int* __restrict__ ptr) {
+  __shared__ int part[1024];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    int i = base + threadIdx.x;
+    int v = i < n ? cnt[i] : 0;
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      int t = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+      __syncthreads();
+      part[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < n) ptr[i] = carry + part[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += part[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) ptr[n] = carry;
+}
+
+// CSR fill, one wave per row, ordered compaction by ballot prefix
+__global__ __launch_bounds__(256) void k_stim_fill_csr(const double* __restrict__ stim, int N, int K, const double* __restrict__ vals_g,
+                                                        const int* __restrict__ nvals, const int* __restrict__ row_ptr,
+                                                        int* __restrict__ col, uint8_t* __restrict__ grp) {
+  __shared__ double vals[CM_MAX_VALS];
+  const int V = *nvals;
+  if (threadIdx.x < CM_MAX_VALS) vals[threadIdx.x] = vals_g[threadIdx.x];
+  __syncthreads();
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE;
+  const int lane = threadIdx.x % CM_WAVE;
+  if (wave >= N) return;
+  const double* row = stim + (size_t)wave * K;
+  int base = row_ptr[wave];
+  for (int k0 = 0; k0 < K; k0 += CM_WAVE) {
+    const int k = k0 + lane;
+    const double v = k < K ? row[k] : 0.0;
+    const bool t = v > 0.0;
+    const unsigned long long m = __ballot(t);
+    if (t) {
+      const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+      col[pos] = k;
+      grp[pos] = (uint8_t)cm_val_index(vals, V, v + 0.0);
+    }
+    base += __popcll(m);
+  }
+}
+
+// CSC: one thread per trial column walks the rows in order (coalesced across the wave), so each
+// column's entries come out sorted by neuron -> deterministic summation order downstream.
+__global__ __launch_bounds__(256) void k_stim_colcount(const double* __restrict__ stim, int N, int K, int* __restrict__ col_cnt) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  int c = 0;
+  for (int n = 0; n < N; ++n) c += (stim[(size_t)n * K + k] > 0.0);
+  col_cnt[k] = c;
+}
+
+__global__ __launch_bounds__(256) void k_stim_fill_csc(const double* __restrict__ stim, int N, int K, const int* __restrict__ col_ptr,
+                                                        const int* __restrict__ row_ptr, const int* __restrict__ col,
+                                                        int* __restrict__ csc_row, int* __restrict__ csc_pos) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  int w = col_ptr[k];
+  for (int n = 0; n < N; ++n) {
+    if (stim[(size_t)n * K + k] > 0.0) {
+      int lo = row_ptr[n], hi = row_ptr[n + 1] - 1;   // binary search of k in the row's sorted trial list
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (col[mid] < k) lo = mid + 1; else hi = mid;
+      }
+      csc_row[w] = n;
+      csc_pos[w] = lo;
+      ++w;
+    }
+  }
+}
+
+int cm_encode_stim(cm_ctx* ctx, cm_problem* p, const double* d_stim) {
+  const int N = p->N, K = p->K;
+  hipStream_t st = ctx->stream;
+  unsigned long long* d_table = nullptr;
+  int *d_flags = nullptr, *d_row_nnz = nullptr, *d_col_cnt = nullptr;
+  CM_HIP(hipMalloc(&d_table, CM_MAX_VALS * sizeof(unsigned long long)));
+  CM_HIP(hipMalloc(&d_flags, 4 * sizeof(int)));
+  CM_HIP(hipMalloc(&d_row_nnz, (size_t)N * sizeof(int)));
+  CM_HIP(hipMalloc(&d_col_cnt, (size_t)K * sizeof(int)));
+  CM_HIP(hipMemsetAsync(d_table, 0xFF, CM_MAX_VALS * sizeof(unsigned long long), st));
+  CM_HIP(hipMemsetAsync(d_flags, 0, 4 * sizeof(int), st));
+  CM_HIP(hipMalloc(&p->vals, CM_MAX_VALS * sizeof(double)));
+  CM_HIP(hipMalloc(&p->rowcnt, (size_t)N * CM_MAX_VALS * sizeof(int)));
+  CM_HIP(hipMemsetAsync(p->rowcnt, 0, (size_t)N * CM_MAX_VALS * sizeof(int), st));
+  CM_HIP(hipMalloc(&p->row_ptr, (size_t)(N + 1) * sizeof(int)));
+  CM_HIP(hipMalloc(&p->col_ptr, (size_t)(K + 1) * sizeof(int)));
+
+  const size_t total = (size_t)N * K;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > ctx->num_cus * 8) blocks = ctx->num_cus * 8;
+  hipLaunchKernelGGL(k_stim_distinct, dim3(blocks), dim3(256), 0, st, d_stim, total, d_table, d_flags);
+  hipLaunchKernelGGL(k_vals_finalize, dim3(1), dim3(64), 0, st, d_table, p->vals, d_flags + 1);
+  const int row_blocks = (N + 3) / 4;
+  hipLaunchKernelGGL(k_stim_rowcount, dim3(row_blocks), dim3(256), 0, st, d_stim, N, K, p->vals, d_flags + 1, p->rowcnt, d_row_nnz);
+  hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, st, d_row_nnz, N, p->row_ptr);
+  hipLaunchKernelGGL(k_stim_colcount, dim3((K + 255) / 256), dim3(256), 0, st, d_stim, N, K, d_col_cnt);
+  hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, st, d_col_cnt, K, p->col_ptr);
+  CM_HIP(hipGetLastError());
+
+  int h_flags[4];
+  p->h_row_ptr.resize(N + 1);
+  CM_HIP(hipMemcpyAsync(h_flags, d_flags, sizeof(h_flags), hipMemcpyDeviceToHost, st));
+  CM_HIP(hipMemcpyAsync(p->h_row_ptr.data(), p->row_ptr, (size_t)(N + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
+  CM_HIP(hipStreamSynchronize(st));
+  if (h_flags[0]) {
+    hipFree(d_table); hipFree(d_flags); hipFree(d_row_nnz); hipFree(d_col_cnt);
+    cm_set_error("stimulus matrix has more than %d distinct values", CM_MAX_VALS);
+    return CM_ERR_TOO_MANY_POWERS;
+  }
+  p->V = h_flags[1];
+  p->nnz = p->h_row_ptr[N];
+  const size_t nnz_alloc = p->nnz > 0 ? (size_t)p->nnz : 1;
+  CM_HIP(hipMalloc(&p->col, nnz_alloc * sizeof(int)));
+  CM_HIP(hipMalloc(&p->grp, nnz_alloc));
+  CM_HIP(hipMalloc(&p->csc_row, nnz_alloc * sizeof(int)));
+  CM_HIP(hipMalloc(&p->csc_pos, nnz_alloc * sizeof(int)));
+  hipLaunchKernelGGL(k_stim_fill_csr, dim3(row_blocks), dim3(256), 0, st, d_stim, N, K, p->vals, d_flags + 1, p->row_ptr, p->col, p->grp);
+  hipLaunchKernelGGL(k_stim_fill_csc, dim3((K + 255) / 256), dim3(256), 0, st, d_stim, N, K, p->col_ptr, p->row_ptr, p->col,
+                     p->csc_row, p->csc_pos);
+  CM_HIP(hipGetLastError());
+  p->h_col.resize(nnz_alloc);
+  p->h_grp.resize(nnz_alloc);
+  p->h_vals.resize(CM_MAX_VALS);
+  CM_HIP(hipMemcpyAsync(p->h_col.data(), p->col, (size_t)p->nnz * sizeof(int), hipMemcpyDeviceToHost, st));
+  CM_HIP(hipMemcpyAsync(p->h_grp.data(), p->grp, (size_t)p->nnz, hipMemcpyDeviceToHost, st));
+  CM_HIP(hipMemcpyAsync(p->h_vals.data(), p->vals, CM_MAX_VALS * sizeof(double), hipMemcpyDeviceToHost, st));
+  CM_HIP(hipStreamSynchronize(st));
+  hipFree(d_table); hipFree(d_flags); hipFree(d_row_nnz); hipFree(d_col_cnt);
+  return CM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// state init: lam_mask = ss > thresh; lam0 = 0.95 * [I > 0] * mask (caviar.py:30-34); z = 0 (caviar.py:50)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_init_mask(const double* __restrict__ ss, int K, double thresh, uint8_t* __restrict__ mask,
+                                                    double* __restrict__ z) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < K) { mask[k] = ss[k] > thresh; z[k] = 0.0; }
+}
+__global__ __launch_bounds__(256) void k_init_lam(const int* __restrict__ col, const uint8_t* __restrict__ mask, long long nnz,
+                                                   double* __restrict__ lam) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < nnz) lam[e] = 0.95 * (double)mask[col[e]];
+}
+
+int cm_launch_init_state(cm_ctx* ctx, cm_problem* p, double y_xcorr_thresh) {
+  hipStream_t st = ctx->stream;
+  hipLaunchKernelGGL(k_init_mask, dim3((p->K + 255) / 256), dim3(256), 0, st, p->ss, p->K, y_xcorr_thresh, p->mask, p->z);
+  if (p->nnz > 0)
+    hipLaunchKernelGGL(k_init_lam, dim3((unsigned)((p->nnz + 255) / 256)), dim3(256), 0, st, p->col, p->mask, (long long)p->nnz, p->lam);
+  hipLaunchKernelGGL(k_sum_y, dim3(1), dim3(1024), 0, st, p->y, p->K, p->sum_y);
+  CM_HIP(hipGetLastError());
+  return CM_OK;
+}
+
+// dense <-> compressed lam (targeted entries only; everything else is identically zero, caviar.py:216)
+__global__ __launch_bounds__(256) void k_scatter_dense(const double* __restrict__ dense, int N, int K, const int* __restrict__ row_ptr,
+                                                        const int* __restrict__ col, double* __restrict__ lam) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE;
+  const int lane = threadIdx.x % CM_WAVE;
+  if (wave >= N) return;
+  for (int e = row_ptr[wave] + lane; e < row_ptr[wave + 1]; e += CM_WAVE) lam[e] = dense[(size_t)wave * K + col[e]];
+}
+__global__ __launch_bounds__(256) void k_expand_dense(const double* __restrict__ lam, int N, int K, const int* __restrict__ row_ptr,
+                                                       const int* __restrict__ col, double* __restrict__ dense) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE;
+  const int lane = threadIdx.x % CM_WAVE;
+  if (wave >= N) return;
+  for (int e = row_ptr[wave] + lane; e < row_ptr[wave + 1]; e += CM_WAVE) dense[(size_t)wave * K + col[e]] = lam[e];
+}
+
+int cm_launch_scatter_dense_lam(cm_ctx* ctx, cm_problem* p, const double* d_lam_dense) {
+  hipLaunchKernelGGL(k_scatter_dense, dim3((p->N + 3) / 4), dim3(256), 0, ctx->stream, d_lam_dense, p->N, p->K, p->row_ptr, p->col, p->lam);
+  CM_HIP(hipGetLastError());
+  return CM_OK;
+}
+int cm_launch_expand_lam(cm_ctx* ctx, cm_problem* p, const double* d_lam_sparse, double* d_dense) {
+  CM_HIP(hipMemsetAsync(d_dense, 0, (size_t)p->N * p->K * sizeof(double), ctx->stream));
+  hipLaunchKernelGGL(k_expand_dense, dim3((p->N + 3) / 4), dim3(256), 0, ctx->stream, d_lam_sparse, p->N, p->K, p->row_ptr, p->col, d_dense);
+  CM_HIP(hipGetLastError());
+  return CM_OK;
+}

@@ -1,0 +1,406 @@
+// Weight posterior (mu, beta): replaces block_update_mu, reference circuitmap/optimise/caviar.py:166-172.
+//
+//   Sigma^-1 = sigma * (D + L) + diag(1/beta0^2),  L = lam lam^T,  D = diag(sum_k lam(1-lam)),  sigma = shape/rate
+//   mu = Sigma (sigma * lam y + mu0/beta0^2),  beta = diag(Sigma)          (the reference's "beta" is a variance)
+//
+// MI355X design: rows with lam == 0 decouple exactly (mu = mu0, beta = beta0^2), so the dense fp64 system is built
+// only over the ACTIVE set (compacted, ascending neuron order).  L is assembled from the compressed stimulus
+// encoding (each trial column couples only the neurons targeted together), then factored by a right-looking
+// blocked Cholesky on 32x32 tiles; L^-1 comes from recursive doubling of triangular blocks (GEMM-shaped),
+// and mu, diag(Sigma) are column reductions of L^-1.  Everything fp64: the early iterations are
+// ill-conditioned enough (SURVEY 8c / tests) that fp32 would not hold the 1e-4 parity target.
+#include "cm_internal.h"
+
+#define TS CM_TILE
+#define TP (CM_TILE + 1)   // padded LDS row (doubles)
+
+// ------------------------------------------------------------------------------------------------
+// row statistics + active flags (one wave per row)
+// rs[n] = {sum lam, sum lam^2, sum y*lam, any(lam != 0)}
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_row_stats(const double* __restrict__ lam, const int* __restrict__ row_ptr,
+                                                    const int* __restrict__ col, const double* __restrict__ y, int N,
+                                                    double* __restrict__ rs) {
+  const int n = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE;
+  const int lane = threadIdx.x % CM_WAVE;
+  if (n >= N) return;
+  double s1 = 0.0, s2 = 0.0, sy = 0.0, d = 0.0;
+  int any = 0;
+  for (int e = row_ptr[n] + lane; e < row_ptr[n + 1]; e += CM_WAVE) {
+    const double l = lam[e];
+    s1 += l;
+    s2 = fma(l, l, s2);
+    sy = fma(y[col[e]], l, sy);
+    d = fma(l, 1.0 - l, d);
+    any |= (l != 0.0);
+  }
+  s1 = cm_wave_sum(s1); s2 = cm_wave_sum(s2); sy = cm_wave_sum(sy); d = cm_wave_sum(d);
+  any = __any(any);
+  if (lane == 0) {
+    rs[(size_t)n * 4 + 0] = s1;
+    rs[(size_t)n * 4 + 1] = s2;
+    rs[(size_t)n * 4 + 2] = sy;
+    rs[(size_t)n * 4 + 3] = any ? d : -1.0;   // sum lam(1-lam) for active rows, -1 marks an all-zero row
+  }
+}
+
+// ordered compaction of the active rows; single workgroup
+__global__ __launch_bounds__(1024) void k_active_compact(const double* __restrict__ rs, int N, int* __restrict__ act_idx,
+                                                          int* __restrict__ act_inv, int* __restrict__ n_act) {
+  __shared__ int wave_cnt[16];
+  __shared__ int base;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  const int lane = threadIdx.x % CM_WAVE, w = threadIdx.x / CM_WAVE;
+  for (int n0 = 0; n0 < N; n0 += 1024) {
+    const int n = n0 + threadIdx.x;
+    const bool a = n < N && rs[(size_t)n * 4 + 3] >= 0.0;
+    const unsigned long long m = __ballot(a);
+    if (lane == 0) wave_cnt[w] = __popcll(m);
+    __syncthreads();
+    int off = base;
+    for (int i = 0; i < w; ++i) off += wave_cnt[i];
+    if (n < N) {
+      if (a) {
+        const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+        act_idx[pos] = n;
+        act_inv[n] = pos;
+      } else {
+        act_inv[n] = -1;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int i = 0; i < 16; ++i) t += wave_cnt[i]; base += t; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) n_act[0] = base;
+}
+
+// ------------------------------------------------------------------------------------------------
+// precision matrix over the active set; one wave per (padded) row, accumulator row in LDS
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_build_precision(const double* __restrict__ lam, const int* __restrict__ row_ptr,
+                                                         const int* __restrict__ col, const int* __restrict__ col_ptr,
+                                                         const int* __restrict__ csc_row, const int* __restrict__ csc_pos,
+                                                         const int* __restrict__ act_idx, const int* __restrict__ act_inv,
+                                                         const double* __restrict__ rs, const double* __restrict__ scal,
+                                                         const double* __restrict__ mu_prior, const double* __restrict__ beta_prior,
+                                                         int n_act, int ld, double* __restrict__ A, double* __restrict__ rhs) {
+  extern __shared__ double acc[];   // [ld]
+  const int a = blockIdx.x;
+  const int lane = threadIdx.x;
+  double* Arow = A + (size_t)a * ld;
+  if (a >= n_act) {                 // identity padding up to the tile multiple
+    for (int b = lane; b < ld; b += CM_WAVE) Arow[b] = (b == a) ? 1.0 : 0.0;
+    if (lane == 0) rhs[a] = 0.0;
+    return;
+  }
+  for (int b = lane; b < ld; b += CM_WAVE) acc[b] = 0.0;
+  const int n = act_idx[a];
+  const double sig = scal[CM_S_SHAPE] / scal[CM_S_RATE];
+  for (int e = row_ptr[n]; e < row_ptr[n + 1]; ++e) {      // sequential over this neuron's trials: fixed summation order
+    const double le = lam[e];
+    if (le == 0.0) continue;
+    const int k = col[e];
+    for (int ce = col_ptr[k] + lane; ce < col_ptr[k + 1]; ce += CM_WAVE) {   // co-targeted neurons: distinct -> no conflicts
+      const int b = act_inv[csc_row[ce]];
+      if (b >= 0) acc[b] = fma(le, lam[csc_pos[ce]], acc[b]);
+    }
+  }
+  const double b0 = beta_prior[n];
+  const double prec0 = 1.0 / (b0 * b0);
+  for (int b = lane; b < ld; b += CM_WAVE) {
+    double v = 0.0;
+    if (b < n_act) v = (b == a) ? sig * (rs[(size_t)n * 4 + 3] + acc[b]) + prec0 : sig * acc[b];
+    Arow[b] = v;
+  }
+  if (lane == 0) rhs[a] = sig * rs[(size_t)n * 4 + 2] + prec0 * mu_prior[n];
+}
+
+// ------------------------------------------------------------------------------------------------
+// 32x32 tile helpers (256 threads, each owns a 2x2 patch)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tile_load(double (*dst)[TP], const double* __restrict__ src, int ld) {
+  for (int i = threadIdx.x; i < TS * TS; i += 256) dst[i / TS][i % TS] = src[(size_t)(i / TS) * ld + (i % TS)];
+}
+__device__ __forceinline__ void tile_store(double* __restrict__ dst, int ld, const double (*src)[TP]) {
+  for (int i = threadIdx.x; i < TS * TS; i += 256) dst[(size_t)(i / TS) * ld + (i % TS)] = src[i / TS][i % TS];
+}
+// c[2][2] += A(rows r0..r0+1, :) * B(rows c0..c0+1, :)^T
+__device__ __forceinline__ void tile_mma_nt(double c[2][2], const double (*A)[TP], const double (*B)[TP], int r0, int c0) {
+#pragma unroll 8
+  for (int k = 0; k < TS; ++k) {
+    const double a0 = A[r0][k], a1 = A[r0 + 1][k], b0 = B[c0][k], b1 = B[c0 + 1][k];
+    c[0][0] = fma(a0, b0, c[0][0]); c[0][1] = fma(a0, b1, c[0][1]);
+    c[1][0] = fma(a1, b0, c[1][0]); c[1][1] = fma(a1, b1, c[1][1]);
+  }
+}
+// c[2][2] += A(rows r0.., :) * B(:, cols c0..)
+__device__ __forceinline__ void tile_mma_nn(double c[2][2], const double (*A)[TP], const double (*B)[TP], int r0, int c0) {
+#pragma unroll 8
+  for (int k = 0; k < TS; ++k) {
+    const double a0 = A[r0][k], a1 = A[r0 + 1][k], b0 = B[k][c0], b1 = B[k][c0 + 1];
+    c[0][0] = fma(a0, b0, c[0][0]); c[0][1] = fma(a0, b1, c[0][1]);
+    c[1][0] = fma(a1, b0, c[1][0]); c[1][1] = fma(a1, b1, c[1][1]);
+  }
+}
+
+// In-LDS Cholesky of a 32x32 tile + inverse of its factor.  C holds the SPD tile on entry, L on exit (upper part
+// zeroed); Li receives L^-1 (lower triangular).  256 threads.
+__device__ void tile_potrf_inv(double (*C)[TP], double (*Li)[TP], int* __restrict__ flag) {
+  const int tid = threadIdx.x;
+  for (int c = 0; c < TS; ++c) {
+    __syncthreads();
+    const double d = C[c][c];
+    if (tid == 0 && !(d > 0.0)) *flag = 1;       // not SPD (also catches NaN)
+    const double s = sqrt(d);
+    __syncthreads();
+    if (tid >= c && tid < TS) C[tid][c] = (tid == c) ? s : C[tid][c] / s;
+    __syncthreads();
+    // trailing update: rows r > c, cols c < cc <= r
+    for (int i = tid; i < TS * TS; i += 256) {
+      const int r = i / TS, cc = i % TS;
+      if (cc > c && r >= cc) C[r][cc] = fma(-C[r][c], C[cc][c], C[r][cc]);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < TS * TS; i += 256) {
+    const int r = i / TS, cc = i % TS;
+    if (cc > r) C[r][cc] = 0.0;
+    Li[r][cc] = 0.0;
+  }
+  __syncthreads();
+  if (tid < TS) {                                 // column tid of L^-1 by forward substitution
+    const int c = tid;
+    Li[c][c] = 1.0 / C[c][c];
+    for (int r = c + 1; r < TS; ++r) {
+      double s = 0.0;
+      for (int j = c; j < r; ++j) s = fma(C[r][j], Li[j][c], s);
+      Li[r][c] = -s / C[r][r];
+    }
+  }
+  __syncthreads();
+}
+
+// factor the first diagonal tile
+__global__ __launch_bounds__(256) void k_chol_first(double* __restrict__ A, int ld, double* __restrict__ Dinv, int* __restrict__ flag) {
+  __shared__ double C[TS][TP], Li[TS][TP];
+  tile_load(C, A, ld);
+  tile_potrf_inv(C, Li, flag);
+  tile_store(A, ld, C);
+  tile_store(Dinv, TS, Li);
+}
+
+// panel j: A[i][j] <- A[i][j] * L_jj^-T for i > j   (one workgroup per tile row)
+__global__ __launch_bounds__(256) void k_chol_trsm(double* __restrict__ A, int ld, const double* __restrict__ Dinv, int j) {
+  __shared__ double P[TS][TP], Li[TS][TP];
+  const int i = j + 1 + blockIdx.x;
+  double* tile = A + (size_t)i * TS * ld + (size_t)j * TS;
+  tile_load(P, tile, ld);
+  tile_load(Li, Dinv + (size_t)j * TS * TS, TS);
+  __syncthreads();
+  const int r0 = 2 * (threadIdx.x / 16), c0 = 2 * (threadIdx.x % 16);
+  double c[2][2] = {{0, 0}, {0, 0}};
+  tile_mma_nt(c, P, Li, r0, c0);       // X = P * Li^T
+  __syncthreads();
+  P[r0][c0] = c[0][0]; P[r0][c0 + 1] = c[0][1]; P[r0 + 1][c0] = c[1][0]; P[r0 + 1][c0 + 1] = c[1][1];
+  __syncthreads();
+  tile_store(tile, ld, P);
+}
+
+// trailing update by panel j: A[i][l] -= A[i][j] A[l][j]^T for j < l <= i; the workgroup that owns the next
+// diagonal tile (j+1, j+1) factors it on the spot, so each panel costs two launches.
+__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int ld, double* __restrict__ Dinv, int j, int nblk,
+                                                      int* __restrict__ flag) {
+  __shared__ double Pi[TS][TP], Pl[TS][TP];
+  // linear block id -> (i, l) with 0 <= l' <= i' in the trailing (nblk - j - 1) tile rows
+  const int t = blockIdx.x;
+  int ip = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while ((ip + 1) * (ip + 2) / 2 <= t) ++ip;
+  while (ip * (ip + 1) / 2 > t) --ip;
+  const int lp = t - ip * (ip + 1) / 2;
+  const int i = j + 1 + ip, l = j + 1 + lp;
+  tile_load(Pi, A + (size_t)i * TS * ld + (size_t)j * TS, ld);
+  tile_load(Pl, A + (size_t)l * TS * ld + (size_t)j * TS, ld);
+  __syncthreads();
+  const int r0 = 2 * (threadIdx.x / 16), c0 = 2 * (threadIdx.x % 16);
+  double c[2][2] = {{0, 0}, {0, 0}};
+  tile_mma_nt(c, Pi, Pl, r0, c0);
+  double* out = A + (size_t)i * TS * ld + (size_t)l * TS;
+  if (i == j + 1 && l == j + 1) {
+    __syncthreads();
+    Pi[r0][c0] = out[(size_t)r0 * ld + c0] - c[0][0];
+    Pi[r0][c0 + 1] = out[(size_t)r0 * ld + c0 + 1] - c[0][1];
+    Pi[r0 + 1][c0] = out[(size_t)(r0 + 1) * ld + c0] - c[1][0];
+    Pi[r0 + 1][c0 + 1] = out[(size_t)(r0 + 1) * ld + c0 + 1] - c[1][1];
+    __syncthreads();
+    tile_potrf_inv(Pi, Pl, flag);
+    tile_store(out, ld, Pi);
+    tile_store(Dinv + (size_t)(j + 1) * TS * TS, TS, Pl);
+  } else {
+    out[(size_t)r0 * ld + c0] -= c[0][0];
+    out[(size_t)r0 * ld + c0 + 1] -= c[0][1];
+    out[(size_t)(r0 + 1) * ld + c0] -= c[1][0];
+    out[(size_t)(r0 + 1) * ld + c0 + 1] -= c[1][1];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// X = L^-1 by recursive doubling.  Level with half-size b tiles, pair q = rows/cols [2qb, 2qb+2b):
+//    T   = L21 * X11        (stored in the unused strictly-upper tile (c, j2) of A)
+//    X21 = -X22 * T
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_inv_seed(const double* __restrict__ Dinv, double* __restrict__ X, int ld) {
+  __shared__ double Tm[TS][TP];
+  const int d = blockIdx.x;
+  tile_load(Tm, Dinv + (size_t)d * TS * TS, TS);
+  __syncthreads();
+  tile_store(X + (size_t)d * TS * ld + (size_t)d * TS, ld, Tm);
+}
+
+__global__ __launch_bounds__(256) void k_inv_T(double* __restrict__ A, const double* __restrict__ X, int ld, int b, int nblk) {
+  __shared__ double Lt[TS][TP], Xt[TS][TP];
+  const int per = b * b;
+  const int q = blockIdx.x / per, rem = blockIdx.x % per;
+  const int j2 = (2 * q + 1) * b + rem / b;     // tile row in the second half
+  const int c = 2 * q * b + rem % b;            // tile col in the first half
+  if (j2 >= nblk) return;
+  const int r0 = 2 * (threadIdx.x / 16), c0 = 2 * (threadIdx.x % 16);
+  double acc[2][2] = {{0, 0}, {0, 0}};
+  for (int j1 = c; j1 < (2 * q + 1) * b; ++j1) {    // X11[j1][c] is non-zero only for j1 >= c
+    __syncthreads();
+    tile_load(Lt, A + (size_t)j2 * TS * ld + (size_t)j1 * TS, ld);
+    tile_load(Xt, X + (size_t)j1 * TS * ld + (size_t)c * TS, ld);
+    __syncthreads();
+    tile_mma_nn(acc, Lt, Xt, r0, c0);
+  }
+  double* out = A + (size_t)c * TS * ld + (size_t)j2 * TS;    // scratch: strictly-upper tile (c, j2)
+  out[(size_t)r0 * ld + c0] = acc[0][0]; out[(size_t)r0 * ld + c0 + 1] = acc[0][1];
+  out[(size_t)(r0 + 1) * ld + c0] = acc[1][0]; out[(size_t)(r0 + 1) * ld + c0 + 1] = acc[1][1];
+}
+
+__global__ __launch_bounds__(256) void k_inv_X21(const double* __restrict__ A, double* __restrict__ X, int ld, int b, int nblk) {
+  __shared__ double Xa[TS][TP], Tt[TS][TP];
+  const int per = b * b;
+  const int q = blockIdx.x / per, rem = blockIdx.x % per;
+  const int i = (2 * q + 1) * b + rem / b;
+  const int c = 2 * q * b + rem % b;
+  if (i >= nblk) return;
+  const int r0 = 2 * (threadIdx.x / 16), c0 = 2 * (threadIdx.x % 16);
+  double acc[2][2] = {{0, 0}, {0, 0}};
+  for (int j2 = (2 * q + 1) * b; j2 <= i; ++j2) {   // X22[i][j2] is non-zero only for j2 <= i
+    __syncthreads();
+    tile_load(Xa, X + (size_t)i * TS * ld + (size_t)j2 * TS, ld);
+    tile_load(Tt, A + (size_t)c * TS * ld + (size_t)j2 * TS, ld);
+    __syncthreads();
+    tile_mma_nn(acc, Xa, Tt, r0, c0);
+  }
+  double* out = X + (size_t)i * TS * ld + (size_t)c * TS;
+  out[(size_t)r0 * ld + c0] = -acc[0][0]; out[(size_t)r0 * ld + c0 + 1] = -acc[0][1];
+  out[(size_t)(r0 + 1) * ld + c0] = -acc[1][0]; out[(size_t)(r0 + 1) * ld + c0 + 1] = -acc[1][1];
+}
+
+// ------------------------------------------------------------------------------------------------
+// w = X rhs (rows), then mu_c = sum_r X[r][c] w_r, beta_c = sum_r X[r][c]^2 (columns, two stages, fixed order)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tri_matvec(const double* __restrict__ X, int ld, int n, const double* __restrict__ rhs,
+                                                     double* __restrict__ w) {
+  const int r = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE;
+  const int lane = threadIdx.x % CM_WAVE;
+  if (r >= n) return;
+  double s = 0.0;
+  for (int c = lane; c <= r; c += CM_WAVE) s = fma(X[(size_t)r * ld + c], rhs[c], s);
+  s = cm_wave_sum(s);
+  if (lane == 0) w[r] = s;
+}
+
+#define CM_COLCHUNK 64
+__global__ __launch_bounds__(64) void k_colsum_partial(const double* __restrict__ X, int ld, int n, const double* __restrict__ w,
+                                                        double* __restrict__ part) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  const int chunk = blockIdx.y;
+  const int rbeg = chunk * CM_COLCHUNK, rend = min(n, rbeg + CM_COLCHUNK);
+  double sm = 0.0, sb = 0.0;
+  if (c < n) {
+    for (int r = max(rbeg, c); r < rend; ++r) {
+      const double x = X[(size_t)r * ld + c];
+      sm = fma(x, w[r], sm);
+      sb = fma(x, x, sb);
+    }
+  }
+  if (c < ld) {
+    part[((size_t)chunk * 2 + 0) * ld + c] = sm;
+    part[((size_t)chunk * 2 + 1) * ld + c] = sb;
+  }
+}
+__global__ __launch_bounds__(256) void k_colsum_final(const double* __restrict__ part, int ld, int n, int nchunks,
+                                                       const int* __restrict__ act_idx, double* __restrict__ mu, double* __restrict__ beta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  double sm = 0.0, sb = 0.0;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    sm += part[((size_t)ch * 2 + 0) * ld + c];
+    sb += part[((size_t)ch * 2 + 1) * ld + c];
+  }
+  const int nn = act_idx[c];
+  mu[nn] = sm;
+  beta[nn] = sb;
+}
+
+__global__ __launch_bounds__(256) void k_fill_prior(const double* __restrict__ mu_prior, const double* __restrict__ beta_prior, int N,
+                                                     double* __restrict__ mu, double* __restrict__ beta) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < N) { mu[n] = mu_prior[n]; beta[n] = beta_prior[n] * beta_prior[n]; }
+}
+
+int cm_launch_row_stats(cm_ctx* ctx, cm_problem* p) {
+  hipLaunchKernelGGL(k_row_stats, dim3((p->N + 3) / 4), dim3(256), 0, ctx->stream, p->lam, p->row_ptr, p->col, p->y, p->N, p->rs);
+  hipLaunchKernelGGL(k_active_compact, dim3(1), dim3(1024), 0, ctx->stream, p->rs, p->N, p->act_idx, p->act_inv, p->n_act);
+  CM_HIP(hipGetLastError());
+  CM_HIP(hipMemcpyAsync(ctx->h_pinned, p->n_act, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  CM_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
+  return CM_OK;
+}
+
+// Expects cm_launch_row_stats() to have been enqueued after the last change of lam.
+int cm_solve_mu(cm_ctx* ctx, cm_problem* p, int* n_active_out) {
+  hipStream_t st = ctx->stream;
+  CM_HIP(hipEventSynchronize(ctx->ev[7]));          // the only host wait of an iteration: size of the active set
+  const int na = ctx->h_pinned[0];
+  if (n_active_out) *n_active_out = na;
+  hipLaunchKernelGGL(k_fill_prior, dim3((p->N + 255) / 256), dim3(256), 0, st, p->mu_prior, p->beta_prior, p->N, p->mu, p->beta);
+  if (na == 0) { CM_HIP(hipGetLastError()); return CM_OK; }
+  const int nblk = (na + TS - 1) / TS;
+  const int ld = nblk * TS;
+  double* A = p->A;
+  double* X = p->X;
+  if ((size_t)ld * sizeof(double) > 150 * 1024) { cm_set_error("active set of %d neurons exceeds the LDS row accumulator", na); return CM_ERR_INVALID; }
+  if ((size_t)ld * sizeof(double) > 48 * 1024)
+    CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_precision), hipFuncAttributeMaxDynamicSharedMemorySize, ld * (int)sizeof(double)));
+  hipLaunchKernelGGL(k_build_precision, dim3(ld), dim3(64), (size_t)ld * sizeof(double), st, p->lam, p->row_ptr, p->col, p->col_ptr,
+                     p->csc_row, p->csc_pos, p->act_idx, p->act_inv, p->rs, p->scal, p->mu_prior, p->beta_prior, na, ld, A, p->rhs);
+  // Cholesky
+  hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(256), 0, st, A, ld, p->Dinv, p->n_act + 1);
+  for (int j = 0; j + 1 < nblk; ++j) {
+    const int t = nblk - j - 1;
+    hipLaunchKernelGGL(k_chol_trsm, dim3(t), dim3(256), 0, st, A, ld, p->Dinv, j);
+    hipLaunchKernelGGL(k_chol_update, dim3(t * (t + 1) / 2), dim3(256), 0, st, A, ld, p->Dinv, j, nblk, p->n_act + 1);
+  }
+  // inverse of the factor
+  CM_HIP(hipMemsetAsync(X, 0, (size_t)ld * ld * sizeof(double), st));
+  hipLaunchKernelGGL(k_inv_seed, dim3(nblk), dim3(256), 0, st, p->Dinv, X, ld);
+  for (int b = 1; b < nblk; b *= 2) {
+    const int npairs = (nblk + 2 * b - 1) / (2 * b);
+    hipLaunchKernelGGL(k_inv_T, dim3(npairs * b * b), dim3(256), 0, st, A, X, ld, b, nblk);
+    hipLaunchKernelGGL(k_inv_X21, dim3(npairs * b * b), dim3(256), 0, st, A, X, ld, b, nblk);
+  }
+  // mu, beta
+  double* w = p->rhs + ld;
+  hipLaunchKernelGGL(k_tri_matvec, dim3((na + 3) / 4), dim3(256), 0, st, X, ld, na, p->rhs, w);
+  const int nchunks = (na + CM_COLCHUNK - 1) / CM_COLCHUNK;
+  double* part = A;   // the factor is no longer needed: reuse its storage for the partial column sums
+  hipLaunchKernelGGL(k_colsum_partial, dim3((ld + 63) / 64, nchunks), dim3(64), 0, st, X, ld, na, w, part);
+  hipLaunchKernelGGL(k_colsum_final, dim3((na + 255) / 256), dim3(256), 0, st, part, ld, na, nchunks, p->act_idx, p->mu, p->beta);
+  CM_HIP(hipGetLastError());
+  return CM_OK;
+}

@@ -1,0 +1,333 @@
+// Spike posterior sweep: replaces update_lam / body_fun / _eval_spike_rates / _eval_lam_update_monte_carlo,
+// reference circuitmap/optimise/caviar.py:174-236, and the jax.random calls it makes (caviar.py:196,209-210).
+//
+// MI355X design.  The reference walks the N neurons strictly in sequence (Gauss-Seidel, caviar.py:229) and each step
+// re-sums (N-1) x K products.  Three observations remove almost all of that while keeping the maths identical:
+//   1. the only cross-neuron state is the K-vector R = sum_m mu_m lam_m; leave-one-out = R - mu_n lam_n(old)
+//       -> O(nnz) per sweep, R lives in LDS;
+//   2. lam is supported on the targeted trials only (caviar.py:216), so a step touches the ~K*H/N entries of one
+//      CSR row: one wavefront per neuron, lanes over its trials, shuffle reductions for the per-power rates;
+//   3. the Monte-Carlo logit depends on the trial only through its stimulus value, and the truncated-normal
+//      samples only on phi of the PREVIOUS iteration, so all N x S x P transcendental evaluations run as one
+//      embarrassingly parallel kernel before the sweep; a neuron with mu_n == 0 neither reads nor changes R, so
+//      those rows are swept in parallel and only the mu_n != 0 rows form the sequential chain (one workgroup).
+#include "cm_internal.h"
+
+// ------------------------------------------------------------------------------------------------
+// RNG.  Key schedule (host, cm_host_key_schedule): per iteration (3 + N) threefry keys:
+//   [0..2]  sort-key subkeys of the permutation rounds (jax _shuffle), [3 + m] the uniform key of sweep step m.
+// ------------------------------------------------------------------------------------------------
+int cm_perm_rounds(int N) {
+  const double r = 3.0 * log((double)(N > 1 ? N : 1)) / log(4294967295.0);
+  int k = (int)ceil(r);
+  return k < 0 ? 0 : k;
+}
+
+static void host_split(const uint32_t key[2], uint32_t out0[2], uint32_t out1[2]) {
+  uint32_t a0 = 0, a1 = 2, b0 = 1, b1 = 3;
+  cm_threefry2x32(key[0], key[1], a0, a1);
+  cm_threefry2x32(key[0], key[1], b0, b1);
+  out0[0] = a0; out0[1] = b0;
+  out1[0] = a1; out1[1] = b1;
+}
+
+// jax key handling of caviar(): see oracle/threefry.py JaxLikeStream (caviar.py:76,196,209-210,227,251,304)
+void cm_host_key_schedule(uint64_t seed, int iters, int N, std::vector<uint32_t>& keys) {
+  const size_t per = (size_t)(N + 3) * 2;
+  keys.assign(per * iters, 0u);
+  uint32_t key[2] = {(uint32_t)(seed >> 32), (uint32_t)(seed & 0xFFFFFFFFull)};
+  const int rounds = cm_perm_rounds(N);
+  for (int it = 0; it < iters; ++it) {
+    uint32_t* out = keys.data() + per * it;
+    uint32_t k[2] = {key[0], key[1]}, s0[2], s1[2];
+    for (int r = 0; r < rounds && r < 3; ++r) {       // key, subkey = split(key)
+      host_split(k, s0, s1);
+      out[2 * r] = s1[0]; out[2 * r + 1] = s1[1];
+      k[0] = s0[0]; k[1] = s0[1];
+    }
+    k[0] = key[0]; k[1] = key[1];
+    for (int m = 0; m < N; ++m) {                      // key, key_next = split(key); uniform(key); carry key_next
+      host_split(k, s0, s1);
+      out[2 * (3 + m)] = s0[0]; out[2 * (3 + m) + 1] = s0[1];
+      k[0] = s1[0]; k[1] = s1[1];
+    }
+    host_split(k, s0, s1);                             // update_phi returns split(key)[1]
+    key[0] = s1[0]; key[1] = s1[1];
+  }
+}
+
+// 32-bit sort keys: jax threefry_2x32(key, iota(n)) layout (odd n padded with one zero counter)
+__device__ __forceinline__ uint32_t cm_bits32(uint32_t k0, uint32_t k1, int i, int n) {
+  const int odd = n & 1, half = (n + odd) >> 1;
+  uint32_t x0, x1;
+  if (i < half) {
+    x0 = (uint32_t)i;
+    x1 = (half + i < n) ? (uint32_t)(half + i) : 0u;
+    cm_threefry2x32(k0, k1, x0, x1);
+    return x0;
+  }
+  x0 = (uint32_t)(i - half);
+  x1 = (uint32_t)i;
+  cm_threefry2x32(k0, k1, x0, x1);
+  return x1;
+}
+
+// One round of jax's sort-based shuffle: stable sort of `in` by fresh 32-bit keys, done as rank-by-counting.
+__global__ __launch_bounds__(256) void k_perm_round(const uint32_t* __restrict__ keys, int round, const int* __restrict__ in,
+                                                     int* __restrict__ out, int N, uint32_t* __restrict__ sk) {
+  // phase split over two launches by `out == nullptr`: first fill the sort keys, then rank
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (out == nullptr) {
+    if (i < N) sk[i] = cm_bits32(keys[2 * round], keys[2 * round + 1], i, N);
+    return;
+  }
+  __shared__ uint32_t tile[256];
+  const uint32_t mine = i < N ? sk[i] : 0u;
+  int rank = 0;
+  for (int j0 = 0; j0 < N; j0 += 256) {
+    __syncthreads();
+    tile[threadIdx.x] = (j0 + (int)threadIdx.x < N) ? sk[j0 + threadIdx.x] : 0xFFFFFFFFu;
+    __syncthreads();
+    const int lim = min(256, N - j0);
+    for (int j = 0; j < lim; ++j) {
+      const uint32_t o = tile[j];
+      rank += (o < mine) || (o == mine && (j0 + j) < i);
+    }
+  }
+  if (i < N) out[rank] = in ? in[i] : i;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Monte-Carlo logit  (caviar.py:209-215, 233-236); one wave per sweep step m (neuron n = order[m])
+//   u ~ U[0,1)^{S x 2}   (threefry 64-bit draws, or host supplied)
+//   mc = ndtri(c + u (1 - c)) * sdev + mean,  c = ndtr(-mean/sdev),  mean = phi[n],  sdev = diag(phi_cov[n])  (a VARIANCE, quirk 2)
+//   mcE[n][g] = mean_s log(f / (1 - f)),  f = sigmoid(mc_s0 * vals[g] - mc_s1)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_mc_logit(const uint32_t* __restrict__ keys, const double* __restrict__ uexp,
+                                                  const int* __restrict__ order, const double* __restrict__ phi,
+                                                  const double* __restrict__ phi_cov, const double* __restrict__ vals, int V, int S, int N,
+                                                  double* __restrict__ mcE, double* __restrict__ u_out) {
+  extern __shared__ double mc[];   // [2*S]
+  const int m = blockIdx.x, lane = threadIdx.x;
+  const int n = order[m];
+  const double mean0 = phi[2 * n], mean1 = phi[2 * n + 1];
+  const double sd0 = phi_cov[4 * n], sd1 = phi_cov[4 * n + 3];
+  const double c0 = normcdf(-mean0 / sd0), c1 = normcdf(-mean1 / sd1);
+  uint32_t k0 = 0, k1 = 0;
+  if (!uexp) { k0 = keys[2 * (3 + m)]; k1 = keys[2 * (3 + m) + 1]; }
+  for (int j = lane; j < 2 * S; j += CM_WAVE) {
+    double u;
+    if (uexp) {
+      u = uexp[(size_t)m * 2 * S + j];
+    } else {
+      uint32_t x0 = (uint32_t)j, x1 = (uint32_t)(2 * S + j);   // 64-bit draw j: hi = word j, lo = word 2S + j
+      cm_threefry2x32(k0, k1, x0, x1);
+      const unsigned long long bits = ((unsigned long long)x0 << 32) | (unsigned long long)x1;
+      u = __longlong_as_double((long long)((bits >> 12) | 0x3FF0000000000000ull)) - 1.0;
+    }
+    if (u_out) u_out[(size_t)m * 2 * S + j] = u;
+    const bool second = j & 1;
+    const double c = second ? c1 : c0, sd = second ? sd1 : sd0, mean = second ? mean1 : mean0;
+    mc[j] = normcdfinv(c + u * (1.0 - c)) * sd + mean;
+  }
+  __syncthreads();
+  for (int g = 0; g < V; ++g) {
+    const double v = vals[g];
+    if (!(v > 0.0)) continue;
+    double acc = 0.0;
+    for (int s = lane; s < S; s += CM_WAVE) {
+      const double f = cm_sigmoid(mc[2 * s] * v - mc[2 * s + 1]);
+      acc += log(f / (1.0 - f));
+    }
+    acc = cm_wave_sum(acc);
+    if (lane == 0) mcE[(size_t)n * CM_MAX_VALS + g] = acc / (double)S;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// one sweep step for neuron n, executed by one wavefront (caviar.py:203-225)
+// ------------------------------------------------------------------------------------------------
+struct SweepArgs {
+  const int* row_ptr; const int* col; const uint8_t* grp; const int* rowcnt;
+  const double* y; const uint8_t* mask; const double* mu; const double* beta; const double* mcE; const double* scal;
+  double* lam;
+  int V, gated;
+  double msrmp, min_count;
+};
+
+// pava.py:9-88 with gamma = 1, last element only; literal pool walk (strict '>' merge test, pava.py:42)
+__device__ __forceinline__ double cm_pava_last_dev(const double* y, int n) {
+  double v[CM_MAX_VALS], w[CM_MAX_VALS];
+  int i = 0;
+  v[0] = y[0]; w[0] = 1.0;
+  for (int t = 1; t < n; ++t) {
+    ++i;
+    v[i] = y[t]; w[i] = 1.0;
+    while (i > 0 && (v[i - 1] / w[i - 1]) > (v[i] / w[i])) {
+      --i;
+      v[i] += v[i + 1];
+      w[i] += w[i + 1];
+    }
+  }
+  return v[i] / w[i];
+}
+
+template <bool R_IN_LDS>
+__device__ __forceinline__ void sweep_step(const SweepArgs& a, int n, double* R, double sig, double thresh, int lane) {
+  const int beg = a.row_ptr[n], end = a.row_ptr[n + 1];
+  const double mu = a.mu[n], be = a.beta[n];
+  const double t3 = sig * (mu * mu + be * be);      // caviar.py:206 (beta squared again, quirk 1)
+  const int P = a.V - 1;                            // powers = vals[1:]
+  double psum[8];
+  double total = 0.0;
+  double srate[CM_MAX_VALS];
+  // pass 1: est per entry, per-power sums
+  for (int p0 = 0; p0 < (P > 0 ? P : 1); p0 += 8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) psum[j] = 0.0;
+    for (int e0 = beg; e0 < end; e0 += CM_WAVE) {
+      const int e = e0 + lane;
+      double est = 0.0;
+      int g = -1;
+      if (e < end) {
+        const int k = a.col[e];
+        g = a.grp[e];
+        if (a.mask[k]) {
+          const double lo = a.lam[e];
+          const double loo = (mu != 0.0) ? sig * (R[k] - mu * lo) : 0.0;
+          const double arg = -2.0 * sig * a.y[k] * mu + 2.0 * mu * loo + t3;          // caviar.py:205-206
+          est = cm_sigmoid(a.mcE[(size_t)n * CM_MAX_VALS + g] - 0.5 * arg);            // caviar.py:216
+        }
+      }
+      if (p0 == 0) total += est;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) psum[j] += (g == p0 + j + 1) ? est : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (p0 + j < P) {
+        const double s = cm_wave_sum(psum[j]);
+        const int cnt = a.rowcnt[(size_t)n * CM_MAX_VALS + p0 + j + 1];
+        srate[p0 + j] = s / ((double)cnt + 1e-4 * (double)(cnt == 0));                  // caviar.py:183
+      }
+    }
+  }
+  total = cm_wave_sum(total);
+  double pava = 1.0;
+  if (a.gated) {                                                                        // caviar.py:220-221
+    const double iso = P > 0 ? cm_pava_last_dev(srate, P) : 0.0;
+    pava = (iso >= thresh && total >= a.min_count) ? 1.0 : 0.0;
+  }
+  // pass 2: write lam, update R
+  for (int e = beg + lane; e < end; e += CM_WAVE) {
+    const int k = a.col[e];
+    double est = 0.0;
+    const double lo = a.lam[e];
+    if (a.mask[k]) {
+      const double loo = (mu != 0.0) ? sig * (R[k] - mu * lo) : 0.0;
+      const double arg = -2.0 * sig * a.y[k] * mu + 2.0 * mu * loo + t3;
+      est = cm_sigmoid(a.mcE[(size_t)n * CM_MAX_VALS + a.grp[e]] - 0.5 * arg);
+    }
+    const double nl = est * pava;                                                       // caviar.py:224
+    a.lam[e] = nl;
+    if (mu != 0.0) R[k] += mu * (nl - lo);
+  }
+}
+
+// rows with mu == 0: independent of R and of each other -> one wave each, whole chip
+__global__ __launch_bounds__(256) void k_sweep_indep(SweepArgs a, int N) {
+  const int n = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE;
+  const int lane = threadIdx.x % CM_WAVE;
+  if (n >= N) return;
+  if (a.mu[n] != 0.0) return;
+  const double sig = a.scal[CM_S_SHAPE] / a.scal[CM_S_RATE];
+  const double thresh = a.msrmp + a.scal[CM_S_SPONT_RATE];
+  sweep_step<false>(a, n, nullptr, sig, thresh, lane);
+}
+
+// R_k = sum_n mu_n lam_nk over the column (ascending neuron order), into LDS or global
+template <bool R_IN_LDS>
+__global__ __launch_bounds__(1024) void k_sweep_seq(SweepArgs a, const int* __restrict__ order, int N, int K,
+                                                     const int* __restrict__ col_ptr, const int* __restrict__ csc_row,
+                                                     const int* __restrict__ csc_pos, double* __restrict__ Rg) {
+  extern __shared__ double Rl[];
+  double* R = R_IN_LDS ? Rl : Rg;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    double s = 0.0;
+    for (int ce = col_ptr[k]; ce < col_ptr[k + 1]; ++ce) s = fma(a.mu[csc_row[ce]], a.lam[csc_pos[ce]], s);
+    R[k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < CM_WAVE) {
+    const int lane = threadIdx.x;
+    const double sig = a.scal[CM_S_SHAPE] / a.scal[CM_S_RATE];
+    const double thresh = a.msrmp + a.scal[CM_S_SPONT_RATE];
+    for (int m = 0; m < N; ++m) {
+      const int n = order[m];
+      if (a.mu[n] == 0.0) continue;
+      sweep_step<R_IN_LDS>(a, n, R, sig, thresh, lane);
+    }
+  }
+}
+
+int cm_launch_rng(cm_ctx* ctx, cm_problem* p, int it, int S, int rng_mode, double* d_u_out) {
+  (void)S; (void)d_u_out;
+  hipStream_t st = ctx->stream;
+  const int N = p->N;
+  if (rng_mode == CM_RNG_EXPLICIT) {
+    CM_HIP(hipMemcpyAsync(p->order, p->orders_exp + (size_t)it * N, (size_t)N * sizeof(int), hipMemcpyDeviceToDevice, st));
+    return CM_OK;
+  }
+  const uint32_t* keys = p->keys + (size_t)it * (N + 3) * 2;
+  const int rounds = cm_perm_rounds(N);           // >= 1 for N >= 2
+  const int blocks = (N + 255) / 256;
+  const int* in = nullptr;                        // nullptr = identity (jnp.arange(N))
+  for (int r = 0; r < rounds; ++r) {
+    int* out = ((rounds - 1 - r) % 2 == 0) ? p->order : p->perm_tmp;   // ping-pong so the last round lands in p->order
+    hipLaunchKernelGGL(k_perm_round, dim3(blocks), dim3(256), 0, st, keys, r, (const int*)nullptr, (int*)nullptr, N, p->sort_keys);
+    hipLaunchKernelGGL(k_perm_round, dim3(blocks), dim3(256), 0, st, keys, r, in, out, N, p->sort_keys);
+    in = out;
+  }
+  CM_HIP(hipGetLastError());
+  return CM_OK;
+}
+
+int cm_launch_mc_logit(cm_ctx* ctx, cm_problem* p, int it, int S, int rng_mode) {
+  const int N = p->N;
+  const uint32_t* keys = (rng_mode == CM_RNG_EXPLICIT) ? nullptr : p->keys + (size_t)it * (N + 3) * 2;
+  const double* uexp = (rng_mode == CM_RNG_EXPLICIT) ? p->uexp + (size_t)it * N * 2 * S : nullptr;
+  hipLaunchKernelGGL(k_mc_logit, dim3(N), dim3(64), (size_t)2 * S * sizeof(double), ctx->stream, keys, uexp, p->order, p->phi,
+                     p->phi_cov, p->vals, p->V, S, N, p->mcE, (double*)nullptr);
+  CM_HIP(hipGetLastError());
+  return CM_OK;
+}
+
+int cm_k_rng_streams_impl(cm_ctx* ctx, cm_problem* p, int it, int S, double* d_u) {
+  const int N = p->N;
+  const uint32_t* keys = p->keys + (size_t)it * (N + 3) * 2;
+  hipLaunchKernelGGL(k_mc_logit, dim3(N), dim3(64), (size_t)2 * S * sizeof(double), ctx->stream, keys, (const double*)nullptr, p->order,
+                     p->phi, p->phi_cov, p->vals, 0, S, N, p->mcE, d_u);
+  CM_HIP(hipGetLastError());
+  return CM_OK;
+}
+
+int cm_launch_sweep(cm_ctx* ctx, cm_problem* p, int it, const cm_options* o) {
+  SweepArgs a;
+  a.row_ptr = p->row_ptr; a.col = p->col; a.grp = p->grp; a.rowcnt = p->rowcnt;
+  a.y = p->y; a.mask = p->mask; a.mu = p->mu; a.beta = p->beta; a.mcE = p->mcE; a.scal = p->scal;
+  a.lam = p->lam; a.V = p->V;
+  a.gated = it > o->delay_spont_est;
+  a.msrmp = o->msrmp; a.min_count = o->minimum_spike_count;
+  hipStream_t st = ctx->stream;
+  hipLaunchKernelGGL(k_sweep_indep, dim3((p->N + 3) / 4), dim3(256), 0, st, a, p->N);
+  const size_t lds = (size_t)p->K * sizeof(double);
+  if (lds <= 120 * 1024) {
+    if (lds > 48 * 1024)
+      CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_seq<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_sweep_seq<true>, dim3(1), dim3(1024), lds, st, a, p->order, p->N, p->K, p->col_ptr, p->csc_row, p->csc_pos, p->R);
+  } else {
+    hipLaunchKernelGGL(k_sweep_seq<false>, dim3(1), dim3(1024), 0, st, a, p->order, p->N, p->K, p->col_ptr, p->csc_row, p->csc_pos, p->R);
+  }
+  CM_HIP(hipGetLastError());
+  return CM_OK;
+}

@@ -1,0 +1,46 @@
+"""`Model` with the reference's interface for the CAVIaR path (reference circuitmap/model.py:16-44,104-162)."""
+import time
+from copy import deepcopy
+
+import numpy as np
+
+from . import optimise
+
+
+class Model:
+    def __init__(self, N, priors=None):
+        """Initialise circuitmap model (defaults: reference circuitmap/model.py:24-31)."""
+        self.N = N
+        self.priors = priors if priors is not None else {}
+        self.priors.setdefault('alpha', 1/4 * np.ones(N))
+        self.priors.setdefault('phi', np.c_[1e-1 * np.ones(N), 5e0 * np.ones(N)])
+        self.priors.setdefault('phi_cov', np.array([np.array([[1e-1, 0], [0, 1e0]]) for _ in range(N)]))
+        self.priors.setdefault('mu', np.zeros(N))
+        self.priors.setdefault('beta', 1e1 * np.ones(N))
+        self.priors.setdefault('shape', 1.)
+        self.priors.setdefault('rate', 1e-1)
+        self.state = deepcopy(self.priors)
+
+    def fit(self, obs, stimuli, method='caviar', fit_options=dict()):
+        if method == 'caviar':
+            self._fit_caviar(obs, stimuli, fit_options)
+        elif method in ('mbcs', 'cavi_sns'):
+            raise NotImplementedError("method '%s' is outside the MI355X hot-path scope (SURVEY.md section 2); "
+                                      "only method='caviar' is implemented" % method)
+        else:
+            raise Exception          # reference circuitmap/model.py:44
+
+    def _fit_caviar(self, obs, stimuli, fit_options):
+        t_start = time.time()
+        result = optimise.caviar(
+            obs, stimuli, self.state['mu'], self.state['beta'], self.state['shape'],
+            self.state['rate'], self.state['phi'], self.state['phi_cov'], **fit_options
+        )
+        t_end = time.time()
+        names = ['mu', 'beta', 'lam', 'shape', 'rate', 'phi', 'phi_cov', 'z', 'receptive_fields']
+        for name, val in zip(names, result[:9]):
+            self.state[name] = np.array(val)       # np.array(None) for receptive_fields, as model.py:126
+        self.trial_count = self.state['lam'].shape[1]
+        self.time = t_end - t_start
+        self.history = {k: np.array(v) for k, v in zip(['mu', 'beta', 'lam', 'shape', 'rate', 'phi', 'phi_cov', 'z'], result[9:17])}
+        return

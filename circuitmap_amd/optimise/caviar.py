@@ -1,0 +1,142 @@
+"""`caviar()` with the reference's signature and 17-tuple return, running on libcaviar_hip (MI355X).
+
+Drop-in for ``circuitmap.optimise.caviar`` (reference circuitmap/optimise/caviar.py:20-23, return
+value :100).  Host code only marshals arguments; every numerical phase runs in HIP kernels.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .. import _lib
+
+_OPTION_NAMES = ["iters", "num_mc_samples", "seed", "y_xcorr_thresh", "minimum_spike_count", "delay_spont_est", "msrmp",
+                 "scale_factor", "penalty", "save_histories", "max_backtrack_iters", "tol", "spont_orthogonality", "fn_scan"]
+
+
+def make_options(lib, iters=50, num_mc_samples=100, seed=0, y_xcorr_thresh=1e-2, minimum_spike_count=3,
+                 delay_spont_est=1, msrmp=0.3, scale_factor=0.75, penalty=5e0, save_histories=False,
+                 max_backtrack_iters=20, tol=0.05, spont_orthogonality=0.1, fn_scan=True, verbose=0):
+    o = _lib.CmOptions()
+    lib.cm_options_default(C.byref(o))
+    o.iters, o.num_mc_samples, o.seed = int(iters), int(num_mc_samples), int(seed)
+    o.y_xcorr_thresh, o.minimum_spike_count = float(y_xcorr_thresh), float(minimum_spike_count)
+    o.delay_spont_est, o.msrmp, o.scale_factor, o.penalty = int(delay_spont_est), float(msrmp), float(scale_factor), float(penalty)
+    o.save_histories, o.max_backtrack_iters, o.tol = int(bool(save_histories)), int(max_backtrack_iters), float(tol)
+    o.spont_orthogonality, o.fn_scan, o.verbose = float(spont_orthogonality), int(bool(fn_scan)), int(verbose)
+    return o
+
+
+class Problem:
+    """A circuit resident in HBM: encoded stimulus + PSC integrals + CAVIaR state (C-ABI cm_problem)."""
+
+    def __init__(self, ctx, y_psc, I, device_ptrs=None):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self.handle = C.c_void_p()
+        if device_ptrs is not None:
+            N, K, T, psc_ptr, stim_ptr = device_ptrs
+            kind = _lib.CM_MEM_DEVICE
+            self._keep = None
+        else:
+            psc = _lib.f64(y_psc)
+            stim = _lib.f64(np.asarray(I).astype(float))          # caviar.py:35 (callers may pass ints)
+            if psc.ndim != 2 or stim.ndim != 2 or psc.shape[0] != stim.shape[1]:
+                raise ValueError("y_psc must be K x T and I must be N x K (got %s, %s)" % (psc.shape, stim.shape))
+            N, K, T = stim.shape[0], stim.shape[1], psc.shape[1]
+            psc_ptr, stim_ptr = psc.ctypes.data, stim.ctypes.data
+            kind = _lib.CM_MEM_HOST
+            self._keep = (psc, stim)
+        self.N, self.K, self.T = int(N), int(K), int(T)
+        _lib.check(self.lib.cm_problem_create(ctx.handle, self.N, self.K, self.T, C.c_void_p(psc_ptr), C.c_void_p(stim_ptr),
+                                              kind, C.byref(self.handle)))
+        self._keep = None
+
+    @property
+    def nnz(self):
+        nnz, nv = C.c_int64(), C.c_int32()
+        _lib.check(self.lib.cm_problem_nnz(self.handle, C.byref(nnz), C.byref(nv)))
+        return nnz.value, nv.value
+
+    def run(self, mu_prior, beta_prior, shape_prior, rate_prior, phi_prior, phi_cov_prior, update_orders=None,
+            uniforms=None, verbose=0, **fit_options):
+        """cm_caviar_run: results stay in HBM.  Returns the device timings."""
+        N = self.N
+        unknown = set(fit_options) - set(_OPTION_NAMES)
+        if unknown:
+            raise TypeError("caviar() got an unexpected keyword argument '%s'" % sorted(unknown)[0])
+        o = make_options(self.lib, verbose=verbose, **fit_options)
+        keep = [_lib.f64(mu_prior, (N,)), _lib.f64(beta_prior, (N,)), _lib.f64(phi_prior, (N, 2)), _lib.f64(phi_cov_prior, (N, 2, 2))]
+        pr = _lib.CmPriors(_lib.dptr(keep[0]), _lib.dptr(keep[1]), float(shape_prior), float(rate_prior), _lib.dptr(keep[2]),
+                           _lib.dptr(keep[3]))
+        if update_orders is not None or uniforms is not None:
+            S = o.num_mc_samples
+            uo = np.ascontiguousarray(update_orders, dtype=np.int32).reshape(o.iters, N)
+            uu = _lib.f64(uniforms, (o.iters, N, S, 2))
+            keep += [uo, uu]
+            o.rng_mode = _lib.CM_RNG_EXPLICIT
+            o.update_orders = uo.ctypes.data_as(C.POINTER(C.c_int32))
+            o.uniforms = _lib.dptr(uu)
+        tm = _lib.CmTimings()
+        _lib.check(self.lib.cm_caviar_run(self.ctx.handle, self.handle, C.byref(pr), C.byref(o), C.byref(tm)))
+        self._last = (o.iters, bool(o.save_histories))
+        return tm
+
+    def fetch(self, want_lam=True):
+        """cm_caviar_fetch -> the reference's 17-tuple (caviar.py:100)."""
+        N, K = self.N, self.K
+        iters, hist = self._last
+        out = dict(mu=np.empty(N), beta=np.empty(N), lam=np.empty((N, K)) if want_lam else None, phi=np.empty((N, 2)),
+                   phi_cov=np.empty((N, 2, 2)), z=np.empty(K))
+        r = _lib.CmResult()
+        for k, v in out.items():
+            if v is not None:
+                setattr(r, k, _lib.dptr(v))
+        hists = [None] * 8
+        if hist and iters > 0:
+            shapes = dict(mu_hist=(iters, N), beta_hist=(iters, N), lam_hist=(iters, N, K), shape_hist=(iters, K),
+                          rate_hist=(iters, K), phi_hist=(iters, N, 2), phi_cov_hist=(iters, N, 2, 2), z_hist=(iters, K))
+            hists = []
+            for k, shp in shapes.items():
+                a = np.empty(shp)
+                setattr(r, k, _lib.dptr(a))
+                hists.append(a)
+        _lib.check(self.lib.cm_caviar_fetch(self.ctx.handle, self.handle, C.byref(r)))
+        receptive_fields = None                                      # caviar.py:51
+        return (out["mu"], out["beta"], out["lam"], np.float64(r.shape), np.float64(r.rate), out["phi"], out["phi_cov"],
+                out["z"], receptive_fields, *hists)
+
+    def close(self):
+        if self.handle:
+            self.lib.cm_problem_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def caviar(y_psc, I, mu_prior, beta_prior, shape_prior, rate_prior, phi_prior, phi_cov_prior,
+           iters=50, num_mc_samples=100, seed=0, y_xcorr_thresh=1e-2, minimum_spike_count=3,
+           delay_spont_est=1, msrmp=0.3, scale_factor=0.75, penalty=5e0, save_histories=False,
+           max_backtrack_iters=20, tol=0.05, spont_orthogonality=0.1, fn_scan=True, *,
+           device_id=0, update_orders=None, uniforms=None, verbose=0, return_timings=False):
+    """Coordinate-ascent variational inference and isotonic regularisation on one MI355X.
+
+    Positional arguments, keyword names, defaults and the 17-element return value are those of the reference
+    (circuitmap/optimise/caviar.py:20-23,100).  Keyword-only extras: `device_id`; `update_orders` [iters, N] and
+    `uniforms` [iters, N, S, 2] to replace the seeded threefry stream by explicit RNG streams.
+    """
+    ctx = _lib.default_context(device_id)
+    prob = Problem(ctx, y_psc, I)
+    try:
+        tm = prob.run(mu_prior, beta_prior, shape_prior, rate_prior, phi_prior, phi_cov_prior, update_orders=update_orders,
+                      uniforms=uniforms, verbose=verbose, iters=iters, num_mc_samples=num_mc_samples, seed=seed,
+                      y_xcorr_thresh=y_xcorr_thresh, minimum_spike_count=minimum_spike_count, delay_spont_est=delay_spont_est,
+                      msrmp=msrmp, scale_factor=scale_factor, penalty=penalty, save_histories=save_histories,
+                      max_backtrack_iters=max_backtrack_iters, tol=tol, spont_orthogonality=spont_orthogonality, fn_scan=fn_scan)
+        res = prob.fetch()
+    finally:
+        prob.close()
+    return (res, tm) if return_timings else res

@@ -1,0 +1,162 @@
+/*
+ * caviar_hip.h -- C ABI of libcaviar_hip.so: MI355X (gfx950) implementation of circuitmap's CAVIaR
+ * coordinate-ascent inner loop.
+ *
+ * Drop-in boundary: this library replaces the callable
+ *     circuitmap.optimise.caviar(y_psc, I, mu_prior, beta_prior, shape_prior, rate_prior, phi_prior,
+ *                                phi_cov_prior, **fit_options)        reference circuitmap/optimise/caviar.py:20-23
+ * whose 17-tuple return (caviar.py:100) is consumed by Model._fit_caviar (reference circuitmap/model.py:107-136).
+ * The reference has no FFI of its own (it is pure Python on jax); a maintainer binds these entry points with
+ * ctypes -- see INTEGRATION.md and circuitmap_amd/_lib.py.
+ *
+ * Conventions: plain pointers and sizes only; every array is float64 unless noted, row-major; the library never
+ * frees caller memory; all functions return CM_OK (0) or a negative cm_status, with a message available from
+ * cm_last_error() (thread-local); no exceptions cross the ABI.  One cm_ctx = one GPU + one HIP stream; calls on
+ * one ctx must be serialised by the caller, distinct ctxs are independent (one process per GPU, or several ctxs
+ * per process).
+ */
+#ifndef CAVIAR_HIP_H
+#define CAVIAR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum cm_status {
+  CM_OK = 0,
+  CM_ERR_INVALID = -1,        /* bad argument (NULL, N < 2, K < 1, ...)                         */
+  CM_ERR_HIP = -2,            /* a HIP runtime call failed (message has the HIP error string)    */
+  CM_ERR_NO_DEVICE = -3,      /* no gfx950 device visible: the library has NO CPU fallback       */
+  CM_ERR_TOO_MANY_POWERS = -4,/* more than CM_MAX_VALS distinct stimulus values                  */
+  CM_ERR_NOT_SPD = -5,        /* weight-posterior precision matrix not positive definite         */
+  CM_ERR_STATE = -6           /* call order violated (e.g. fetch before run)                     */
+} cm_status;
+
+#define CM_MAX_VALS 64        /* distinct values of the stimulus matrix (0 and the laser powers) */
+
+typedef enum cm_mem_kind { CM_MEM_HOST = 0, CM_MEM_DEVICE = 1 } cm_mem_kind;
+typedef enum cm_rng_mode {
+  CM_RNG_THREEFRY = 0,        /* counter-based Threefry-2x32-20 keyed by `seed`, jax.random conventions
+                                 (replaces jax.random.PRNGKey/split/uniform/choice, caviar.py:76,196,209-210,304) */
+  CM_RNG_EXPLICIT = 1         /* host-supplied streams: update_orders[iters*N], uniforms[iters*N*S*2]              */
+} cm_rng_mode;
+
+typedef struct cm_ctx cm_ctx;           /* device context: stream + workspaces                    */
+typedef struct cm_problem cm_problem;   /* one circuit's encoded inputs + CAVIaR state, in HBM    */
+
+/* Replaces the reference's positional prior arguments (caviar.py:20; defaults circuitmap/model.py:24-31). Host memory. */
+typedef struct cm_priors {
+  const double* mu;        /* [N]      */
+  const double* beta;      /* [N]  prior std-dev of the weights */
+  double shape;
+  double rate;
+  const double* phi;       /* [N*2]    */
+  const double* phi_cov;   /* [N*2*2]  */
+} cm_priors;
+
+/* Mirrors every keyword of caviar() (caviar.py:21-23), same names and defaults (see cm_options_default). */
+typedef struct cm_options {
+  int32_t iters;
+  int32_t num_mc_samples;
+  uint64_t seed;
+  double y_xcorr_thresh;
+  double minimum_spike_count;
+  int32_t delay_spont_est;
+  double msrmp;
+  double scale_factor;
+  double penalty;
+  int32_t save_histories;
+  int32_t max_backtrack_iters;
+  double tol;
+  double spont_orthogonality;
+  int32_t fn_scan;
+  /* additions of this library */
+  int32_t rng_mode;                /* cm_rng_mode */
+  const int32_t* update_orders;    /* CM_RNG_EXPLICIT: [iters*N] host, sweep order per iteration               */
+  const double* uniforms;          /* CM_RNG_EXPLICIT: [iters*N*S*2] host, U[0,1) indexed by sweep step         */
+  int32_t verbose;
+} cm_options;
+
+/* Caller-allocated host output buffers (any pointer may be NULL = not wanted).  Replaces the 17-tuple of caviar.py:100. */
+typedef struct cm_result {
+  double* mu;          /* [N]                                                                      */
+  double* beta;        /* [N]   posterior VARIANCE as returned by the reference (caviar.py:172)    */
+  double* lam;         /* [N*K] dense                                                              */
+  double shape;
+  double rate;
+  double* phi;         /* [N*2]  */
+  double* phi_cov;     /* [N*4]  */
+  double* z;           /* [K]    */
+  /* histories, only filled when options.save_histories != 0 (caviar.py:53-73,90-92) */
+  double* mu_hist;       /* [iters*N]   */
+  double* beta_hist;     /* [iters*N]   */
+  double* lam_hist;      /* [iters*N*K] */
+  double* shape_hist;    /* [iters*K] (scalar broadcast, as the reference does) */
+  double* rate_hist;     /* [iters*K]   */
+  double* phi_hist;      /* [iters*N*2] */
+  double* phi_cov_hist;  /* [iters*N*4] */
+  double* z_hist;        /* [iters*K]   */
+} cm_result;
+
+/* Per-run device timings (HIP events on the ctx stream), milliseconds. */
+typedef struct cm_timings {
+  double total_ms;       /* iterations + fn_scan                                    */
+  double iters_ms;       /* the `iters` CAVIaR iterations only                      */
+  double fn_scan_ms;     /* reconnect_spont_cells + final update_phi                */
+  double solve_ms, sweep_ms, post_ms;   /* filled when options.verbose >= 2 (adds syncs) */
+  int32_t iters;
+  int32_t last_active;   /* size of the active (lam row != 0) set in the last iteration */
+} cm_timings;
+
+const char* cm_last_error(void);
+const char* cm_version(void);
+int cm_device_count(void);
+
+void cm_options_default(cm_options* o);   /* defaults of caviar.py:21-23 */
+
+/* hip_stream: a hipStream_t to run on (e.g. torch's current stream) or NULL for a private stream. */
+int cm_ctx_create(int device_id, void* hip_stream, cm_ctx** out);
+int cm_ctx_destroy(cm_ctx* ctx);
+int cm_ctx_synchronize(cm_ctx* ctx);
+
+/* Uploads (CM_MEM_HOST) or adopts by copy (CM_MEM_DEVICE) psc[K*T] and stim[N*K], then runs the one-off prologue
+ * on the GPU: y = trapz(psc), sum(psc^2) (caviar.py:28-30) and the compressed encoding of the stimulus matrix
+ * (distinct powers, per-row and per-column index of targeted trials; caviar.py:32-35,42). */
+int cm_problem_create(cm_ctx* ctx, int32_t N, int32_t K, int32_t T, const double* psc, const double* stim,
+                      int mem_kind, cm_problem** out);
+int cm_problem_destroy(cm_problem* p);
+int cm_problem_nnz(const cm_problem* p, int64_t* nnz, int32_t* n_vals);
+
+/* Runs caviar(): `iters` iterations (mu/beta -> lam -> shape/rate -> phi -> z, caviar.py:79-92) and, if
+ * options.fn_scan, reconnect_spont_cells + the final update_phi (caviar.py:94-98).  Results stay in HBM. */
+int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* priors, const cm_options* options, cm_timings* timings);
+
+/* Copies the results of the last cm_caviar_run to host buffers. */
+int cm_caviar_fetch(cm_ctx* ctx, cm_problem* p, cm_result* result);
+
+/* Convenience: create + run + fetch + destroy for host inputs (what a ctypes drop-in of caviar() calls). */
+int cm_caviar_fit(cm_ctx* ctx, int32_t N, int32_t K, int32_t T, const double* psc, const double* stim,
+                  const cm_priors* priors, const cm_options* options, cm_result* result, cm_timings* timings);
+
+/* ---- per-phase entry points (parity tests exercise each kernel in isolation; host buffers in/out) ---- */
+
+/* caviar.py:28-30: y[K] = trapz(psc[k,:]), ss[K] = sum_t psc[k,t]^2 */
+int cm_k_prologue(cm_ctx* ctx, int32_t K, int32_t T, const double* psc, double* y, double* ss);
+/* pava.py:86-88: last element of the isotonic (non-decreasing) regression of y[n] (host-side helper, P <= CM_MAX_VALS) */
+int cm_pava_last(const double* y, int32_t n, double* out);
+/* caviar.py:166-172 on a dense lam[N*K] */
+int cm_k_block_update_mu(cm_ctx* ctx, int32_t N, int32_t K, const double* stim, const double* lam, const double* y,
+                         double shape, double rate, const double* mu_prior, const double* beta_prior,
+                         double* mu, double* beta);
+/* caviar.py:246-316 on dense lam/stim */
+int cm_k_update_phi(cm_ctx* ctx, int32_t N, int32_t K, const double* stim, const double* lam,
+                    const double* phi_prior, const double* phi_cov_prior, double* phi, double* phi_cov);
+/* Threefry streams as the device generates them (for comparison with oracle/threefry.py): order[N], u[N*S*2] of iteration `it` */
+int cm_k_rng_streams(cm_ctx* ctx, uint64_t seed, int32_t it, int32_t N, int32_t S, int32_t* order, double* u);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAVIAR_HIP_H */
