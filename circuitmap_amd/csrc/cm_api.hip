@@ -65,6 +65,7 @@ extern "C" int cm_ctx_destroy(cm_ctx* c) {
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
   for (auto& e : c->ev) if (e) hipEventDestroy(e);
+  for (auto& e : c->pool) hipEventDestroy(e);
   if (c->h_pinned) hipHostFree(c->h_pinned);
   if (c->own_stream) hipStreamDestroy(c->stream);
   delete c;
@@ -315,17 +316,29 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
   }
   if (o->save_histories && iters > 0) CM_TRY(alloc_hist(p, iters)); else free_hist(p);
 
+  const bool timed = tm != nullptr;
+  if (timed) {
+    while (ctx->pool.size() < (size_t)iters * 6) { hipEvent_t e; CM_HIP(hipEventCreate(&e)); ctx->pool.push_back(e); }
+  }
   CM_HIP(hipEventRecord(ctx->ev[1], st));
   int last_active = 0;
+  long long sum_active = 0;
   for (int it = 0; it < iters; ++it) {                               // caviar.py:79
+    hipEvent_t* ev = timed ? &ctx->pool[(size_t)it * 6] : nullptr;
+    if (timed) CM_HIP(hipEventRecord(ev[0], st));
     CM_TRY(cm_solve_mu(ctx, p, &last_active));                       // :80  block_update_mu
+    sum_active += last_active;
     if (ctx->h_pinned[1]) { cm_set_error("iteration %d: weight precision matrix not positive definite", it); return CM_ERR_NOT_SPD; }
+    if (timed) CM_HIP(hipEventRecord(ev[1], st));
     CM_TRY(cm_launch_rng(ctx, p, it, S, o->rng_mode, nullptr));      // :196 update order
     CM_TRY(cm_launch_mc_logit(ctx, p, it, S, o->rng_mode));          // :209-215
-    CM_TRY(cm_launch_sweep(ctx, p, it, o));                          // :81  update_lam
+    if (timed) CM_HIP(hipEventRecord(ev[2], st));
+    CM_TRY(cm_launch_sweep(ctx, p, it, o, timed ? ev[3] : nullptr)); // :81  update_lam
+    if (timed) CM_HIP(hipEventRecord(ev[4], st));
     CM_TRY(cm_launch_row_stats(ctx, p));                             // row sums of the new lam (+ next active set)
     CM_TRY(cm_launch_post(ctx, p, it, o));                           // :84-88 update_sigma, update_phi, z, spont_rate
     if (o->save_histories) CM_TRY(record_hist(ctx, p, it));          // :90-92
+    if (timed) CM_HIP(hipEventRecord(ev[5], st));
     if (o->verbose >= 2) {
       CM_HIP(hipStreamSynchronize(st));
       fprintf(stderr, "[caviar_hip] it %d active %d\n", it, last_active);
@@ -362,6 +375,13 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
     hipEventElapsedTime(&c, ctx->ev[2], ctx->ev[3]);
     memset(tm, 0, sizeof(*tm));
     tm->total_ms = a; tm->iters_ms = b; tm->fn_scan_ms = c; tm->iters = iters; tm->last_active = last_active;
+    tm->sum_active = sum_active;
+    for (int it = 0; it < iters; ++it) {
+      hipEvent_t* ev = &ctx->pool[(size_t)it * 6];
+      float d[5];
+      for (int j = 0; j < 5; ++j) hipEventElapsedTime(&d[j], ev[j], ev[j + 1]);
+      tm->solve_ms += d[0]; tm->mc_ms += d[1]; tm->sweep_indep_ms += d[2]; tm->sweep_seq_ms += d[3]; tm->post_ms += d[4];
+    }
   }
   p->ran = true;
   return CM_OK;

@@ -34,6 +34,7 @@ struct cm_ctx {
   hipEvent_t ev[8] = {};
   int32_t* h_pinned = nullptr;   // small pinned host mailbox (active-set size, flags)
   int num_cus = 256;
+  std::vector<hipEvent_t> pool;   // per-iteration phase events (6 per iteration)
 };
 
 // One circuit: encoded stimulus + observations + CAVIaR state.  All pointers are device memory.
@@ -176,7 +177,7 @@ int cm_launch_expand_lam(cm_ctx* ctx, cm_problem* p, const double* d_lam_sparse,
 int cm_solve_mu(cm_ctx* ctx, cm_problem* p, int* n_active_out);                      // syncs once (active-set size)
 int cm_launch_rng(cm_ctx* ctx, cm_problem* p, int it, int S, int rng_mode, double* d_u_out);
 int cm_launch_mc_logit(cm_ctx* ctx, cm_problem* p, int it, int S, int rng_mode);
-int cm_launch_sweep(cm_ctx* ctx, cm_problem* p, int it, const cm_options* o);
+int cm_launch_sweep(cm_ctx* ctx, cm_problem* p, int it, const cm_options* o, hipEvent_t mid);
 int cm_launch_post(cm_ctx* ctx, cm_problem* p, int it, const cm_options* o);
 int cm_launch_update_phi(cm_ctx* ctx, cm_problem* p);
 int cm_launch_col_stats(cm_ctx* ctx, cm_problem* p, double spont_orthogonality);

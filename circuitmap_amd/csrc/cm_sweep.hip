@@ -311,7 +311,7 @@ int cm_k_rng_streams_impl(cm_ctx* ctx, cm_problem* p, int it, int S, double* d_u
   return CM_OK;
 }
 
-int cm_launch_sweep(cm_ctx* ctx, cm_problem* p, int it, const cm_options* o) {
+int cm_launch_sweep(cm_ctx* ctx, cm_problem* p, int it, const cm_options* o, hipEvent_t mid) {
   SweepArgs a;
   a.row_ptr = p->row_ptr; a.col = p->col; a.grp = p->grp; a.rowcnt = p->rowcnt;
   a.y = p->y; a.mask = p->mask; a.mu = p->mu; a.beta = p->beta; a.mcE = p->mcE; a.scal = p->scal;
@@ -320,6 +320,7 @@ int cm_launch_sweep(cm_ctx* ctx, cm_problem* p, int it, const cm_options* o) {
   a.msrmp = o->msrmp; a.min_count = o->minimum_spike_count;
   hipStream_t st = ctx->stream;
   hipLaunchKernelGGL(k_sweep_indep, dim3((p->N + 3) / 4), dim3(256), 0, st, a, p->N);
+  if (mid) CM_HIP(hipEventRecord(mid, st));
   const size_t lds = (size_t)p->K * sizeof(double);
   if (lds <= 120 * 1024) {
     if (lds > 48 * 1024)

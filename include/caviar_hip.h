@@ -100,14 +100,21 @@ typedef struct cm_result {
   double* z_hist;        /* [iters*K]   */
 } cm_result;
 
-/* Per-run device timings (HIP events on the ctx stream), milliseconds. */
+/* Per-run device timings in milliseconds, from HIP events recorded on the ctx stream around each phase of every
+ * iteration (no extra host synchronisation; elapsed times are read after the run's final sync). */
 typedef struct cm_timings {
-  double total_ms;       /* iterations + fn_scan                                    */
-  double iters_ms;       /* the `iters` CAVIaR iterations only                      */
-  double fn_scan_ms;     /* reconnect_spont_cells + final update_phi                */
-  double solve_ms, sweep_ms, post_ms;   /* filled when options.verbose >= 2 (adds syncs) */
+  double total_ms;       /* whole run: state init + iterations + fn_scan                      */
+  double iters_ms;       /* the `iters` CAVIaR iterations only                                */
+  double fn_scan_ms;     /* reconnect_spont_cells (host) + final update_phi                   */
+  double solve_ms;       /* sum over iterations: block_update_mu (build + Cholesky + inverse) */
+  double mc_ms;          /* sum: permutation + Monte-Carlo logit kernels                      */
+  double sweep_indep_ms; /* sum: k_sweep_indep launches                                       */
+  double sweep_seq_ms;   /* sum: k_sweep_seq launches (the sequential Gauss-Seidel chain)     */
+  double post_ms;        /* sum: row/col stats, update_sigma, soft-threshold, update_phi      */
   int32_t iters;
-  int32_t last_active;   /* size of the active (lam row != 0) set in the last iteration */
+  int32_t last_active;   /* size of the active (lam row != 0) set in the last iteration       */
+  int64_t sum_active;    /* sum over iterations of the active-set size                        */
+  int64_t sum_seq_rows;  /* reserved                                                          */
 } cm_timings;
 
 const char* cm_last_error(void);

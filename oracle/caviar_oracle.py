@@ -159,36 +159,60 @@ def update_lam(y, I, mu, beta, lam, shape, rate, phi, phi_cov, lam_mask, stream,
     order = np.asarray(stream.update_order(it, N))        # :196
     sig = shape / rate                                    # :197
     lam = lam.copy()
-    mu_c = mu.copy()                                      # in-sweep mu edits are discarded (:225,231)
-    if not literal:
-        R = mu @ lam                                      # running residual  sum_m mu_m lam_mk
     gates = np.ones(N)
+    if not literal:
+        return _update_lam_fast(y, I, mu, beta, lam, sig, phi, phi_cov, lam_mask, stream, it, num_mc_samples, powers,
+                                minimum_spike_count, minimax_spk_prob, delay_spont_est, order, gates)
+    mu_c = mu.copy()                                      # in-sweep mu edits are discarded (:225,231)
     for m in range(N):                                    # :229
         n = int(order[m])                                 # :203
-        if literal:
-            mask = np.arange(N) != n                      # :204
-            loo = np.sum(sig * mu_c[mask][:, None] * lam[mask], 0)
-            arg = -2 * sig * y * mu_c[n] + 2 * mu_c[n] * loo + sig * (mu_c[n] ** 2 + beta[n] ** 2)   # :205-206
-        else:
-            loo = sig * (R - mu[n] * lam[n])
-            arg = -2 * sig * y * mu[n] + 2 * mu[n] * loo + sig * (mu[n] ** 2 + beta[n] ** 2)
+        mask = np.arange(N) != n                          # :204
+        loo = np.sum(sig * mu_c[mask][:, None] * lam[mask], 0)
+        arg = -2 * sig * y * mu_c[n] + 2 * mu_c[n] * loo + sig * (mu_c[n] ** 2 + beta[n] ** 2)   # :205-206
         u = stream.uniforms(it, m, num_mc_samples)        # :209-210
         mc = sample_phi_mc(phi[n], phi_cov[n], u)         # :211-212
         mcE = mc_logit(I[n], mc)                          # :215
         with np.errstate(all="ignore"):
             est = lam_mask * (I[n] > 0) * sigmoid(mcE - 0.5 * arg)       # :216
         srates = eval_spike_rates(I[n], est, powers)      # :219
-        iso_last = isotonic_regression(srates)[-1] if literal else pava_last(srates)
+        iso_last = isotonic_regression(srates)[-1]
         pava = float(iso_last >= minimax_spk_prob) * float(np.sum(est) >= minimum_spike_count)   # :220
         pava = pava * (it > delay_spont_est) + 1.0 * (it <= delay_spont_est)                        # :221
-        new_row = est * pava                              # :224
-        if not literal:
-            R += mu[n] * (new_row - lam[n])
-        lam[n] = new_row
+        lam[n] = est * pava                               # :224
         mu_c[n] = mu_c[n] * (pava == 1.0)                 # :225 (no numerical effect; kept literal)
         gates[n] = pava
         if trace is not None:
             trace.setdefault("srates", {})[(it, n)] = srates
+    return lam, gates
+
+
+def _update_lam_fast(y, I, mu, beta, lam, sig, phi, phi_cov, lam_mask, stream, it, S, powers, minimum_spike_count,
+                     minimax_spk_prob, delay_spont_est, order, gates):
+    """Same sweep on the targeted trials only, with the running residual R = sum_m mu_m lam_m
+    (leave-one-out = R - mu_n lam_n) and the Monte-Carlo logit evaluated once per distinct power."""
+    N, K = I.shape
+    R = mu @ lam
+    cnt = np.array([[np.sum(I[n] == p) for p in powers] for n in range(N)]) if len(powers) else np.zeros((N, 0))
+    for m in range(N):
+        n = int(order[m])
+        idx = np.flatnonzero(I[n] > 0)
+        Iv = I[n, idx]
+        u = stream.uniforms(it, m, S)
+        mc = sample_phi_mc(phi[n], phi_cov[n], u)
+        vals, inv = np.unique(Iv, return_inverse=True)
+        mcE = mc_logit(vals, mc)[inv] if len(idx) else np.zeros(0)
+        loo = sig * (R[idx] - mu[n] * lam[n, idx])
+        arg = -2 * sig * y[idx] * mu[n] + 2 * mu[n] * loo + sig * (mu[n] ** 2 + beta[n] ** 2)
+        with np.errstate(all="ignore"):
+            est = lam_mask[idx] * sigmoid(mcE - 0.5 * arg)
+        srates = np.array([np.sum(est[Iv == p]) / (c + 1e-4 * (c == 0)) for p, c in zip(powers, cnt[n])])
+        iso_last = pava_last(srates) if len(srates) else 0.0
+        pava = float(iso_last >= minimax_spk_prob) * float(np.sum(est) >= minimum_spike_count)
+        pava = pava * (it > delay_spont_est) + 1.0 * (it <= delay_spont_est)
+        new = est * pava
+        R[idx] += mu[n] * (new - lam[n, idx])
+        lam[n, idx] = new
+        gates[n] = pava
     return lam, gates
 
 
@@ -315,6 +339,9 @@ def laplace_approx_one_suff(vals, st, phi_prior, phi_cov, t=1e1, backtrack_alpha
     return phi, cov
 
 
+_PHI_MEMO = {}
+
+
 def update_phi(lam, I, phi_prior, phi_cov_prior, powers=None, literal=True):
     """caviar.py:246-251,310: independent Laplace approximations for all N cells."""
     N = lam.shape[0]
@@ -325,7 +352,12 @@ def update_phi(lam, I, phi_prior, phi_cov_prior, powers=None, literal=True):
             phi[n], phi_cov[n] = laplace_approx_one(lam[n], phi_prior[n], phi_cov_prior[n], I[n])
         else:
             vals, st = phi_suffstats(lam[n], I[n], powers)
-            phi[n], phi_cov[n] = laplace_approx_one_suff(vals, st, phi_prior[n], phi_cov_prior[n])
+            key = (vals.tobytes(), st.tobytes(), phi_prior[n].tobytes(), phi_cov_prior[n].tobytes())
+            if key not in _PHI_MEMO:          # rows that stay all-zero repeat the same problem every iteration
+                if len(_PHI_MEMO) > 200000:
+                    _PHI_MEMO.clear()
+                _PHI_MEMO[key] = laplace_approx_one_suff(vals, st, phi_prior[n], phi_cov_prior[n])
+            phi[n], phi_cov[n] = _PHI_MEMO[key]
     return phi, phi_cov
 
 
