@@ -97,7 +97,8 @@ extern "C" int cm_problem_destroy(cm_problem* p) {
   void* ptrs[] = {p->y, p->ss, p->sum_y, p->vals, p->row_ptr, p->col, p->grp, p->rowcnt, p->col_ptr, p->csc_row, p->csc_pos,
                   p->mask, p->lam, p->mu, p->beta, p->mu_prior, p->beta_prior, p->phi, p->phi_cov, p->phi_prior, p->phi_cov_prior,
                   p->scal, p->R, p->colany, p->z, p->mcE, p->rs, p->act_idx, p->act_inv, p->n_act, p->order, p->perm_tmp,
-                  p->sort_keys, p->keys, p->uexp, p->orders_exp, p->A, p->X, p->Dinv, p->rhs};
+                  p->sort_keys, p->keys, p->uexp, p->orders_exp, p->A, p->X, p->Dinv, p->rhs, p->seq_n, p->seq_off, p->chunk_first,
+                  p->seq_meta, p->packed};
   for (void* q : ptrs) if (q) hipFree(q);
   free_hist(p);
   delete p;
@@ -141,7 +142,9 @@ extern "C" int cm_problem_create(cm_ctx* ctx, int32_t N, int32_t K, int32_t T, c
       (rc = dmalloc(&p->rs, 4 * (size_t)N)) || (rc = dmalloc(&p->act_idx, N)) || (rc = dmalloc(&p->act_inv, N)) ||
       (rc = dmalloc(&p->n_act, 4)) || (rc = dmalloc(&p->order, N)) || (rc = dmalloc(&p->perm_tmp, N)) ||
       (rc = dmalloc(&p->sort_keys, N)) || (rc = dmalloc(&p->A, ld * ld)) || (rc = dmalloc(&p->X, ld * ld)) ||
-      (rc = dmalloc(&p->Dinv, ld * CM_TILE)) || (rc = dmalloc(&p->rhs, 2 * ld)))
+      (rc = dmalloc(&p->Dinv, ld * CM_TILE)) || (rc = dmalloc(&p->rhs, 2 * ld)) || (rc = dmalloc(&p->seq_n, N)) ||
+      (rc = dmalloc(&p->seq_off, (size_t)N + 1)) || (rc = dmalloc(&p->chunk_first, ((size_t)N + p->nnz) / 512 + 8)) ||
+      (rc = dmalloc(&p->seq_meta, 4)) || (rc = dmalloc((char**)&p->packed, ((size_t)N + p->nnz) * 32)))
     return fail(rc);
   if (hipMemsetAsync(p->mcE, 0, (size_t)N * CM_MAX_VALS * sizeof(double), st) != hipSuccess) return fail(CM_ERR_HIP);
   if (hipStreamSynchronize(st) != hipSuccess) { cm_set_error("prologue failed: %s", hipGetErrorString(hipGetLastError())); return fail(CM_ERR_HIP); }

@@ -83,6 +83,11 @@ struct cm_problem {
   int32_t* order = nullptr;   // [N] sweep order of the current iteration
   int32_t* perm_tmp = nullptr;// [N] ping-pong buffer of the shuffle rounds
   uint32_t* sort_keys = nullptr; // [N] 32-bit sort keys of one shuffle round
+  int32_t* seq_n = nullptr;   // [N]   neurons with mu != 0 in sweep order
+  int32_t* seq_off = nullptr; // [N+1] record offset of each such row in `packed`
+  int32_t* chunk_first = nullptr; // [n_chunk_cap] first row of each LDS chunk
+  int32_t* seq_meta = nullptr;// [4]   nseq, total records, nchunks
+  void* packed = nullptr;     // [(N + nnz) * 32 B] packed row records of the sequential chain
   uint32_t* keys = nullptr;   // [iters*(N+3)*2] threefry key schedule (host computed)
   double* uexp = nullptr;     // explicit uniforms (device copy) or nullptr
   int32_t* orders_exp = nullptr;
@@ -107,10 +112,40 @@ enum {
 // device helpers
 // ------------------------------------------------------------------------------------------------
 #ifdef __HIPCC__
-__device__ __forceinline__ double cm_wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, CM_WAVE);
+// ---- DPP cross-lane adds (VALU data path; no LDS crossbar).  All 64 lanes must be active at the call site.
+#define CM_DPP_XOR1 0xB1          // quad_perm [1,0,3,2]
+#define CM_DPP_XOR2 0x4E          // quad_perm [2,3,0,1]
+#define CM_DPP_HALF_MIRROR 0x141  // lane i <-> 7 - i within 8
+#define CM_DPP_MIRROR 0x140       // lane i <-> 15 - i within 16
+template <int CTRL>
+__device__ __forceinline__ double cm_dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double cm_readlane_f64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+// sum over aligned segments of SEG lanes (SEG = 1,2,4,8,16 by DPP; 32, 64 add LDS-crossbar steps); every lane of a
+// segment receives the segment's sum; fixed association -> deterministic
+template <int SEG>
+__device__ __forceinline__ double cm_seg_sum(double v) {
+  if (SEG >= 2) v += cm_dpp_f64<CM_DPP_XOR1>(v);
+  if (SEG >= 4) v += cm_dpp_f64<CM_DPP_XOR2>(v);
+  if (SEG >= 8) v += cm_dpp_f64<CM_DPP_HALF_MIRROR>(v);
+  if (SEG >= 16) v += cm_dpp_f64<CM_DPP_MIRROR>(v);
+  if (SEG >= 32) v += __shfl_xor(v, 16, CM_WAVE);
+  if (SEG >= 64) v += __shfl_xor(v, 32, CM_WAVE);
   return v;
+}
+// full-wave sum, result uniform: four DPP steps give every 16-lane row its sum, the four row sums are read to scalars
+__device__ __forceinline__ double cm_wave_sum(double v) {
+  v = cm_seg_sum<16>(v);
+  const double r0 = cm_readlane_f64(v, 0), r1 = cm_readlane_f64(v, 16), r2 = cm_readlane_f64(v, 32), r3 = cm_readlane_f64(v, 48);
+  return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ int cm_wave_sum_i(int v) {
 #pragma unroll

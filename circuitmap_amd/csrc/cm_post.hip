@@ -130,6 +130,7 @@ __device__ __forceinline__ void inv2x2(double h11, double h12, double h21, doubl
   o[1] = x0; o[3] = x1;
 }
 
+template <int SEG>
 __device__ __forceinline__ double phi_nll(double p0, double p1, double val, double n0, double n1, double smid, double nmid,
                                           bool lane_on, double pr0, double pr1, const double prec[4], double t) {
   double tot = 0.0;
@@ -143,37 +144,45 @@ __device__ __forceinline__ double phi_nll(double p0, double p1, double val, doub
       else tot += nmid * cm_nan_to_num(0.5 * ls + 0.5 * l1s);
     }
   }
-  tot = cm_wave_sum(tot);
+  tot = cm_seg_sum<SEG>(tot);
   const double d0 = p0 - pr0, d1 = p1 - pr1;
   const double quad = d0 * (prec[0] * d0 + prec[1] * d1) + d1 * (prec[2] * d0 + prec[3] * d1);
   return -tot - (log(p0) + log(p1)) / t + 0.5 * quad;
 }
 
+// One wavefront per neuron.  SEG = lanes per evaluation point (power of two >= V; lane g of a segment owns stimulus
+// value g) and E = 64 / SEG evaluation points per wave: in one pass segment 0 evaluates the objective at phi (the
+// right-hand side of the Armijo test) while segments 1..E-1 evaluate it at phi + 2^-b v for consecutive b, so the
+// reference's sequential backtracking (caviar.py:259-268: accept the first b whose test passes, at most 40 halvings)
+// collapses into one parallel evaluation per Newton step in the common case.
+template <int SEG>
 __global__ __launch_bounds__(256) void k_update_phi(const double* __restrict__ lam, const int* __restrict__ row_ptr,
                                                      const uint8_t* __restrict__ grp, const int* __restrict__ rowcnt,
                                                      const double* __restrict__ vals, int V, int N,
                                                      const double* __restrict__ phi_prior, const double* __restrict__ phi_cov_prior,
                                                      double* __restrict__ phi, double* __restrict__ phi_cov) {
+  constexpr int E = CM_WAVE / SEG;
   const int n = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE;
   const int lane = threadIdx.x % CM_WAVE;
   if (n >= N) return;
-  // sufficient statistics for value `lane`
-  const bool on = lane < V;
-  const double val = on ? vals[lane] : 0.0;
-  const double cnt = on ? (double)rowcnt[(size_t)n * CM_MAX_VALS + lane] : 0.0;
+  const int g = lane % SEG, ev = lane / SEG;
+  // sufficient statistics of value g: segment `ev` scans entries ev, ev + E, ...; partial sums are then combined
+  // across the segments (lanes at stride SEG)
+  const bool on = g < V;
+  const double val = on ? vals[g] : 0.0;
+  const double cnt = on ? (double)rowcnt[(size_t)n * CM_MAX_VALS + g] : 0.0;
   double n1 = 0.0, nmid = 0.0, smid = 0.0;
-  const int beg = row_ptr[n], end = row_ptr[n + 1];
-  for (int g = 0; g < V; ++g) {
-    if (!(vals[g] > 0.0)) continue;       // untargeted values carry lam == 0 on every trial
-    double c1 = 0.0, cm = 0.0, sm = 0.0;
-    for (int e = beg + lane; e < end; e += CM_WAVE) {
+  if (on && val > 0.0) {                       // untargeted values carry lam == 0 on every trial
+    for (int e = row_ptr[n] + ev; e < row_ptr[n + 1]; e += E) {
       if (grp[e] != g) continue;
       const double l = lam[e];
-      if (l == 1.0) c1 += 1.0;
-      else if (l > 0.0 && l < 1.0) { cm += 1.0; sm += l; }
+      if (l == 1.0) n1 += 1.0;
+      else if (l > 0.0 && l < 1.0) { nmid += 1.0; smid += l; }
     }
-    c1 = cm_wave_sum(c1); cm = cm_wave_sum(cm); sm = cm_wave_sum(sm);
-    if (lane == g) { n1 = c1; nmid = cm; smid = sm; }
+  }
+#pragma unroll
+  for (int o = SEG; o < CM_WAVE; o <<= 1) {
+    n1 += __shfl_xor(n1, o, CM_WAVE); nmid += __shfl_xor(nmid, o, CM_WAVE); smid += __shfl_xor(smid, o, CM_WAVE);
   }
   const double n0 = cnt - n1 - nmid;
   const double sy = n1 + smid;
@@ -181,7 +190,7 @@ __global__ __launch_bounds__(256) void k_update_phi(const double* __restrict__ l
   const double pr0 = phi_prior[2 * n], pr1 = phi_prior[2 * n + 1];
   double prec[4];
   inv2x2(phi_cov_prior[4 * n], phi_cov_prior[4 * n + 1], phi_cov_prior[4 * n + 2], phi_cov_prior[4 * n + 3], prec);   // caviar.py:306
-  const double t = 1e1, alpha = 0.25, bbeta = 0.5;
+  const double t = 1e1, alpha = 0.25;
   double p0 = pr0, p1 = pr1;                     // caviar.py:305: restart from the prior every call (quirk 3)
   double cov[4] = {0, 0, 0, 0};
   for (int stepi = 0; stepi < 10; ++stepi) {     // caviar.py:308
@@ -193,25 +202,35 @@ __global__ __launch_bounds__(256) void k_update_phi(const double* __restrict__ l
       const double ff = cnt * f * (1.0 - f);
       h11 = val * val * ff; h12 = -val * ff; h22 = ff;
     }
-    j1 = cm_wave_sum(j1); j2 = cm_wave_sum(j2);
-    h11 = cm_wave_sum(h11); h12 = cm_wave_sum(h12); h22 = cm_wave_sum(h22);
+    j1 = cm_seg_sum<SEG>(j1); j2 = cm_seg_sum<SEG>(j2);
+    h11 = cm_seg_sum<SEG>(h11); h12 = cm_seg_sum<SEG>(h12); h22 = cm_seg_sum<SEG>(h22);
     const double d0 = p0 - pr0, d1 = p1 - pr1;
     const double J0 = j1 + (prec[0] * d0 + prec[1] * d1) - 1.0 / (t * p0);      // caviar.py:278-280
     const double J1 = j2 + (prec[2] * d0 + prec[3] * d1) - 1.0 / (t * p1);
     inv2x2(h11 + prec[0] + 1.0 / (t * p0 * p0), h12 + prec[1], h12 + prec[2], h22 + prec[3] + 1.0 / (t * p1 * p1), cov);   // :283-289
     const double v0 = -(cov[0] * J0 + cov[1] * J1), v1 = -(cov[2] * J0 + cov[3] * J1);
     const double Jv = J0 * v0 + J1 * v1;
-    double step = 1.0;
-    const double f0 = phi_nll(p0, p1, val, n0, n1, smid, nmid, on, pr0, pr1, prec, t);
-    double lhs = phi_nll(p0 + step * v0, p1 + step * v1, val, n0, n1, smid, nmid, on, pr0, pr1, prec, t);
-    double rhs = f0 + alpha * step * Jv;
-    int bt = 0;
-    while (bt < 40 && (isnan(lhs) || lhs > rhs)) {                                // caviar.py:259-268
-      ++bt;
-      step *= bbeta;
-      lhs = phi_nll(p0 + step * v0, p1 + step * v1, val, n0, n1, smid, nmid, on, pr0, pr1, prec, t);
-      rhs = f0 + alpha * step * Jv;
+    // candidates b = 0..40 (step 2^-b); b <= 39 needs its Armijo test to pass, b = 40 is taken unconditionally
+    int accepted = -1;
+    double f0 = 0.0;
+    int base = 0;                                 // first candidate of this round
+    bool first = true;
+    while (accepted < 0 && base < 40) {
+      const int b = first ? base + ev - 1 : base + ev;       // first round: segment 0 evaluates phi itself
+      const bool is_f0 = first && ev == 0;
+      const double st = is_f0 ? 0.0 : ldexp(1.0, -b);
+      const double q0 = is_f0 ? p0 : p0 + st * v0, q1 = is_f0 ? p1 : p1 + st * v1;
+      const double fv = phi_nll<SEG>(q0, q1, val, n0, n1, smid, nmid, on, pr0, pr1, prec, t);
+      if (first) f0 = cm_readlane_f64(fv, 0);
+      const double rhs = f0 + alpha * st * Jv;
+      const bool ok = !is_f0 && b <= 39 && !(isnan(fv) || fv > rhs);
+      const unsigned long long m = __ballot(ok);
+      if (m) accepted = (first ? base - 1 : base) + (int)(__ffsll((long long)m) - 1) / SEG;
+      base += first ? E - 1 : E;
+      first = false;
     }
+    if (accepted < 0) accepted = 40;
+    const double step = ldexp(1.0, -accepted);
     p0 += step * v0; p1 += step * v1;                                             // caviar.py:301
   }
   if (lane == 0) {
@@ -220,9 +239,21 @@ __global__ __launch_bounds__(256) void k_update_phi(const double* __restrict__ l
   }
 }
 
+template <int SEG>
+static void launch_phi(cm_ctx* ctx, cm_problem* p) {
+  hipLaunchKernelGGL(k_update_phi<SEG>, dim3((unsigned)((p->N + 3) / 4)), dim3(256), 0, ctx->stream, p->lam, p->row_ptr, p->grp,
+                     p->rowcnt, p->vals, p->V, p->N, p->phi_prior, p->phi_cov_prior, p->phi, p->phi_cov);
+}
+
 int cm_launch_update_phi(cm_ctx* ctx, cm_problem* p) {
-  hipLaunchKernelGGL(k_update_phi, dim3((p->N + 3) / 4), dim3(256), 0, ctx->stream, p->lam, p->row_ptr, p->grp, p->rowcnt, p->vals, p->V,
-                     p->N, p->phi_prior, p->phi_cov_prior, p->phi, p->phi_cov);
+  const int V = p->V;
+  if (V <= 1) launch_phi<1>(ctx, p);
+  else if (V <= 2) launch_phi<2>(ctx, p);
+  else if (V <= 4) launch_phi<4>(ctx, p);
+  else if (V <= 8) launch_phi<8>(ctx, p);
+  else if (V <= 16) launch_phi<16>(ctx, p);
+  else if (V <= 32) launch_phi<32>(ctx, p);
+  else launch_phi<64>(ctx, p);
   CM_HIP(hipGetLastError());
   return CM_OK;
 }

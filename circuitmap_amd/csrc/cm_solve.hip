@@ -145,39 +145,48 @@ __device__ __forceinline__ void tile_mma_nn(double c[2][2], const double (*A)[TP
   }
 }
 
-// In-LDS Cholesky of a 32x32 tile + inverse of its factor.  C holds the SPD tile on entry, L on exit (upper part
-// zeroed); Li receives L^-1 (lower triangular).  256 threads.
-__device__ void tile_potrf_inv(double (*C)[TP], double (*Li)[TP], int* __restrict__ flag) {
-  const int tid = threadIdx.x;
-  for (int c = 0; c < TS; ++c) {
-    __syncthreads();
-    const double d = C[c][c];
-    if (tid == 0 && !(d > 0.0)) *flag = 1;       // not SPD (also catches NaN)
-    const double s = sqrt(d);
-    __syncthreads();
-    if (tid >= c && tid < TS) C[tid][c] = (tid == c) ? s : C[tid][c] / s;
-    __syncthreads();
-    // trailing update: rows r > c, cols c < cc <= r
-    for (int i = tid; i < TS * TS; i += 256) {
-      const int r = i / TS, cc = i % TS;
-      if (cc > c && r >= cc) C[r][cc] = fma(-C[r][c], C[cc][c], C[r][cc]);
-    }
-  }
+// Cholesky of a 32x32 SPD tile + inverse of its factor, by ONE wavefront entirely in registers: lane r owns row r of
+// the tile (32 doubles), the pivot column is broadcast with v_readlane, so the 32 dependent column steps need no
+// barrier and no LDS round trip.  L^-1 is then built row by row, lane c owning column c.  C holds the SPD tile on
+// entry and L on exit (upper part zeroed); Li receives L^-1.  Called by all 256 threads (waves 1..3 only wait).
+__device__ __forceinline__ void tile_potrf_inv(double (*C)[TP], double (*Li)[TP], int* __restrict__ flag) {
   __syncthreads();
-  for (int i = tid; i < TS * TS; i += 256) {
-    const int r = i / TS, cc = i % TS;
-    if (cc > r) C[r][cc] = 0.0;
-    Li[r][cc] = 0.0;
-  }
-  __syncthreads();
-  if (tid < TS) {                                 // column tid of L^-1 by forward substitution
-    const int c = tid;
-    Li[c][c] = 1.0 / C[c][c];
-    for (int r = c + 1; r < TS; ++r) {
-      double s = 0.0;
-      for (int j = c; j < r; ++j) s = fma(C[r][j], Li[j][c], s);
-      Li[r][c] = -s / C[r][r];
+  if (threadIdx.x < CM_WAVE) {
+    const int lane = threadIdx.x;
+    const int row = lane & (TS - 1);
+    double a[TS], x[TS];
+#pragma unroll
+    for (int j = 0; j < TS; ++j) { a[j] = C[row][j]; x[j] = 0.0; }
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < TS; ++c) {
+      const double d = cm_readlane_f64(a[c], c);
+      bad |= !(d > 0.0);                           // not SPD (also catches NaN)
+      const double s = sqrt(d);
+      const double rs = 1.0 / s;
+      a[c] = (lane == c) ? s : a[c] * rs;
+#pragma unroll
+      for (int cc = c + 1; cc < TS; ++cc) {
+        const double l = cm_readlane_f64(a[c], cc);
+        a[cc] = fma(-a[c], l, a[cc]);
+      }
     }
+#pragma unroll
+    for (int r = 0; r < TS; ++r) {                 // row r of L^-1: X[r][c] = -(sum_{j<r} L[r][j] X[j][c]) / L[r][r]
+      const double inv = 1.0 / cm_readlane_f64(a[r], r);
+      double sacc = 0.0;
+#pragma unroll
+      for (int j = 0; j < r; ++j) sacc = fma(cm_readlane_f64(a[j], r), x[j], sacc);
+      x[r] = (lane == r) ? inv : (lane < r ? -sacc * inv : 0.0);
+    }
+    if (lane < TS) {
+#pragma unroll
+      for (int j = 0; j < TS; ++j) {
+        C[lane][j] = (j <= lane) ? a[j] : 0.0;
+        Li[j][lane] = x[j];
+      }
+    }
+    if (bad && lane == 0) *flag = 1;
   }
   __syncthreads();
 }

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(64) void k_mc_logit(const uint32_t* __restrict__ ke
 }
 
 // ------------------------------------------------------------------------------------------------
-// one sweep step for neuron n, executed by one wavefront (caviar.py:203-225)
+// one sweep step for neuron n (caviar.py:203-225)
 // ------------------------------------------------------------------------------------------------
 struct SweepArgs {
   const int* row_ptr; const int* col; const uint8_t* grp; const int* rowcnt;
@@ -156,8 +156,7 @@ struct SweepArgs {
 };
 
 // pava.py:9-88 with gamma = 1, last element only; literal pool walk (strict '>' merge test, pava.py:42)
-__device__ __forceinline__ double cm_pava_last_dev(const double* y, int n) {
-  double v[CM_MAX_VALS], w[CM_MAX_VALS];
+__device__ __forceinline__ double cm_pava_last_dev(const double* y, int n, double* v, double* w) {
   int i = 0;
   v[0] = y[0]; w[0] = 1.0;
   for (int t = 1; t < n; ++t) {
@@ -172,102 +171,321 @@ __device__ __forceinline__ double cm_pava_last_dev(const double* y, int n) {
   return v[i] / w[i];
 }
 
-template <bool R_IN_LDS>
-__device__ __forceinline__ void sweep_step(const SweepArgs& a, int n, double* R, double sig, double thresh, int lane) {
+// Gate of a row held one entry per lane (<= 64 targeted trials): per-power mean rates by wave reductions, isotonic
+// tail, minimum spike count (caviar.py:219-221).  For P <= 8 powers everything stays in registers and the isotonic
+// tail uses its closed form max_j mean(srates[j:]) (== the pool walk's last value; tests/test_oracle_golden.py).
+__device__ __forceinline__ double row_gate(bool valid, int g, double est, int P, double thresh, double min_count, double* scr) {
+  const double total = cm_wave_sum(est);
+  double iso;
+  if (P <= 8) {
+    double sr[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      sr[p] = 0.0;
+      if (p < P) {
+        const bool in = valid && g == p + 1;
+        const double s = cm_wave_sum(in ? est : 0.0);
+        const int cnt = __popcll(__ballot(in));
+        sr[p] = s / ((double)cnt + 1e-4 * (double)(cnt == 0));          // caviar.py:183
+      }
+    }
+    double best = -1.0, s = 0.0;
+    int c = 0;
+#pragma unroll
+    for (int j = 7; j >= 0; --j) {
+      if (j < P) {
+        s += sr[j]; ++c;
+        const double m = s / (double)c;
+        best = m > best ? m : best;
+      }
+    }
+    iso = P > 0 ? best : 0.0;
+  } else {                                   // many powers: rates and pool stacks in the wave's LDS scratch (3 x 64 doubles)
+    double* sr = scr;
+    for (int p = 0; p < P; ++p) {
+      const bool in = valid && g == p + 1;
+      const double s = cm_wave_sum(in ? est : 0.0);
+      const int cnt = __popcll(__ballot(in));
+      sr[p] = s / ((double)cnt + 1e-4 * (double)(cnt == 0));     // every lane writes the same value
+    }
+    iso = cm_pava_last_dev(sr, P, scr + CM_MAX_VALS, scr + 2 * CM_MAX_VALS);
+  }
+  return (iso >= thresh && total >= min_count) ? 1.0 : 0.0;                // caviar.py:220
+}
+
+// generic (any row length) step straight from the CSR arrays: two passes over the row in chunks of 64
+template <bool USE_R, typename RPtr>
+__device__ __forceinline__ void sweep_step_long(const SweepArgs& a, int n, RPtr R, double sig, double thresh, int lane, double* scr) {
   const int beg = a.row_ptr[n], end = a.row_ptr[n + 1];
   const double mu = a.mu[n], be = a.beta[n];
   const double t3 = sig * (mu * mu + be * be);      // caviar.py:206 (beta squared again, quirk 1)
   const int P = a.V - 1;                            // powers = vals[1:]
-  double psum[8];
-  double total = 0.0;
-  double srate[CM_MAX_VALS];
-  // pass 1: est per entry, per-power sums
-  for (int p0 = 0; p0 < (P > 0 ? P : 1); p0 += 8) {
+  double pava = 1.0;
+  if (a.gated) {
+    double total = 0.0;
+    double* srate = scr;
+    for (int p0 = 0; p0 < (P > 0 ? P : 1); p0 += 8) {
+      double psum[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) psum[j] = 0.0;
-    for (int e0 = beg; e0 < end; e0 += CM_WAVE) {
-      const int e = e0 + lane;
-      double est = 0.0;
-      int g = -1;
-      if (e < end) {
-        const int k = a.col[e];
-        g = a.grp[e];
-        if (a.mask[k]) {
-          const double lo = a.lam[e];
-          const double loo = (mu != 0.0) ? sig * (R[k] - mu * lo) : 0.0;
-          const double arg = -2.0 * sig * a.y[k] * mu + 2.0 * mu * loo + t3;          // caviar.py:205-206
-          est = cm_sigmoid(a.mcE[(size_t)n * CM_MAX_VALS + g] - 0.5 * arg);            // caviar.py:216
+      for (int j = 0; j < 8; ++j) psum[j] = 0.0;
+      for (int e0 = beg; e0 < end; e0 += CM_WAVE) {
+        const int e = e0 + lane;
+        double est = 0.0;
+        int g = -1;
+        if (e < end) {
+          const int k = a.col[e];
+          g = a.grp[e];
+          if (a.mask[k]) {
+            const double lo = a.lam[e];
+            const double loo = USE_R ? sig * (R[k] - mu * lo) : 0.0;
+            const double arg = -2.0 * sig * a.y[k] * mu + 2.0 * mu * loo + t3;          // caviar.py:205-206
+            est = cm_sigmoid(a.mcE[(size_t)n * CM_MAX_VALS + g] - 0.5 * arg);            // caviar.py:216
+          }
+        }
+        if (p0 == 0) total += est;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) psum[j] += (g == p0 + j + 1) ? est : 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (p0 + j < P) {
+          const double s = cm_wave_sum(psum[j]);
+          const int cnt = a.rowcnt[(size_t)n * CM_MAX_VALS + p0 + j + 1];
+          srate[p0 + j] = s / ((double)cnt + 1e-4 * (double)(cnt == 0));                // caviar.py:183
         }
       }
-      if (p0 == 0) total += est;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) psum[j] += (g == p0 + j + 1) ? est : 0.0;
     }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (p0 + j < P) {
-        const double s = cm_wave_sum(psum[j]);
-        const int cnt = a.rowcnt[(size_t)n * CM_MAX_VALS + p0 + j + 1];
-        srate[p0 + j] = s / ((double)cnt + 1e-4 * (double)(cnt == 0));                  // caviar.py:183
-      }
-    }
+    total = cm_wave_sum(total);
+    const double iso = P > 0 ? cm_pava_last_dev(srate, P, scr + CM_MAX_VALS, scr + 2 * CM_MAX_VALS) : 0.0;
+    pava = (iso >= thresh && total >= a.min_count) ? 1.0 : 0.0;                          // caviar.py:220-221
   }
-  total = cm_wave_sum(total);
-  double pava = 1.0;
-  if (a.gated) {                                                                        // caviar.py:220-221
-    const double iso = P > 0 ? cm_pava_last_dev(srate, P) : 0.0;
-    pava = (iso >= thresh && total >= a.min_count) ? 1.0 : 0.0;
-  }
-  // pass 2: write lam, update R
   for (int e = beg + lane; e < end; e += CM_WAVE) {
     const int k = a.col[e];
     double est = 0.0;
     const double lo = a.lam[e];
     if (a.mask[k]) {
-      const double loo = (mu != 0.0) ? sig * (R[k] - mu * lo) : 0.0;
+      const double loo = USE_R ? sig * (R[k] - mu * lo) : 0.0;
       const double arg = -2.0 * sig * a.y[k] * mu + 2.0 * mu * loo + t3;
       est = cm_sigmoid(a.mcE[(size_t)n * CM_MAX_VALS + a.grp[e]] - 0.5 * arg);
     }
-    const double nl = est * pava;                                                       // caviar.py:224
+    const double nl = est * pava;                                                         // caviar.py:224
     a.lam[e] = nl;
-    if (mu != 0.0) R[k] += mu * (nl - lo);
+    if (USE_R) R[k] += mu * (nl - lo);
   }
 }
 
-// rows with mu == 0: independent of R and of each other -> one wave each, whole chip
+// rows with mu == 0: arg = sigma * beta^2 does not involve R and mu * lam contributes nothing to R, so these rows are
+// independent of the chain and of each other -> one wave each over the whole chip
 __global__ __launch_bounds__(256) void k_sweep_indep(SweepArgs a, int N) {
+  __shared__ double scr_all[4][3 * CM_MAX_VALS];
+  double* scr = scr_all[threadIdx.x / CM_WAVE];
   const int n = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE;
   const int lane = threadIdx.x % CM_WAVE;
   if (n >= N) return;
   if (a.mu[n] != 0.0) return;
   const double sig = a.scal[CM_S_SHAPE] / a.scal[CM_S_RATE];
   const double thresh = a.msrmp + a.scal[CM_S_SPONT_RATE];
-  sweep_step<false>(a, n, nullptr, sig, thresh, lane);
+  const int beg = a.row_ptr[n], len = a.row_ptr[n + 1] - beg;
+  if (len > CM_WAVE) { sweep_step_long<false>(a, n, (double*)nullptr, sig, thresh, lane, scr); return; }
+  const bool valid = lane < len;
+  const double be = a.beta[n];
+  const double arg = sig * (be * be);                // mu == 0: caviar.py:205-206 reduces to sigma * beta^2
+  int g = -1;
+  double est = 0.0;
+  if (valid) {
+    const int e = beg + lane;
+    g = a.grp[e];
+    if (a.mask[a.col[e]]) est = cm_sigmoid(a.mcE[(size_t)n * CM_MAX_VALS + g] - 0.5 * arg);
+  }
+  double pava = 1.0;
+  if (a.gated) pava = row_gate(valid, g, est, a.V - 1, thresh, a.min_count, scr);
+  if (valid) a.lam[beg + lane] = est * pava;
 }
 
-// R_k = sum_n mu_n lam_nk over the column (ascending neuron order), into LDS or global
+// ------------------------------------------------------------------------------------------------
+// The sequential chain (rows with mu != 0, in sweep order).
+//   k_seq_scan : ordered compaction of those rows + record offsets + chunk table      (one workgroup)
+//   k_seq_pack : per row, one 32-byte header + one 32-byte record per targeted trial holding everything the step
+//                needs (trial, power code, mask, CSR slot, lam_old, MC logit, -2 sigma y mu)   (whole chip)
+//   k_sweep_seq: one workgroup.  R lives in LDS; waves 1..15 stream the packed records of the NEXT chunk into an LDS
+//                double buffer while wave 0 walks the rows of the current chunk (software-pipelined LDS reads,
+//                DPP reductions), so no global-memory latency sits on the chain.
+// ------------------------------------------------------------------------------------------------
+struct __align__(16) SeqRec {
+  uint32_t a; int32_t b; double x, y, z;
+  // header: a = neuron, b = row length, x = mu, y = sigma (mu^2 + beta^2), z unused
+  // entry : a = trial | power code << 24 | mask << 31, b = CSR slot, x = lam_old, y = MC logit, z = -2 sigma y_k mu
+};
+#define CM_SEQ_CAP 1024                       // records per LDS buffer
+#define CM_SEQ_B (CM_SEQ_CAP - CM_WAVE - 1)   // chunking granule: a chunk spans < B + 65 <= CAP records
+#define CM_SEQ_LDS_CHUNKS 512
+
+__global__ __launch_bounds__(1024) void k_seq_scan(const int* __restrict__ order, const double* __restrict__ mu,
+                                                    const int* __restrict__ row_ptr, int N, int* __restrict__ seq_n,
+                                                    int* __restrict__ seq_off, int* __restrict__ chunk_first, int* __restrict__ meta) {
+  __shared__ int wsum[2][16];
+  __shared__ int carry[2];
+  if (threadIdx.x < 2) carry[threadIdx.x] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x % CM_WAVE, w = threadIdx.x / CM_WAVE;
+  for (int m0 = 0; m0 < N; m0 += 1024) {
+    const int m = m0 + threadIdx.x;
+    int f = 0, recs = 0, n = 0;
+    if (m < N) {
+      n = order[m];
+      f = mu[n] != 0.0;
+      const int len = row_ptr[n + 1] - row_ptr[n];
+      recs = f ? 1 + (len <= CM_WAVE ? len : 0) : 0;
+    }
+    int sf = f, sr = recs;                     // inclusive wave scans
+    for (int o = 1; o < CM_WAVE; o <<= 1) {
+      const int tf = __shfl_up(sf, o, CM_WAVE), tr = __shfl_up(sr, o, CM_WAVE);
+      if (lane >= o) { sf += tf; sr += tr; }
+    }
+    if (lane == CM_WAVE - 1) { wsum[0][w] = sf; wsum[1][w] = sr; }
+    __syncthreads();
+    int bf = carry[0], br = carry[1];
+    for (int i = 0; i < w; ++i) { bf += wsum[0][i]; br += wsum[1][i]; }
+    if (f) {
+      const int j = bf + sf - 1, off = br + sr - recs;     // exclusive positions
+      seq_n[j] = n;
+      seq_off[j] = off;
+      // chunk of this row = floor((end offset - 1) / B); first row of each chunk registers itself
+      const int c = (off + recs - 1) / CM_SEQ_B;
+      const int cprev = off == 0 ? -1 : (off - 1) / CM_SEQ_B;   // previous row ends at `off`
+      if (c != cprev) chunk_first[c] = j;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int tf = 0, tr = 0;
+      for (int i = 0; i < 16; ++i) { tf += wsum[0][i]; tr += wsum[1][i]; }
+      carry[0] += tf; carry[1] += tr;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int nseq = carry[0], total = carry[1];
+    const int nchunks = total > 0 ? (total - 1) / CM_SEQ_B + 1 : 0;
+    seq_off[nseq] = total;
+    chunk_first[nchunks] = nseq;
+    meta[0] = nseq; meta[1] = total; meta[2] = nchunks;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_seq_pack(SweepArgs a, const int* __restrict__ seq_n, const int* __restrict__ seq_off,
+                                                   const int* __restrict__ meta, SeqRec* __restrict__ packed) {
+  const int j = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE;
+  const int lane = threadIdx.x % CM_WAVE;
+  if (j >= meta[0]) return;
+  const int n = seq_n[j], off = seq_off[j];
+  const int beg = a.row_ptr[n], len = a.row_ptr[n + 1] - beg;
+  const double sig = a.scal[CM_S_SHAPE] / a.scal[CM_S_RATE];
+  const double mu = a.mu[n], be = a.beta[n];
+  if (lane == 0) {
+    SeqRec h;
+    h.a = (uint32_t)n; h.b = len; h.x = mu; h.y = sig * (mu * mu + be * be); h.z = 0.0;   // caviar.py:206
+    packed[off] = h;
+  }
+  if (len <= CM_WAVE && lane < len) {
+    const int e = beg + lane;
+    const int k = a.col[e], g = a.grp[e];
+    SeqRec r;
+    r.a = (uint32_t)k | ((uint32_t)g << 24) | ((uint32_t)(a.mask[k] != 0) << 31);
+    r.b = e;
+    r.x = a.lam[e];
+    r.y = a.mcE[(size_t)n * CM_MAX_VALS + g];
+    r.z = -2.0 * sig * a.y[k] * mu;                                                       // caviar.py:205, first term
+    packed[off + 1 + lane] = r;
+  }
+}
+
 template <bool R_IN_LDS>
-__global__ __launch_bounds__(1024) void k_sweep_seq(SweepArgs a, const int* __restrict__ order, int N, int K,
+__global__ __launch_bounds__(1024) void k_sweep_seq(SweepArgs a, const SeqRec* __restrict__ packed, const int* __restrict__ seq_off,
+                                                     const int* __restrict__ chunk_first, const int* __restrict__ meta, int K,
                                                      const int* __restrict__ col_ptr, const int* __restrict__ csc_row,
                                                      const int* __restrict__ csc_pos, double* __restrict__ Rg) {
+  __shared__ SeqRec buf[2][CM_SEQ_CAP];
+  __shared__ int cfo[CM_SEQ_LDS_CHUNKS][2];      // per chunk: first row, first record offset
+  __shared__ double scr[3 * CM_MAX_VALS];
   extern __shared__ double Rl[];
-  double* R = R_IN_LDS ? Rl : Rg;
+#define R_AT(k) (R_IN_LDS ? Rl[k] : Rg[k])
+  const int nseq = meta[0], nchunks = meta[2];
+  if (nseq == 0) return;
+  for (int i = threadIdx.x; i <= nchunks && i < CM_SEQ_LDS_CHUNKS; i += blockDim.x) {
+    const int f = chunk_first[i];
+    cfo[i][0] = f; cfo[i][1] = seq_off[f];
+  }
+  __syncthreads();
+  auto first_row = [&](int c) { return c < CM_SEQ_LDS_CHUNKS ? cfo[c][0] : chunk_first[c]; };
+  auto first_off = [&](int c) { return c < CM_SEQ_LDS_CHUNKS ? cfo[c][1] : seq_off[chunk_first[c]]; };
+  // R_k = sum_n mu_n lam_nk, ascending neuron order (= lam.T @ mu restricted to the targeted entries)
   for (int k = threadIdx.x; k < K; k += blockDim.x) {
     double s = 0.0;
     for (int ce = col_ptr[k]; ce < col_ptr[k + 1]; ++ce) s = fma(a.mu[csc_row[ce]], a.lam[csc_pos[ce]], s);
-    R[k] = s;
+    if (R_IN_LDS) Rl[k] = s; else Rg[k] = s;
+  }
+  const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE;
+  const double sig = a.scal[CM_S_SHAPE] / a.scal[CM_S_RATE];
+  const double thresh = a.msrmp + a.scal[CM_S_SPONT_RATE];
+  const int P = a.V - 1;
+  // chunk 0 is loaded by everybody
+  {
+    const int o0 = first_off(0), o1 = first_off(1);
+    for (int i = threadIdx.x; i < o1 - o0; i += blockDim.x) buf[0][i] = packed[o0 + i];
   }
   __syncthreads();
-  if (threadIdx.x < CM_WAVE) {
-    const int lane = threadIdx.x;
-    const double sig = a.scal[CM_S_SHAPE] / a.scal[CM_S_RATE];
-    const double thresh = a.msrmp + a.scal[CM_S_SPONT_RATE];
-    for (int m = 0; m < N; ++m) {
-      const int n = order[m];
-      if (a.mu[n] == 0.0) continue;
-      sweep_step<R_IN_LDS>(a, n, R, sig, thresh, lane);
+  int cur = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    if (wave > 0) {
+      if (c + 1 < nchunks) {                                   // producers: stream chunk c + 1 into the other buffer
+        const int o0 = first_off(c + 1), o1 = first_off(c + 2);
+        for (int i = threadIdx.x - CM_WAVE; i < o1 - o0; i += blockDim.x - CM_WAVE) buf[cur ^ 1][i] = packed[o0 + i];
+      }
+    } else {                                                   // consumer: the Gauss-Seidel chain
+      const int rows = first_row(c + 1) - first_row(c);
+      int pos = 0;
+      SeqRec h = buf[cur][0];
+      SeqRec r = buf[cur][min(1 + lane, CM_SEQ_CAP - 1)];
+      for (int j = 0; j < rows; ++j) {
+        const int len = h.b;
+        const bool lng = len > CM_WAVE;
+        const int npos = pos + 1 + (lng ? 0 : len);
+        // software pipeline: the next row's header and records are requested before this row is computed
+        const SeqRec hn = buf[cur][min(npos, CM_SEQ_CAP - 1)];
+        const SeqRec rn = buf[cur][min(npos + 1 + lane, CM_SEQ_CAP - 1)];
+        if (lng) {
+          if (R_IN_LDS) sweep_step_long<true>(a, (int)h.a, Rl, sig, thresh, lane, scr);
+          else sweep_step_long<true>(a, (int)h.a, Rg, sig, thresh, lane, scr);
+        } else {
+          const bool valid = lane < len;
+          const double mu = h.x, t3 = h.y;
+          const int k = (int)(r.a & 0xFFFFFFu), g = (int)((r.a >> 24) & 0x7Fu);
+          const bool msk = (r.a >> 31) != 0u;
+          double est = 0.0, rk = 0.0;
+          if (valid) {
+            rk = R_AT(k);
+            if (msk) {
+              const double loo = sig * (rk - mu * r.x);
+              const double arg = r.z + 2.0 * mu * loo + t3;                              // caviar.py:205-206
+              est = cm_sigmoid(r.y - 0.5 * arg);                                         // caviar.py:216
+            }
+          }
+          double pava = 1.0;
+          if (a.gated) pava = row_gate(valid, g, est, P, thresh, a.min_count, scr);      // caviar.py:219-221
+          if (valid) {
+            const double nl = est * pava;                                                // caviar.py:224
+            a.lam[r.b] = nl;
+            const double rnew = rk + mu * (nl - r.x);
+            if (R_IN_LDS) Rl[k] = rnew; else Rg[k] = rnew;
+          }
+        }
+        h = hn; r = rn; pos = npos;
+      }
     }
+    __syncthreads();
+    cur ^= 1;
   }
+#undef R_AT
 }
 
 int cm_launch_rng(cm_ctx* ctx, cm_problem* p, int it, int S, int rng_mode, double* d_u_out) {
@@ -319,15 +537,20 @@ int cm_launch_sweep(cm_ctx* ctx, cm_problem* p, int it, const cm_options* o, hip
   a.gated = it > o->delay_spont_est;
   a.msrmp = o->msrmp; a.min_count = o->minimum_spike_count;
   hipStream_t st = ctx->stream;
-  hipLaunchKernelGGL(k_sweep_indep, dim3((p->N + 3) / 4), dim3(256), 0, st, a, p->N);
+  const int N = p->N;
+  hipLaunchKernelGGL(k_sweep_indep, dim3((N + 3) / 4), dim3(256), 0, st, a, N);
+  hipLaunchKernelGGL(k_seq_scan, dim3(1), dim3(1024), 0, st, p->order, p->mu, p->row_ptr, N, p->seq_n, p->seq_off, p->chunk_first, p->seq_meta);
+  hipLaunchKernelGGL(k_seq_pack, dim3((N + 3) / 4), dim3(256), 0, st, a, p->seq_n, p->seq_off, p->seq_meta, (SeqRec*)p->packed);
   if (mid) CM_HIP(hipEventRecord(mid, st));
   const size_t lds = (size_t)p->K * sizeof(double);
-  if (lds <= 120 * 1024) {
-    if (lds > 48 * 1024)
+  if (lds <= 88 * 1024) {     // 64 KiB of record buffers + R must fit the CU's 160 KiB
+    if (lds > 0)
       CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_seq<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_sweep_seq<true>, dim3(1), dim3(1024), lds, st, a, p->order, p->N, p->K, p->col_ptr, p->csc_row, p->csc_pos, p->R);
+    hipLaunchKernelGGL(k_sweep_seq<true>, dim3(1), dim3(1024), lds, st, a, (const SeqRec*)p->packed, p->seq_off, p->chunk_first,
+                       p->seq_meta, p->K, p->col_ptr, p->csc_row, p->csc_pos, p->R);
   } else {
-    hipLaunchKernelGGL(k_sweep_seq<false>, dim3(1), dim3(1024), 0, st, a, p->order, p->N, p->K, p->col_ptr, p->csc_row, p->csc_pos, p->R);
+    hipLaunchKernelGGL(k_sweep_seq<false>, dim3(1), dim3(1024), 0, st, a, (const SeqRec*)p->packed, p->seq_off, p->chunk_first,
+                       p->seq_meta, p->K, p->col_ptr, p->csc_row, p->csc_pos, p->R);
   }
   CM_HIP(hipGetLastError());
   return CM_OK;
