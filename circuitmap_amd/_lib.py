@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcaviar_hip.so")
+LIB_PATH = os.environ.get("CAVIAR_HIP_LIB", os.path.join(_HERE, "libcaviar_hip.so"))   # override: A/B builds of the same ABI
 
 CM_OK = 0
 CM_MEM_HOST, CM_MEM_DEVICE = 0, 1

@@ -96,8 +96,8 @@ extern "C" int cm_problem_destroy(cm_problem* p) {
   hipStreamSynchronize(p->ctx->stream);
   void* ptrs[] = {p->y, p->ss, p->sum_y, p->vals, p->row_ptr, p->col, p->grp, p->rowcnt, p->col_ptr, p->csc_row, p->csc_pos,
                   p->mask, p->lam, p->mu, p->beta, p->mu_prior, p->beta_prior, p->phi, p->phi_cov, p->phi_prior, p->phi_cov_prior,
-                  p->scal, p->R, p->colany, p->z, p->mcE, p->rs, p->act_idx, p->act_inv, p->n_act, p->order, p->perm_tmp,
-                  p->sort_keys, p->keys, p->uexp, p->orders_exp, p->A, p->X, p->Dinv, p->rhs, p->seq_n, p->seq_off, p->chunk_first,
+                  p->scal, p->R, p->colany, p->z, p->mcE, p->rs, p->act_idx, p->act_inv, p->n_act, p->orders_all, p->orders_tmp,
+                  p->keys, p->uexp, p->A, p->X, p->Dinv, p->rhs, p->seq_n, p->seq_off, p->chunk_first,
                   p->seq_meta, p->packed};
   for (void* q : ptrs) if (q) hipFree(q);
   free_hist(p);
@@ -140,8 +140,7 @@ extern "C" int cm_problem_create(cm_ctx* ctx, int32_t N, int32_t K, int32_t T, c
       (rc = dmalloc(&p->phi_cov_prior, 4 * (size_t)N)) || (rc = dmalloc(&p->scal, CM_S_COUNT)) || (rc = dmalloc(&p->R, K)) ||
       (rc = dmalloc(&p->colany, K)) || (rc = dmalloc(&p->z, K)) || (rc = dmalloc(&p->mcE, (size_t)N * CM_MAX_VALS)) ||
       (rc = dmalloc(&p->rs, 4 * (size_t)N)) || (rc = dmalloc(&p->act_idx, N)) || (rc = dmalloc(&p->act_inv, N)) ||
-      (rc = dmalloc(&p->n_act, 4)) || (rc = dmalloc(&p->order, N)) || (rc = dmalloc(&p->perm_tmp, N)) ||
-      (rc = dmalloc(&p->sort_keys, N)) || (rc = dmalloc(&p->A, ld * ld)) || (rc = dmalloc(&p->X, ld * ld)) ||
+      (rc = dmalloc(&p->n_act, 4)) || (rc = dmalloc(&p->A, ld * ld)) || (rc = dmalloc(&p->X, ld * ld)) ||
       (rc = dmalloc(&p->Dinv, ld * CM_TILE)) || (rc = dmalloc(&p->rhs, 2 * ld)) || (rc = dmalloc(&p->seq_n, N)) ||
       (rc = dmalloc(&p->seq_off, (size_t)N + 1)) || (rc = dmalloc(&p->chunk_first, ((size_t)N + p->nnz) / 512 + 8)) ||
       (rc = dmalloc(&p->seq_meta, 4)) || (rc = dmalloc((char**)&p->packed, ((size_t)N + p->nnz) * 32)))
@@ -214,32 +213,39 @@ static void host_reconnect(const cm_problem* p, std::vector<double>& mu, std::ve
   const size_t init = disc.size();
   // np.where(stim_matrix[n]) selects NON-ZERO entries; targeted entries (> 0) are the CSR row.  Negative stimulus values
   // are outside the reference's contract (powers are non-negative) and are treated as untargeted here.
+  // The reference recounts, for every remaining cell, the spontaneous events on its targeted trials in every pass
+  // (:112-114).  The counts only change when a reconnection clears events, so they are kept and refreshed then.
+  long nz = 0;
+  for (int k = 0; k < K; ++k) nz += (z[k] != 0.0);
+  std::vector<long> cnt(disc.size());
+  auto recount = [&]() {
+    for (size_t i = 0; i < disc.size(); ++i) {
+      long c = 0;
+      for (int e = p->h_row_ptr[disc[i]]; e < p->h_row_ptr[disc[i] + 1]; ++e) c += (z[p->h_col[e]] != 0.0);
+      cnt[i] = c;
+    }
+  };
+  recount();
   while (!disc.empty()) {
-    long nz = 0;
-    for (int k = 0; k < K; ++k) nz += (z[k] != 0.0);
     if (!((double)nz > minimum_spike_count)) break;                           // :111,141
     int focus_indx = 0; long best = -1;
-    for (size_t i = 0; i < disc.size(); ++i) {                                // :112-117 (argmax takes the first maximum)
-      const int n = disc[i];
-      long c = 0;
-      for (int e = p->h_row_ptr[n]; e < p->h_row_ptr[n + 1]; ++e) c += (z[p->h_col[e]] != 0.0);
-      if (c > best) { best = c; focus_indx = (int)i; }
-    }
+    for (size_t i = 0; i < disc.size(); ++i)                                  // :117 (argmax takes the first maximum)
+      if (cnt[i] > best) { best = cnt[i]; focus_indx = (int)i; }
     const int focus = disc[focus_indx];
     std::vector<double> srates(P > 0 ? P : 0, 0.0);
     double spike_count = 0.0;
     for (int i = 0; i < P; ++i) {                                             // :121-127
-      long cnt = 0, hit = 0;
+      long c = 0, hit = 0;
       for (int e = p->h_row_ptr[focus]; e < p->h_row_ptr[focus + 1]; ++e)
-        if (p->h_grp[e] == i + 1) { ++cnt; hit += (z[p->h_col[e]] != 0.0); }
-      if (cnt > 0) { srates[i] = (double)hit / (double)cnt; spike_count += (double)hit; }
+        if (p->h_grp[e] == i + 1) { ++c; hit += (z[p->h_col[e]] != 0.0); }
+      if (c > 0) { srates[i] = (double)hit / (double)c; spike_count += (double)hit; }
     }
     const double pava = P > 0 ? cm_host_pava_last(srates.data(), P) : 0.0;    // :128
+    bool changed = false;
     if (pava >= minimax_spk_prob && spike_count >= minimum_spike_count) {     // :130
       std::vector<int> locs;
       for (int e = p->h_row_ptr[focus]; e < p->h_row_ptr[focus + 1]; ++e) if (z[p->h_col[e]] != 0.0) locs.push_back(e);
       const size_t m = locs.size();
-      // np.mean: pairwise summation; m is small (a cell's targeted trials), plain left-to-right sum matches for m < 8
       double s = 0.0;
       for (int e : locs) s += z[p->h_col[e]];
       const double mean = s / (double)m;
@@ -248,9 +254,13 @@ static void host_reconnect(const cm_problem* p, std::vector<double>& mu, std::ve
       mu[focus] = mean;                                                        // :134
       beta[focus] = m > 1 ? sqrt(ssd / (double)(m - 1)) / sqrt((double)m) : NAN;   // :135 scipy.stats.sem, ddof = 1
       for (int e : locs) { lam[e] = 1.0; z[p->h_col[e]] = 0.0; }               // :136-137
+      nz -= (long)m;
+      changed = m > 0;
       if (verbose) fprintf(stderr, "Reconnecting cell %d with maximal pava spike rate %.2f\n", focus, pava);
     }
     disc.erase(disc.begin() + focus_indx);                                     // :139
+    cnt.erase(cnt.begin() + focus_indx);
+    if (changed) recount();
   }
   if (verbose) fprintf(stderr, "Examined %zu/%d cells for false negatives. Cell reconnection complete.\n", init, N);
 }
@@ -293,14 +303,20 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
   p->ran = false;
   CM_HIP(hipEventRecord(ctx->ev[0], st));
 
-  // RNG streams
+  // RNG streams: sweep orders of all iterations live in orders_all (uploaded, or generated below in one batched launch)
+  if (p->orders_cap < iters) {
+    if (p->orders_all) hipFree(p->orders_all);
+    if (p->orders_tmp) hipFree(p->orders_tmp);
+    p->orders_all = p->orders_tmp = nullptr;
+    CM_TRY(dmalloc(&p->orders_all, (size_t)iters * N));
+    CM_TRY(dmalloc(&p->orders_tmp, (size_t)iters * N));
+    p->orders_cap = iters;
+  }
   if (o->rng_mode == CM_RNG_EXPLICIT) {
     if (p->uexp) { hipFree(p->uexp); p->uexp = nullptr; }
-    if (p->orders_exp) { hipFree(p->orders_exp); p->orders_exp = nullptr; }
     CM_TRY(dmalloc(&p->uexp, (size_t)iters * N * S * 2));
-    CM_TRY(dmalloc(&p->orders_exp, (size_t)iters * N));
     CM_HIP(hipMemcpyAsync(p->uexp, o->uniforms, (size_t)iters * N * S * 2 * sizeof(double), hipMemcpyHostToDevice, st));
-    CM_HIP(hipMemcpyAsync(p->orders_exp, o->update_orders, (size_t)iters * N * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    CM_HIP(hipMemcpyAsync(p->orders_all, o->update_orders, (size_t)iters * N * sizeof(int32_t), hipMemcpyHostToDevice, st));
   }
   CM_TRY(upload_priors(ctx, p, pr));
   CM_TRY(cm_launch_init_state(ctx, p, o->y_xcorr_thresh));
@@ -316,6 +332,7 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
       p->keys_iters = iters;
     }
     CM_HIP(hipMemcpyAsync(p->keys, keys.data(), keys.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    CM_TRY(cm_launch_rng(ctx, p, 0, iters));           // :196 update orders of every iteration (data independent)
   }
   if (o->save_histories && iters > 0) CM_TRY(alloc_hist(p, iters)); else free_hist(p);
 
@@ -333,7 +350,7 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
     sum_active += last_active;
     if (ctx->h_pinned[1]) { cm_set_error("iteration %d: weight precision matrix not positive definite", it); return CM_ERR_NOT_SPD; }
     if (timed) CM_HIP(hipEventRecord(ev[1], st));
-    CM_TRY(cm_launch_rng(ctx, p, it, S, o->rng_mode, nullptr));      // :196 update order
+    p->order = p->orders_all + (size_t)it * N;
     CM_TRY(cm_launch_mc_logit(ctx, p, it, S, o->rng_mode));          // :209-215
     if (timed) CM_HIP(hipEventRecord(ev[2], st));
     CM_TRY(cm_launch_sweep(ctx, p, it, o, timed ? ev[3] : nullptr)); // :81  update_lam
@@ -540,19 +557,20 @@ extern "C" int cm_k_rng_streams(cm_ctx* ctx, uint64_t seed, int32_t it, int32_t 
   cm_host_key_schedule(seed, it + 1, N, keys);
   double* d_u = nullptr;
   int rc = CM_OK;
-  if ((rc = dmalloc(&q.keys, keys.size())) || (rc = dmalloc(&q.order, N)) || (rc = dmalloc(&q.perm_tmp, N)) ||
-      (rc = dmalloc(&q.sort_keys, N)) || (rc = dmalloc(&q.phi, 2 * (size_t)N)) || (rc = dmalloc(&q.phi_cov, 4 * (size_t)N)) ||
+  if ((rc = dmalloc(&q.keys, keys.size())) || (rc = dmalloc(&q.orders_all, (size_t)(it + 1) * N)) ||
+      (rc = dmalloc(&q.orders_tmp, (size_t)(it + 1) * N)) || (rc = dmalloc(&q.phi, 2 * (size_t)N)) || (rc = dmalloc(&q.phi_cov, 4 * (size_t)N)) ||
       (rc = dmalloc(&q.mcE, 1)) || (rc = dmalloc(&q.vals, CM_MAX_VALS)) || (rc = dmalloc(&d_u, (size_t)N * S * 2))) {
   } else if (hipMemcpyAsync(q.keys, keys.data(), keys.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
              hipMemsetAsync(q.phi, 0, (size_t)N * 16, st) != hipSuccess || hipMemsetAsync(q.phi_cov, 0, (size_t)N * 32, st) != hipSuccess) {
     cm_set_error("rng upload failed"); rc = CM_ERR_HIP;
   }
-  if (!rc) rc = cm_launch_rng(ctx, &q, it, S, CM_RNG_THREEFRY, nullptr);
+  if (!rc) rc = cm_launch_rng(ctx, &q, 0, it + 1);
+  q.order = q.orders_all + (size_t)it * N;
   if (!rc) rc = cm_k_rng_streams_impl(ctx, &q, it, S, d_u);
   if (!rc && (hipMemcpyAsync(order, q.order, (size_t)N * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
               hipMemcpyAsync(u, d_u, (size_t)N * S * 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
               hipStreamSynchronize(st) != hipSuccess)) { cm_set_error("rng download failed: %s", hipGetErrorString(hipGetLastError())); rc = CM_ERR_HIP; }
-  void* ptrs[] = {q.keys, q.order, q.perm_tmp, q.sort_keys, q.phi, q.phi_cov, q.mcE, q.vals, d_u};
+  void* ptrs[] = {q.keys, q.orders_all, q.orders_tmp, q.phi, q.phi_cov, q.mcE, q.vals, d_u};
   for (void* x : ptrs) if (x) hipFree(x);
   return rc;
 }

@@ -80,9 +80,10 @@ struct cm_problem {
   int32_t* act_idx = nullptr; // [N] active neurons (compact list)
   int32_t* act_inv = nullptr; // [N] neuron -> compact index or -1
   int32_t* n_act = nullptr;   // [4] device: N_a, flags
-  int32_t* order = nullptr;   // [N] sweep order of the current iteration
-  int32_t* perm_tmp = nullptr;// [N] ping-pong buffer of the shuffle rounds
-  uint32_t* sort_keys = nullptr; // [N] 32-bit sort keys of one shuffle round
+  int32_t* order = nullptr;   // sweep order of the current iteration (points into orders_all)
+  int32_t* orders_all = nullptr; // [iters*N] sweep orders of every iteration (device generated, or the explicit stream)
+  int32_t* orders_tmp = nullptr; // [iters*N] ping-pong buffer of the shuffle rounds
+  int32_t orders_cap = 0;     // iterations the two buffers are sized for
   int32_t* seq_n = nullptr;   // [N]   neurons with mu != 0 in sweep order
   int32_t* seq_off = nullptr; // [N+1] record offset of each such row in `packed`
   int32_t* chunk_first = nullptr; // [n_chunk_cap] first row of each LDS chunk
@@ -90,7 +91,6 @@ struct cm_problem {
   void* packed = nullptr;     // [(N + nnz) * 32 B] packed row records of the sequential chain
   uint32_t* keys = nullptr;   // [iters*(N+3)*2] threefry key schedule (host computed)
   double* uexp = nullptr;     // explicit uniforms (device copy) or nullptr
-  int32_t* orders_exp = nullptr;
   double* A = nullptr;        // [ld*ld] precision matrix / Cholesky factor
   double* X = nullptr;        // [ld*ld] inverse factor
   double* Dinv = nullptr;     // [ld*CM_TILE] inverses of the diagonal tiles
@@ -210,7 +210,7 @@ int cm_launch_scatter_dense_lam(cm_ctx* ctx, cm_problem* p, const double* d_lam_
 int cm_launch_expand_lam(cm_ctx* ctx, cm_problem* p, const double* d_lam_sparse, double* d_dense);
 
 int cm_solve_mu(cm_ctx* ctx, cm_problem* p, int* n_active_out);                      // syncs once (active-set size)
-int cm_launch_rng(cm_ctx* ctx, cm_problem* p, int it, int S, int rng_mode, double* d_u_out);
+int cm_launch_rng(cm_ctx* ctx, cm_problem* p, int it0, int n_it);
 int cm_launch_mc_logit(cm_ctx* ctx, cm_problem* p, int it, int S, int rng_mode);
 int cm_launch_sweep(cm_ctx* ctx, cm_problem* p, int it, const cm_options* o, hipEvent_t mid);
 int cm_launch_post(cm_ctx* ctx, cm_problem* p, int it, const cm_options* o);

@@ -72,29 +72,37 @@ __device__ __forceinline__ uint32_t cm_bits32(uint32_t k0, uint32_t k1, int i, i
   return x1;
 }
 
-// One round of jax's sort-based shuffle: stable sort of `in` by fresh 32-bit keys, done as rank-by-counting.
-__global__ __launch_bounds__(256) void k_perm_round(const uint32_t* __restrict__ keys, int round, const int* __restrict__ in,
-                                                     int* __restrict__ out, int N, uint32_t* __restrict__ sk) {
-  // phase split over two launches by `out == nullptr`: first fill the sort keys, then rank
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (out == nullptr) {
-    if (i < N) sk[i] = cm_bits32(keys[2 * round], keys[2 * round + 1], i, N);
-    return;
-  }
-  __shared__ uint32_t tile[256];
-  const uint32_t mine = i < N ? sk[i] : 0u;
+// One round of jax's sort-based shuffle for ALL iterations at once (the streams are data independent): stable sort of
+// `in` by fresh 32-bit keys, done as rank-by-counting.  grid = (ceil(N / 64), iters); a block ranks 64 elements, its
+// four waves each scanning a quarter of every 1024-key tile (same-address LDS reads broadcast).
+__global__ __launch_bounds__(256) void k_perm_batch(const uint32_t* __restrict__ keys_all, int key_stride, int round,
+                                                     const int* __restrict__ in_all, int* __restrict__ out_all, int N) {
+  __shared__ uint32_t tile[1024];
+  __shared__ int part_rank[4][64];
+  const int it = blockIdx.y;
+  const uint32_t* keys = keys_all + (size_t)it * key_stride;
+  const uint32_t k0 = keys[2 * round], k1 = keys[2 * round + 1];
+  const int li = threadIdx.x % 64, part = threadIdx.x / 64;
+  const int i = blockIdx.x * 64 + li;
+  const uint32_t mine = i < N ? cm_bits32(k0, k1, i, N) : 0u;
   int rank = 0;
-  for (int j0 = 0; j0 < N; j0 += 256) {
+  for (int j0 = 0; j0 < N; j0 += 1024) {
     __syncthreads();
-    tile[threadIdx.x] = (j0 + (int)threadIdx.x < N) ? sk[j0 + threadIdx.x] : 0xFFFFFFFFu;
+    for (int q = threadIdx.x; q < 1024; q += 256) tile[q] = (j0 + q < N) ? cm_bits32(k0, k1, j0 + q, N) : 0xFFFFFFFFu;
     __syncthreads();
-    const int lim = min(256, N - j0);
-    for (int j = 0; j < lim; ++j) {
+    const int lim = min(1024, N - j0);
+    const int jb = part * 256, je = min(jb + 256, lim);
+    for (int j = jb; j < je; ++j) {
       const uint32_t o = tile[j];
       rank += (o < mine) || (o == mine && (j0 + j) < i);
     }
   }
-  if (i < N) out[rank] = in ? in[i] : i;
+  part_rank[part][li] = rank;
+  __syncthreads();
+  if (part == 0 && i < N) {
+    const int r = part_rank[0][li] + part_rank[1][li] + part_rank[2][li] + part_rank[3][li];
+    out_all[(size_t)it * N + r] = in_all ? in_all[(size_t)it * N + i] : i;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -178,26 +186,33 @@ __device__ __forceinline__ double row_gate(bool valid, int g, double est, int P,
   const double total = cm_wave_sum(est);
   double iso;
   if (P <= 8) {
-    double sr[8];
+    // the P rate divisions run in P different lanes at once, and so do the P suffix-mean divisions
+    const int lane = (int)(threadIdx.x % CM_WAVE);
+    double num = 0.0, den = 1.0;
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
-      sr[p] = 0.0;
       if (p < P) {
         const bool in = valid && g == p + 1;
         const double s = cm_wave_sum(in ? est : 0.0);
         const int cnt = __popcll(__ballot(in));
-        sr[p] = s / ((double)cnt + 1e-4 * (double)(cnt == 0));          // caviar.py:183
+        if (lane == p) { num = s; den = (double)cnt + 1e-4 * (double)(cnt == 0); }   // caviar.py:183
       }
     }
-    double best = -1.0, s = 0.0;
+    const double sr_l = num / den;                 // lane p: mean rate at power p
+    double S = 0.0, numj = 0.0, denj = 1.0;
     int c = 0;
 #pragma unroll
     for (int j = 7; j >= 0; --j) {
       if (j < P) {
-        s += sr[j]; ++c;
-        const double m = s / (double)c;
-        best = m > best ? m : best;
+        S += cm_readlane_f64(sr_l, j); ++c;
+        if (lane == j) { numj = S; denj = (double)c; }
       }
+    }
+    const double m_l = numj / denj;                // lane j: mean(srates[j:])
+    double best = -1.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < P) { const double m = cm_readlane_f64(m_l, j); best = m > best ? m : best; }
     }
     iso = P > 0 ? best : 0.0;
   } else {                                   // many powers: rates and pool stacks in the wave's LDS scratch (3 x 64 doubles)
@@ -316,7 +331,10 @@ struct __align__(16) SeqRec {
   // header: a = neuron, b = row length, x = mu, y = sigma (mu^2 + beta^2), z unused
   // entry : a = trial | power code << 24 | mask << 31, b = CSR slot, x = lam_old, y = MC logit, z = -2 sigma y_k mu
 };
-#define CM_SEQ_CAP 1024                       // records per LDS buffer
+#ifndef CM_SEQ_CAP
+#define CM_SEQ_CAP 1024
+#endif
+//                       // records per LDS buffer
 #define CM_SEQ_B (CM_SEQ_CAP - CM_WAVE - 1)   // chunking granule: a chunk spans < B + 65 <= CAP records
 #define CM_SEQ_LDS_CHUNKS 512
 
@@ -418,12 +436,9 @@ __global__ __launch_bounds__(1024) void k_sweep_seq(SweepArgs a, const SeqRec* _
   __syncthreads();
   auto first_row = [&](int c) { return c < CM_SEQ_LDS_CHUNKS ? cfo[c][0] : chunk_first[c]; };
   auto first_off = [&](int c) { return c < CM_SEQ_LDS_CHUNKS ? cfo[c][1] : seq_off[chunk_first[c]]; };
-  // R_k = sum_n mu_n lam_nk, ascending neuron order (= lam.T @ mu restricted to the targeted entries)
-  for (int k = threadIdx.x; k < K; k += blockDim.x) {
-    double s = 0.0;
-    for (int ce = col_ptr[k]; ce < col_ptr[k + 1]; ++ce) s = fma(a.mu[csc_row[ce]], a.lam[csc_pos[ce]], s);
-    if (R_IN_LDS) Rl[k] = s; else Rg[k] = s;
-  }
+  // R_k = sum_n mu_n lam_nk was formed by the column kernel (cm_launch_col_stats) just before this launch
+  if (R_IN_LDS)
+    for (int k = threadIdx.x; k < K; k += blockDim.x) Rl[k] = Rg[k];
   const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE;
   const double sig = a.scal[CM_S_SHAPE] / a.scal[CM_S_RATE];
   const double thresh = a.msrmp + a.scal[CM_S_SPONT_RATE];
@@ -488,22 +503,18 @@ __global__ __launch_bounds__(1024) void k_sweep_seq(SweepArgs a, const SeqRec* _
 #undef R_AT
 }
 
-int cm_launch_rng(cm_ctx* ctx, cm_problem* p, int it, int S, int rng_mode, double* d_u_out) {
-  (void)S; (void)d_u_out;
+// Sweep orders of iterations [it0, it0 + n_it) into p->orders_all (caviar.py:196); threefry mode only.
+int cm_launch_rng(cm_ctx* ctx, cm_problem* p, int it0, int n_it) {
   hipStream_t st = ctx->stream;
   const int N = p->N;
-  if (rng_mode == CM_RNG_EXPLICIT) {
-    CM_HIP(hipMemcpyAsync(p->order, p->orders_exp + (size_t)it * N, (size_t)N * sizeof(int), hipMemcpyDeviceToDevice, st));
-    return CM_OK;
-  }
-  const uint32_t* keys = p->keys + (size_t)it * (N + 3) * 2;
   const int rounds = cm_perm_rounds(N);           // >= 1 for N >= 2
-  const int blocks = (N + 255) / 256;
+  const uint32_t* keys = p->keys + (size_t)it0 * (N + 3) * 2;
+  int* fin = p->orders_all + (size_t)it0 * N;
+  int* tmp = p->orders_tmp + (size_t)it0 * N;
   const int* in = nullptr;                        // nullptr = identity (jnp.arange(N))
   for (int r = 0; r < rounds; ++r) {
-    int* out = ((rounds - 1 - r) % 2 == 0) ? p->order : p->perm_tmp;   // ping-pong so the last round lands in p->order
-    hipLaunchKernelGGL(k_perm_round, dim3(blocks), dim3(256), 0, st, keys, r, (const int*)nullptr, (int*)nullptr, N, p->sort_keys);
-    hipLaunchKernelGGL(k_perm_round, dim3(blocks), dim3(256), 0, st, keys, r, in, out, N, p->sort_keys);
+    int* out = ((rounds - 1 - r) % 2 == 0) ? fin : tmp;    // ping-pong so the last round lands in orders_all
+    hipLaunchKernelGGL(k_perm_batch, dim3((N + 63) / 64, n_it), dim3(256), 0, st, keys, (N + 3) * 2, r, in, out, N);
     in = out;
   }
   CM_HIP(hipGetLastError());
@@ -541,6 +552,7 @@ int cm_launch_sweep(cm_ctx* ctx, cm_problem* p, int it, const cm_options* o, hip
   hipLaunchKernelGGL(k_sweep_indep, dim3((N + 3) / 4), dim3(256), 0, st, a, N);
   hipLaunchKernelGGL(k_seq_scan, dim3(1), dim3(1024), 0, st, p->order, p->mu, p->row_ptr, N, p->seq_n, p->seq_off, p->chunk_first, p->seq_meta);
   hipLaunchKernelGGL(k_seq_pack, dim3((N + 3) / 4), dim3(256), 0, st, a, p->seq_n, p->seq_off, p->seq_meta, (SeqRec*)p->packed);
+  CM_TRY(cm_launch_col_stats(ctx, p, o->spont_orthogonality));     // R = lam.T @ mu with the new mu (colany is recomputed later)
   if (mid) CM_HIP(hipEventRecord(mid, st));
   const size_t lds = (size_t)p->K * sizeof(double);
   if (lds <= 88 * 1024) {     // 64 KiB of record buffers + R must fit the CU's 160 KiB
