@@ -145,7 +145,7 @@ def main():
         dense_equiv_bytes = 12 * N * K                                             # I + lam read + lam write, fp32 dense
         achieved = sparse_bytes / (seq_ms * 1e-3) / 1e9
         phase = {k: float(np.mean([t[k] for t in tms])) for k in
-                 ("total_ms", "iters_ms", "fn_scan_ms", "solve_ms", "mc_ms", "sweep_indep_ms", "sweep_seq_ms", "post_ms")}
+                 ("total_ms", "iters_ms", "fn_scan_ms", "solve_ms", "mc_ms", "mc_wait_ms", "sweep_indep_ms", "sweep_seq_ms", "post_ms")}
         out = {
             "metric": "CAVIaR iterations/sec (N=%d, K=%d, T=%d)" % (N, K, T),
             "value": value, "unit": "iterations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

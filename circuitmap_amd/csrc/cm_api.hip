@@ -51,6 +51,7 @@ extern "C" int cm_ctx_create(int device_id, void* hip_stream, cm_ctx** out) {
   c->device = device_id;
   if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
   else { CM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+  CM_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
   for (auto& e : c->ev) CM_HIP(hipEventCreate(&e));
   CM_HIP(hipHostMalloc((void**)&c->h_pinned, 64 * sizeof(int32_t), hipHostMallocDefault));
   hipDeviceProp_t prop;
@@ -64,6 +65,7 @@ extern "C" int cm_ctx_destroy(cm_ctx* c) {
   if (!c) return CM_OK;
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
+  if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
   for (auto& e : c->ev) if (e) hipEventDestroy(e);
   for (auto& e : c->pool) hipEventDestroy(e);
   if (c->h_pinned) hipHostFree(c->h_pinned);
@@ -337,33 +339,50 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
   if (o->save_histories && iters > 0) CM_TRY(alloc_hist(p, iters)); else free_hist(p);
 
   const bool timed = tm != nullptr;
-  if (timed) {
-    while (ctx->pool.size() < (size_t)iters * 6) { hipEvent_t e; CM_HIP(hipEventCreate(&e)); ctx->pool.push_back(e); }
-  }
+  while (ctx->pool.size() < (size_t)(iters + 1) * CM_EV_PER_IT) { hipEvent_t e; CM_HIP(hipEventCreate(&e)); ctx->pool.push_back(e); }
+  // Two streams.  Main: solve -> sweep -> row/col stats -> sigma, z.  Side: update_phi(it) -> MC logit(it + 1); neither is
+  // needed by the next solve, so they overlap with it.  Per-iteration events: [0..5] phase stamps on the main stream,
+  // [6] lam(it) final (main -> side), [7] MC logit(it) ready (side -> main), [8] side-stream start stamp.
+  hipStream_t sb = ctx->side;
+  auto EV = [&](int it, int j) { return ctx->pool[(size_t)it * CM_EV_PER_IT + j]; };
   CM_HIP(hipEventRecord(ctx->ev[1], st));
+  if (iters > 0) {
+    CM_HIP(hipStreamWaitEvent(sb, ctx->ev[1], 0));                   // priors, keys and orders are in place
+    CM_TRY(cm_launch_mc_logit(ctx, p, 0, S, o->rng_mode, sb));       // :209-215 for iteration 0 (phi = prior)
+    CM_HIP(hipEventRecord(EV(0, 7), sb));
+  }
   int last_active = 0;
   long long sum_active = 0;
   for (int it = 0; it < iters; ++it) {                               // caviar.py:79
-    hipEvent_t* ev = timed ? &ctx->pool[(size_t)it * 6] : nullptr;
-    if (timed) CM_HIP(hipEventRecord(ev[0], st));
+    p->order = p->orders_all + (size_t)it * N;
+    if (timed) CM_HIP(hipEventRecord(EV(it, 0), st));
     CM_TRY(cm_solve_mu(ctx, p, &last_active));                       // :80  block_update_mu
     sum_active += last_active;
     if (ctx->h_pinned[1]) { cm_set_error("iteration %d: weight precision matrix not positive definite", it); return CM_ERR_NOT_SPD; }
-    if (timed) CM_HIP(hipEventRecord(ev[1], st));
-    p->order = p->orders_all + (size_t)it * N;
-    CM_TRY(cm_launch_mc_logit(ctx, p, it, S, o->rng_mode));          // :209-215
-    if (timed) CM_HIP(hipEventRecord(ev[2], st));
-    CM_TRY(cm_launch_sweep(ctx, p, it, o, timed ? ev[3] : nullptr)); // :81  update_lam
-    if (timed) CM_HIP(hipEventRecord(ev[4], st));
+    if (timed) CM_HIP(hipEventRecord(EV(it, 1), st));
+    CM_HIP(hipStreamWaitEvent(st, EV(it, 7), 0));                    // MC logit of this iteration (and phi(it - 1)) done
+    if (timed) CM_HIP(hipEventRecord(EV(it, 2), st));
+    CM_TRY(cm_launch_sweep(ctx, p, it, o, timed ? EV(it, 3) : nullptr)); // :81  update_lam
+    if (timed) CM_HIP(hipEventRecord(EV(it, 4), st));
     CM_TRY(cm_launch_row_stats(ctx, p));                             // row sums of the new lam (+ next active set)
-    CM_TRY(cm_launch_post(ctx, p, it, o));                           // :84-88 update_sigma, update_phi, z, spont_rate
-    if (o->save_histories) CM_TRY(record_hist(ctx, p, it));          // :90-92
-    if (timed) CM_HIP(hipEventRecord(ev[5], st));
+    CM_HIP(hipEventRecord(EV(it, 6), st));
+    CM_HIP(hipStreamWaitEvent(sb, EV(it, 6), 0));
+    if (timed) CM_HIP(hipEventRecord(EV(it, 8), sb));
+    CM_TRY(cm_launch_update_phi(ctx, p, sb));                        // :85  update_phi            (side stream)
+    if (it + 1 < iters) CM_TRY(cm_launch_mc_logit(ctx, p, it + 1, S, o->rng_mode, sb));   // next iteration's MC logit
+    CM_HIP(hipEventRecord(EV(it + 1, 7), sb));
+    CM_TRY(cm_launch_post(ctx, p, it, o));                           // :84,86-88 update_sigma, z, spont_rate (main stream)
+    if (o->save_histories) {                                         // :90-92
+      CM_HIP(hipStreamWaitEvent(st, EV(it + 1, 7), 0));
+      CM_TRY(record_hist(ctx, p, it));
+    }
+    if (timed) CM_HIP(hipEventRecord(EV(it, 5), st));
     if (o->verbose >= 2) {
       CM_HIP(hipStreamSynchronize(st));
       fprintf(stderr, "[caviar_hip] it %d active %d\n", it, last_active);
     }
   }
+  if (iters > 0) CM_HIP(hipStreamWaitEvent(st, EV(iters, 7), 0));   // last update_phi
   CM_HIP(hipEventRecord(ctx->ev[2], st));
 
   if (o->fn_scan) {                                                  // caviar.py:94-98
@@ -379,7 +398,7 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
     CM_HIP(hipMemcpyAsync(p->beta, beta.data(), (size_t)N * 8, hipMemcpyHostToDevice, st));
     if (nnz) CM_HIP(hipMemcpyAsync(p->lam, lam.data(), nnz * 8, hipMemcpyHostToDevice, st));
     CM_HIP(hipMemcpyAsync(p->z, z.data(), (size_t)K * 8, hipMemcpyHostToDevice, st));
-    CM_TRY(cm_launch_update_phi(ctx, p));
+    CM_TRY(cm_launch_update_phi(ctx, p, st));
     CM_HIP(hipStreamSynchronize(st));   // host vectors go out of scope
   }
   CM_HIP(hipEventRecord(ctx->ev[3], st));
@@ -397,10 +416,11 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
     tm->total_ms = a; tm->iters_ms = b; tm->fn_scan_ms = c; tm->iters = iters; tm->last_active = last_active;
     tm->sum_active = sum_active;
     for (int it = 0; it < iters; ++it) {
-      hipEvent_t* ev = &ctx->pool[(size_t)it * 6];
-      float d[5];
-      for (int j = 0; j < 5; ++j) hipEventElapsedTime(&d[j], ev[j], ev[j + 1]);
-      tm->solve_ms += d[0]; tm->mc_ms += d[1]; tm->sweep_indep_ms += d[2]; tm->sweep_seq_ms += d[3]; tm->post_ms += d[4];
+      float d[5], sd = 0;
+      for (int j = 0; j < 5; ++j) hipEventElapsedTime(&d[j], EV(it, j), EV(it, j + 1));
+      hipEventElapsedTime(&sd, EV(it, 8), EV(it + 1, 7));
+      tm->solve_ms += d[0]; tm->sweep_indep_ms += d[2]; tm->sweep_seq_ms += d[3]; tm->post_ms += d[4];
+      tm->mc_wait_ms += d[1]; tm->mc_ms += sd;
     }
   }
   p->ran = true;
@@ -539,7 +559,7 @@ extern "C" int cm_k_update_phi(cm_ctx* ctx, int32_t N, int32_t K, const double* 
   int rc = CM_OK;
   if (hipMemcpy(p->phi_prior, phi_prior, (size_t)N * 16, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(p->phi_cov_prior, phi_cov_prior, (size_t)N * 32, hipMemcpyHostToDevice) != hipSuccess) { cm_set_error("upload failed"); rc = CM_ERR_HIP; }
-  if (!rc) rc = cm_launch_update_phi(ctx, p);
+  if (!rc) rc = cm_launch_update_phi(ctx, p, st);
   if (!rc && (hipMemcpyAsync(phi, p->phi, (size_t)N * 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
               hipMemcpyAsync(phi_cov, p->phi_cov, (size_t)N * 32, hipMemcpyDeviceToHost, st) != hipSuccess ||
               hipStreamSynchronize(st) != hipSuccess)) { cm_set_error("download failed: %s", hipGetErrorString(hipGetLastError())); rc = CM_ERR_HIP; }

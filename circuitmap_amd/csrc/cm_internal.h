@@ -9,6 +9,7 @@
 
 #define CM_WAVE 64
 #define CM_TILE 32          // tile edge of the blocked SPD solve
+#define CM_EV_PER_IT 10
 
 void cm_set_error(const char* fmt, ...);
 
@@ -30,11 +31,12 @@ void cm_set_error(const char* fmt, ...);
 struct cm_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t side = nullptr;     // side stream: update_phi(it) -> MC logit(it + 1), overlapped with sigma/z and the next solve
   bool own_stream = false;
   hipEvent_t ev[8] = {};
   int32_t* h_pinned = nullptr;   // small pinned host mailbox (active-set size, flags)
   int num_cus = 256;
-  std::vector<hipEvent_t> pool;   // per-iteration phase events (6 per iteration)
+  std::vector<hipEvent_t> pool;   // per-iteration events (CM_EV_PER_IT per iteration): phase stamps + cross-stream edges
 };
 
 // One circuit: encoded stimulus + observations + CAVIaR state.  All pointers are device memory.
@@ -44,6 +46,7 @@ struct cm_problem {
   int64_t nnz = 0;       // number of targeted (stim > 0) entries
   int32_t V = 0;         // number of distinct stimulus values (sorted ascending; powers = vals[1:])
   int32_t ld = 0;        // leading dimension of the solve matrices (multiple of CM_TILE), sized for N
+  int32_t max_row_len = 0; // longest CSR row (targeted trials of one neuron)
   // --- static encoding (built once by cm_problem_create) ---
   double* y = nullptr;        // [K]  trapz(psc)
   double* ss = nullptr;       // [K]  sum psc^2
@@ -211,10 +214,10 @@ int cm_launch_expand_lam(cm_ctx* ctx, cm_problem* p, const double* d_lam_sparse,
 
 int cm_solve_mu(cm_ctx* ctx, cm_problem* p, int* n_active_out);                      // syncs once (active-set size)
 int cm_launch_rng(cm_ctx* ctx, cm_problem* p, int it0, int n_it);
-int cm_launch_mc_logit(cm_ctx* ctx, cm_problem* p, int it, int S, int rng_mode);
+int cm_launch_mc_logit(cm_ctx* ctx, cm_problem* p, int it, int S, int rng_mode, hipStream_t st);
 int cm_launch_sweep(cm_ctx* ctx, cm_problem* p, int it, const cm_options* o, hipEvent_t mid);
 int cm_launch_post(cm_ctx* ctx, cm_problem* p, int it, const cm_options* o);
-int cm_launch_update_phi(cm_ctx* ctx, cm_problem* p);
+int cm_launch_update_phi(cm_ctx* ctx, cm_problem* p, hipStream_t st);
 int cm_launch_col_stats(cm_ctx* ctx, cm_problem* p, double spont_orthogonality);
 
 void cm_host_key_schedule(uint64_t seed, int iters, int N, std::vector<uint32_t>& keys);

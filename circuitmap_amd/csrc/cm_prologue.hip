@@ -1,5 +1,7 @@
 // One-off prologue kernels: PSC integrals and the compressed encoding of the stimulus matrix.
 // Replaces reference circuitmap/optimise/caviar.py:28-51 (prologue of caviar()).
+#include <algorithm>
+
 #include "cm_internal.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -255,6 +257,8 @@ int cm_encode_stim(cm_ctx* ctx, cm_problem* p, const double* d_stim) {
   }
   p->V = h_flags[1];
   p->nnz = p->h_row_ptr[N];
+  p->max_row_len = 0;
+  for (int n = 0; n < N; ++n) p->max_row_len = std::max(p->max_row_len, p->h_row_ptr[n + 1] - p->h_row_ptr[n]);
   const size_t nnz_alloc = p->nnz > 0 ? (size_t)p->nnz : 1;
   CM_HIP(hipMalloc(&p->col, nnz_alloc * sizeof(int)));
   CM_HIP(hipMalloc(&p->grp, nnz_alloc));

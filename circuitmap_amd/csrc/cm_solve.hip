@@ -145,58 +145,43 @@ __device__ __forceinline__ void tile_mma_nn(double c[2][2], const double (*A)[TP
   }
 }
 
-// Cholesky of a 32x32 SPD tile + inverse of its factor, by ONE wavefront entirely in registers: lane r owns row r of
-// the tile (32 doubles), the pivot column is broadcast with v_readlane, so the 32 dependent column steps need no
-// barrier and no LDS round trip.  L^-1 is then built row by row, lane c owning column c.  C holds the SPD tile on
-// entry and L on exit (upper part zeroed); Li receives L^-1.  Called by all 256 threads (waves 1..3 only wait).
-__device__ __forceinline__ void tile_potrf_inv(double (*C)[TP], double (*Li)[TP], int* __restrict__ flag) {
-  __syncthreads();
-  if (threadIdx.x < CM_WAVE) {
-    const int lane = threadIdx.x;
-    const int row = lane & (TS - 1);
-    double a[TS], x[TS];
-#pragma unroll
-    for (int j = 0; j < TS; ++j) { a[j] = C[row][j]; x[j] = 0.0; }
-    bool bad = false;
-#pragma unroll
-    for (int c = 0; c < TS; ++c) {
-      const double d = cm_readlane_f64(a[c], c);
-      bad |= !(d > 0.0);                           // not SPD (also catches NaN)
-      const double s = sqrt(d);
-      const double rs = 1.0 / s;
-      a[c] = (lane == c) ? s : a[c] * rs;
-#pragma unroll
-      for (int cc = c + 1; cc < TS; ++cc) {
-        const double l = cm_readlane_f64(a[c], cc);
-        a[cc] = fma(-a[c], l, a[cc]);
-      }
+// L^-1 of a 32x32 SPD tile (C = L L^T) by forward elimination of the augmented matrix [C | I] in LDS, all 256 threads,
+// ONE barrier per pivot: after the sweep the right half holds Ltilde^-1 (unit lower, C = Ltilde D Ltilde^T) and
+// L^-1 = D^-1/2 Ltilde^-1.  Only L^-1 is needed downstream (panel solve and inverse seed), so L itself is not formed.
+// C is destroyed; Rt is scratch; Li receives L^-1 (lower triangular).
+__device__ __forceinline__ void tile_linv(double (*C)[TP], double (*Rt)[TP], double (*Li)[TP], int* __restrict__ flag) {
+  __shared__ double dk[TS];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < TS * TS; i += 256) Rt[i / TS][i % TS] = (i / TS == i % TS) ? 1.0 : 0.0;
+  bool bad = false;
+  for (int k = 0; k < TS; ++k) {
+    __syncthreads();
+    const double d = C[k][k];
+    bad |= !(d > 0.0);                             // not SPD (also catches NaN)
+    const double rd = 1.0 / d;
+    if (tid == 0) dk[k] = d;
+    const int rem = TS - 1 - k;                    // rows below the pivot
+    for (int idx = tid; idx < rem * TS; idx += 256) {
+      const int i = k + 1 + idx / TS, q = idx % TS;
+      const double m = C[i][k] * rd;
+      if (q < rem) { const int j = k + 1 + q; C[i][j] = fma(-m, C[k][j], C[i][j]); }
+      else { const int c = q - rem; Rt[i][c] = fma(-m, Rt[k][c], Rt[i][c]); }
     }
-#pragma unroll
-    for (int r = 0; r < TS; ++r) {                 // row r of L^-1: X[r][c] = -(sum_{j<r} L[r][j] X[j][c]) / L[r][r]
-      const double inv = 1.0 / cm_readlane_f64(a[r], r);
-      double sacc = 0.0;
-#pragma unroll
-      for (int j = 0; j < r; ++j) sacc = fma(cm_readlane_f64(a[j], r), x[j], sacc);
-      x[r] = (lane == r) ? inv : (lane < r ? -sacc * inv : 0.0);
-    }
-    if (lane < TS) {
-#pragma unroll
-      for (int j = 0; j < TS; ++j) {
-        C[lane][j] = (j <= lane) ? a[j] : 0.0;
-        Li[j][lane] = x[j];
-      }
-    }
-    if (bad && lane == 0) *flag = 1;
   }
+  __syncthreads();
+  for (int i = tid; i < TS * TS; i += 256) {
+    const int r = i / TS, c = i % TS;
+    Li[r][c] = (c <= r) ? Rt[r][c] / sqrt(dk[r]) : 0.0;
+  }
+  if (bad && tid == 0) *flag = 1;
   __syncthreads();
 }
 
 // factor the first diagonal tile
 __global__ __launch_bounds__(256) void k_chol_first(double* __restrict__ A, int ld, double* __restrict__ Dinv, int* __restrict__ flag) {
-  __shared__ double C[TS][TP], Li[TS][TP];
+  __shared__ double C[TS][TP], Rt[TS][TP], Li[TS][TP];
   tile_load(C, A, ld);
-  tile_potrf_inv(C, Li, flag);
-  tile_store(A, ld, C);
+  tile_linv(C, Rt, Li, flag);
   tile_store(Dinv, TS, Li);
 }
 
@@ -221,7 +206,7 @@ __global__ __launch_bounds__(256) void k_chol_trsm(double* __restrict__ A, int l
 // diagonal tile (j+1, j+1) factors it on the spot, so each panel costs two launches.
 __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int ld, double* __restrict__ Dinv, int j, int nblk,
                                                       int* __restrict__ flag) {
-  __shared__ double Pi[TS][TP], Pl[TS][TP];
+  __shared__ double Pi[TS][TP], Pl[TS][TP], Rt[TS][TP];
   // linear block id -> (i, l) with 0 <= l' <= i' in the trailing (nblk - j - 1) tile rows
   const int t = blockIdx.x;
   int ip = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
@@ -242,9 +227,7 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int
     Pi[r0][c0 + 1] = out[(size_t)r0 * ld + c0 + 1] - c[0][1];
     Pi[r0 + 1][c0] = out[(size_t)(r0 + 1) * ld + c0] - c[1][0];
     Pi[r0 + 1][c0 + 1] = out[(size_t)(r0 + 1) * ld + c0 + 1] - c[1][1];
-    __syncthreads();
-    tile_potrf_inv(Pi, Pl, flag);
-    tile_store(out, ld, Pi);
+    tile_linv(Pi, Rt, Pl, flag);
     tile_store(Dinv + (size_t)(j + 1) * TS * TS, TS, Pl);
   } else {
     out[(size_t)r0 * ld + c0] -= c[0][0];
@@ -362,6 +345,109 @@ __global__ __launch_bounds__(256) void k_fill_prior(const double* __restrict__ m
   if (n < N) { mu[n] = mu_prior[n]; beta[n] = beta_prior[n] * beta_prior[n]; }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Small active sets (the steady state of a fit): the whole block_update_mu in ONE workgroup, everything in LDS.
+//   1. stage the active rows' (trial, lam) lists;  2. A_ab = sigma * sum_k lam_ak lam_bk by merge-intersection of the two
+//   sorted trial lists (ascending trial order -> deterministic);  3. A^-1 in place by the sweep operator (n pivots, two
+//   barriers each; pivots of an SPD matrix are positive, no pivoting needed);  4. mu = A^-1 rhs, beta = diag(A^-1).
+// ------------------------------------------------------------------------------------------------
+#define CM_SMALL_MAX 128
+__global__ __launch_bounds__(1024) void k_solve_small(const double* __restrict__ lam, const int* __restrict__ row_ptr,
+                                                       const int* __restrict__ col, const int* __restrict__ act_idx,
+                                                       const double* __restrict__ rs, const double* __restrict__ scal,
+                                                       const double* __restrict__ mu_prior, const double* __restrict__ beta_prior,
+                                                       int n, int N, int tot_cap, double* __restrict__ mu, double* __restrict__ beta,
+                                                       int* __restrict__ flag) {
+  extern __shared__ double sm[];
+  const int ldA = n + 1;
+  double* A = sm;                              // [n][n+1]
+  double* rowk = A + (size_t)n * ldA;          // [CM_SMALL_MAX]
+  double* colk = rowk + CM_SMALL_MAX;
+  double* rhs = colk + CM_SMALL_MAX;
+  double* lams = rhs + CM_SMALL_MAX;           // [tot_cap]
+  int* cols = (int*)(lams + tot_cap);          // [tot_cap]
+  int* rp = cols + tot_cap;                    // [CM_SMALL_MAX + 1]
+  int* nidx = rp + CM_SMALL_MAX + 1;           // [CM_SMALL_MAX]
+  __shared__ int bad;
+  const int tid = threadIdx.x;
+  // inactive rows: mu = mu0, beta = beta0^2 exactly (their rows of the precision matrix are diagonal)
+  for (int i = tid; i < N; i += blockDim.x) { mu[i] = mu_prior[i]; const double b0 = beta_prior[i]; beta[i] = b0 * b0; }
+  if (tid == 0) bad = 0;
+  // ---- 1. stage
+  if (tid < n) { const int nn = act_idx[tid]; nidx[tid] = nn; rp[tid + 1] = row_ptr[nn + 1] - row_ptr[nn]; }
+  if (tid == 0) rp[0] = 0;
+  __syncthreads();
+  for (int o = 1; o < n; o <<= 1) {            // inclusive scan of the row lengths
+    int v = 0;
+    if (tid < n && tid >= o) v = rp[tid + 1 - o];
+    __syncthreads();
+    if (tid < n && tid >= o) rp[tid + 1] += v;
+    __syncthreads();
+  }
+  const int wave = tid / CM_WAVE, lane = tid % CM_WAVE, nw = blockDim.x / CM_WAVE;
+  for (int a = wave; a < n; a += nw) {
+    const int g0 = row_ptr[nidx[a]], len = rp[a + 1] - rp[a], o0 = rp[a];
+    for (int e = lane; e < len; e += CM_WAVE) { cols[o0 + e] = col[g0 + e]; lams[o0 + e] = lam[g0 + e]; }
+  }
+  __syncthreads();
+  // ---- 2. build (lower triangle pairs, mirrored)
+  const double sig = scal[CM_S_SHAPE] / scal[CM_S_RATE];
+  const int npairs = n * (n + 1) / 2;
+  for (int q = tid; q < npairs; q += blockDim.x) {
+    int a = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
+    while ((a + 1) * (a + 2) / 2 <= q) ++a;
+    while (a * (a + 1) / 2 > q) --a;
+    const int b = q - a * (a + 1) / 2;
+    int ia = rp[a], ib = rp[b];
+    const int ea = rp[a + 1], eb = rp[b + 1];
+    double acc = 0.0;
+    while (ia < ea && ib < eb) {
+      const int ka = cols[ia], kb = cols[ib];
+      if (ka == kb) { acc = fma(lams[ia], lams[ib], acc); ++ia; ++ib; }
+      else if (ka < kb) ++ia; else ++ib;
+    }
+    double v = sig * acc;
+    if (a == b) {
+      const int nn = nidx[a];
+      const double b0 = beta_prior[nn], prec0 = 1.0 / (b0 * b0);
+      v = sig * (rs[(size_t)nn * 4 + 3] + acc) + prec0;
+      rhs[a] = sig * rs[(size_t)nn * 4 + 2] + prec0 * mu_prior[nn];
+    }
+    A[a * ldA + b] = v;
+    A[b * ldA + a] = v;
+  }
+  // ---- 3. sweep-operator inverse
+  for (int k = 0; k < n; ++k) {
+    __syncthreads();
+    const double d = A[k * ldA + k];
+    const double inv = 1.0 / d;
+    if (tid == 0 && !(d > 0.0)) bad = 1;
+    if (tid < n) { rowk[tid] = A[k * ldA + tid] * inv; colk[tid] = A[tid * ldA + k]; }
+    __syncthreads();
+    for (int idx = tid; idx < n * n; idx += blockDim.x) {
+      const int i = idx / n, j = idx % n;
+      double v;
+      if (i == k) v = (j == k) ? inv : rowk[j];
+      else if (j == k) v = -colk[i] * inv;
+      else v = fma(-colk[i], rowk[j], A[i * ldA + j]);
+      A[i * ldA + j] = v;
+    }
+  }
+  __syncthreads();
+  // ---- 4. mu = A^-1 rhs (one wave per row), beta = diag(A^-1)
+  for (int a = wave; a < n; a += nw) {
+    double sacc = 0.0;
+    for (int b = lane; b < n; b += CM_WAVE) sacc = fma(A[a * ldA + b], rhs[b], sacc);
+    sacc = cm_wave_sum(sacc);
+    if (lane == 0) { mu[nidx[a]] = sacc; beta[nidx[a]] = A[a * ldA + a]; }
+  }
+  if (tid == 0 && bad) *flag = 1;
+}
+
+static size_t small_lds_bytes(int n, int tot_cap) {
+  return ((size_t)n * (n + 1) + 3 * CM_SMALL_MAX + tot_cap) * sizeof(double) + ((size_t)tot_cap + 2 * CM_SMALL_MAX + 1) * sizeof(int);
+}
+
 int cm_launch_row_stats(cm_ctx* ctx, cm_problem* p) {
   hipLaunchKernelGGL(k_row_stats, dim3((p->N + 3) / 4), dim3(256), 0, ctx->stream, p->lam, p->row_ptr, p->col, p->y, p->N, p->rs);
   hipLaunchKernelGGL(k_active_compact, dim3(1), dim3(1024), 0, ctx->stream, p->rs, p->N, p->act_idx, p->act_inv, p->n_act);
@@ -377,6 +463,18 @@ int cm_solve_mu(cm_ctx* ctx, cm_problem* p, int* n_active_out) {
   CM_HIP(hipEventSynchronize(ctx->ev[7]));          // the only host wait of an iteration: size of the active set
   const int na = ctx->h_pinned[0];
   if (n_active_out) *n_active_out = na;
+  if (na > 0 && na <= CM_SMALL_MAX) {
+    const int tot_cap = na * p->max_row_len;
+    const size_t lds = small_lds_bytes(na, tot_cap);
+    if (lds <= 150 * 1024) {
+      if (lds > 48 * 1024)
+        CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_small), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_solve_small, dim3(1), dim3(1024), lds, st, p->lam, p->row_ptr, p->col, p->act_idx, p->rs, p->scal, p->mu_prior,
+                         p->beta_prior, na, p->N, tot_cap, p->mu, p->beta, p->n_act + 1);
+      CM_HIP(hipGetLastError());
+      return CM_OK;
+    }
+  }
   hipLaunchKernelGGL(k_fill_prior, dim3((p->N + 255) / 256), dim3(256), 0, st, p->mu_prior, p->beta_prior, p->N, p->mu, p->beta);
   if (na == 0) { CM_HIP(hipGetLastError()); return CM_OK; }
   const int nblk = (na + TS - 1) / TS;

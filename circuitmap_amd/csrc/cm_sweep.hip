@@ -521,11 +521,12 @@ int cm_launch_rng(cm_ctx* ctx, cm_problem* p, int it0, int n_it) {
   return CM_OK;
 }
 
-int cm_launch_mc_logit(cm_ctx* ctx, cm_problem* p, int it, int S, int rng_mode) {
+int cm_launch_mc_logit(cm_ctx* ctx, cm_problem* p, int it, int S, int rng_mode, hipStream_t st) {
   const int N = p->N;
   const uint32_t* keys = (rng_mode == CM_RNG_EXPLICIT) ? nullptr : p->keys + (size_t)it * (N + 3) * 2;
   const double* uexp = (rng_mode == CM_RNG_EXPLICIT) ? p->uexp + (size_t)it * N * 2 * S : nullptr;
-  hipLaunchKernelGGL(k_mc_logit, dim3(N), dim3(64), (size_t)2 * S * sizeof(double), ctx->stream, keys, uexp, p->order, p->phi,
+  const int* order = p->orders_all + (size_t)it * N;
+  hipLaunchKernelGGL(k_mc_logit, dim3(N), dim3(64), (size_t)2 * S * sizeof(double), st, keys, uexp, order, p->phi,
                      p->phi_cov, p->vals, p->V, S, N, p->mcE, (double*)nullptr);
   CM_HIP(hipGetLastError());
   return CM_OK;

@@ -107,10 +107,11 @@ typedef struct cm_timings {
   double iters_ms;       /* the `iters` CAVIaR iterations only                                */
   double fn_scan_ms;     /* reconnect_spont_cells (host) + final update_phi                   */
   double solve_ms;       /* sum over iterations: block_update_mu (build + Cholesky + inverse) */
-  double mc_ms;          /* sum: permutation + Monte-Carlo logit kernels                      */
+  double mc_ms;          /* sum: update_phi(it) + Monte-Carlo logit(it+1) on the side stream (overlapped) */
+  double mc_wait_ms;     /* sum: main stream waiting for the side stream before the sweep     */
   double sweep_indep_ms; /* sum: k_sweep_indep launches                                       */
   double sweep_seq_ms;   /* sum: k_sweep_seq launches (the sequential Gauss-Seidel chain)     */
-  double post_ms;        /* sum: row/col stats, update_sigma, soft-threshold, update_phi      */
+  double post_ms;        /* sum: row/col stats, update_sigma, soft-threshold (main stream)    */
   int32_t iters;
   int32_t last_active;   /* size of the active (lam row != 0) set in the last iteration       */
   int64_t sum_active;    /* sum over iterations of the active-set size                        */
