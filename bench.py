@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--phases", action="store_true", help="stamp every phase of every iteration (more host API calls)")
     a = ap.parse_args()
 
     import numpy as np
@@ -113,6 +114,8 @@ def main():
     nnz, nvals = prob.nnz
     run_args = (pri["mu"], pri["beta"], pri["shape"], pri["rate"], pri["phi"], pri["phi_cov"])
     opts = dict(iters=a.iters, seed=0)
+    if a.phases:
+        opts["verbose"] = 1
 
     def barrier():
         if dist is not None:

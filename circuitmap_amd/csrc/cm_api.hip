@@ -3,13 +3,13 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
 
 #include "cm_internal.h"
 
-int cm_launch_row_stats(cm_ctx* ctx, cm_problem* p);
 int cm_k_rng_streams_impl(cm_ctx* ctx, cm_problem* p, int it, int S, double* d_u);
 
 static thread_local char g_err[512] = "";
@@ -53,7 +53,10 @@ extern "C" int cm_ctx_create(int device_id, void* hip_stream, cm_ctx** out) {
   else { CM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
   CM_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
   for (auto& e : c->ev) CM_HIP(hipEventCreate(&e));
-  CM_HIP(hipHostMalloc((void**)&c->h_pinned, 64 * sizeof(int32_t), hipHostMallocDefault));
+  CM_HIP(hipHostMalloc((void**)&c->h_pinned, 64 * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent));
+  memset(c->h_pinned, 0, 64 * sizeof(int32_t));
+  CM_HIP(hipHostGetDevicePointer((void**)&c->d_mailbox, c->h_pinned, 0));
+  c->use_mailbox = getenv("CAVIAR_HIP_NO_MAILBOX") == nullptr;
   hipDeviceProp_t prop;
   CM_HIP(hipGetDeviceProperties(&prop, device_id));
   c->num_cus = prop.multiProcessorCount;
@@ -323,7 +326,8 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
   CM_TRY(upload_priors(ctx, p, pr));
   CM_TRY(cm_launch_init_state(ctx, p, o->y_xcorr_thresh));
   CM_HIP(hipMemsetAsync(p->n_act, 0, 4 * sizeof(int), st));
-  CM_TRY(cm_launch_row_stats(ctx, p));          // active set of lam0 for the first solve
+  CM_TRY(cm_launch_stats(ctx, p, o->spont_orthogonality));   // row sums + active set of lam0 for the first solve
+  CM_TRY(cm_launch_post_single(ctx, p, -1, o, 0));
   std::vector<uint32_t> keys;
   if (o->rng_mode == CM_RNG_THREEFRY && iters > 0) {
     cm_host_key_schedule(o->seed, iters, N, keys);      // overlaps with the init kernels above
@@ -338,7 +342,8 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
   }
   if (o->save_histories && iters > 0) CM_TRY(alloc_hist(p, iters)); else free_hist(p);
 
-  const bool timed = tm != nullptr;
+  const bool timed = tm != nullptr;              // stamps around k_sweep_seq (events 3, 4)
+  const bool phases = timed && o->verbose >= 1;  // all phase stamps (adds ~6 host API calls per iteration)
   while (ctx->pool.size() < (size_t)(iters + 1) * CM_EV_PER_IT) { hipEvent_t e; CM_HIP(hipEventCreate(&e)); ctx->pool.push_back(e); }
   // Two streams.  Main: solve -> sweep -> row/col stats -> sigma, z.  Side: update_phi(it) -> MC logit(it + 1); neither is
   // needed by the next solve, so they overlap with it.  Per-iteration events: [0..5] phase stamps on the main stream,
@@ -355,28 +360,28 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
   long long sum_active = 0;
   for (int it = 0; it < iters; ++it) {                               // caviar.py:79
     p->order = p->orders_all + (size_t)it * N;
-    if (timed) CM_HIP(hipEventRecord(EV(it, 0), st));
+    if (phases) CM_HIP(hipEventRecord(EV(it, 0), st));
     CM_TRY(cm_solve_mu(ctx, p, &last_active));                       // :80  block_update_mu
     sum_active += last_active;
     if (ctx->h_pinned[1]) { cm_set_error("iteration %d: weight precision matrix not positive definite", it); return CM_ERR_NOT_SPD; }
-    if (timed) CM_HIP(hipEventRecord(EV(it, 1), st));
+    if (phases) CM_HIP(hipEventRecord(EV(it, 1), st));
     CM_HIP(hipStreamWaitEvent(st, EV(it, 7), 0));                    // MC logit of this iteration (and phi(it - 1)) done
-    if (timed) CM_HIP(hipEventRecord(EV(it, 2), st));
+    if (phases) CM_HIP(hipEventRecord(EV(it, 2), st));
     CM_TRY(cm_launch_sweep(ctx, p, it, o, timed ? EV(it, 3) : nullptr)); // :81  update_lam
     if (timed) CM_HIP(hipEventRecord(EV(it, 4), st));
-    CM_TRY(cm_launch_row_stats(ctx, p));                             // row sums of the new lam (+ next active set)
+    CM_TRY(cm_launch_stats(ctx, p, o->spont_orthogonality));         // row + column statistics of the new lam
     CM_HIP(hipEventRecord(EV(it, 6), st));
     CM_HIP(hipStreamWaitEvent(sb, EV(it, 6), 0));
-    if (timed) CM_HIP(hipEventRecord(EV(it, 8), sb));
+    if (phases) CM_HIP(hipEventRecord(EV(it, 8), sb));
     CM_TRY(cm_launch_update_phi(ctx, p, sb));                        // :85  update_phi            (side stream)
     if (it + 1 < iters) CM_TRY(cm_launch_mc_logit(ctx, p, it + 1, S, o->rng_mode, sb));   // next iteration's MC logit
     CM_HIP(hipEventRecord(EV(it + 1, 7), sb));
-    CM_TRY(cm_launch_post(ctx, p, it, o));                           // :84,86-88 update_sigma, z, spont_rate (main stream)
+    CM_TRY(cm_launch_post_single(ctx, p, it, o, 1));                 // next active set (posted to the host), :84,86-88 sigma, z, spont_rate
     if (o->save_histories) {                                         // :90-92
       CM_HIP(hipStreamWaitEvent(st, EV(it + 1, 7), 0));
       CM_TRY(record_hist(ctx, p, it));
     }
-    if (timed) CM_HIP(hipEventRecord(EV(it, 5), st));
+    if (phases) CM_HIP(hipEventRecord(EV(it, 5), st));
     if (o->verbose >= 2) {
       CM_HIP(hipStreamSynchronize(st));
       fprintf(stderr, "[caviar_hip] it %d active %d\n", it, last_active);
@@ -404,8 +409,8 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
   CM_HIP(hipEventRecord(ctx->ev[3], st));
   CM_HIP(hipStreamSynchronize(st));
   if (iters > 0) {
-    CM_HIP(hipMemcpy(ctx->h_pinned, p->n_act, 4 * sizeof(int), hipMemcpyDeviceToHost));
-    if (ctx->h_pinned[1]) { cm_set_error("weight precision matrix not positive definite"); return CM_ERR_NOT_SPD; }
+    CM_HIP(hipMemcpy(ctx->h_pinned + 8, p->n_act, 4 * sizeof(int), hipMemcpyDeviceToHost));   // [8..11]: outside the mailbox words
+    if (ctx->h_pinned[9]) { cm_set_error("weight precision matrix not positive definite"); return CM_ERR_NOT_SPD; }
   }
   if (tm) {
     float a = 0, b = 0, c = 0;
@@ -416,10 +421,13 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
     tm->total_ms = a; tm->iters_ms = b; tm->fn_scan_ms = c; tm->iters = iters; tm->last_active = last_active;
     tm->sum_active = sum_active;
     for (int it = 0; it < iters; ++it) {
-      float d[5], sd = 0;
-      for (int j = 0; j < 5; ++j) hipEventElapsedTime(&d[j], EV(it, j), EV(it, j + 1));
+      float d[5] = {0, 0, 0, 0, 0}, sd = 0;
+      hipEventElapsedTime(&d[3], EV(it, 3), EV(it, 4));
+      tm->sweep_seq_ms += d[3];
+      if (!phases) continue;
+      for (int j = 0; j < 5; ++j) if (j != 3) hipEventElapsedTime(&d[j], EV(it, j), EV(it, j + 1));
       hipEventElapsedTime(&sd, EV(it, 8), EV(it + 1, 7));
-      tm->solve_ms += d[0]; tm->sweep_indep_ms += d[2]; tm->sweep_seq_ms += d[3]; tm->post_ms += d[4];
+      tm->solve_ms += d[0]; tm->sweep_indep_ms += d[2]; tm->post_ms += d[4];
       tm->mc_wait_ms += d[1]; tm->mc_ms += sd;
     }
   }
@@ -539,13 +547,14 @@ extern "C" int cm_k_block_update_mu(cm_ctx* ctx, int32_t N, int32_t K, const dou
       hipMemcpy(p->beta_prior, beta_prior, (size_t)N * 8, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemset(p->n_act, 0, 4 * sizeof(int)) != hipSuccess) { cm_set_error("upload failed"); rc = CM_ERR_HIP; }
   int na = 0;
-  if (!rc) rc = cm_launch_row_stats(ctx, p);
+  if (!rc) rc = cm_launch_stats(ctx, p, 0.1);
+  if (!rc) rc = cm_launch_post_single(ctx, p, -1, nullptr, 0);
   if (!rc) rc = cm_solve_mu(ctx, p, &na);
   if (!rc && (hipMemcpyAsync(mu, p->mu, (size_t)N * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
               hipMemcpyAsync(beta, p->beta, (size_t)N * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
-              hipMemcpyAsync(ctx->h_pinned, p->n_act, 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
+              hipMemcpyAsync(ctx->h_pinned + 8, p->n_act, 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
               hipStreamSynchronize(st) != hipSuccess)) { cm_set_error("download failed: %s", hipGetErrorString(hipGetLastError())); rc = CM_ERR_HIP; }
-  if (!rc && ctx->h_pinned[1]) { cm_set_error("precision matrix not positive definite"); rc = CM_ERR_NOT_SPD; }
+  if (!rc && ctx->h_pinned[9]) { cm_set_error("precision matrix not positive definite"); rc = CM_ERR_NOT_SPD; }
   cm_problem_destroy(p);
   return rc;
 }

@@ -34,7 +34,10 @@ struct cm_ctx {
   hipStream_t side = nullptr;     // side stream: update_phi(it) -> MC logit(it + 1), overlapped with sigma/z and the next solve
   bool own_stream = false;
   hipEvent_t ev[8] = {};
-  int32_t* h_pinned = nullptr;   // small pinned host mailbox (active-set size, flags)
+  int32_t* h_pinned = nullptr;   // host-mapped pinned mailbox: [0] active-set size, [1] SPD flag, [2] sequence number
+  int32_t* d_mailbox = nullptr;  // device address of h_pinned
+  int mail_seq = 0;
+  bool use_mailbox = true;
   int num_cus = 256;
   std::vector<hipEvent_t> pool;   // per-iteration events (CM_EV_PER_IT per iteration): phase stamps + cross-stream edges
 };
@@ -216,7 +219,9 @@ int cm_solve_mu(cm_ctx* ctx, cm_problem* p, int* n_active_out);                 
 int cm_launch_rng(cm_ctx* ctx, cm_problem* p, int it0, int n_it);
 int cm_launch_mc_logit(cm_ctx* ctx, cm_problem* p, int it, int S, int rng_mode, hipStream_t st);
 int cm_launch_sweep(cm_ctx* ctx, cm_problem* p, int it, const cm_options* o, hipEvent_t mid);
-int cm_launch_post(cm_ctx* ctx, cm_problem* p, int it, const cm_options* o);
+int cm_launch_stats(cm_ctx* ctx, cm_problem* p, double spont_orthogonality);
+int cm_launch_post_single(cm_ctx* ctx, cm_problem* p, int it, const cm_options* o, int do_sigma);
+int cm_wait_active(cm_ctx* ctx, cm_problem* p);
 int cm_launch_update_phi(cm_ctx* ctx, cm_problem* p, hipStream_t st);
 int cm_launch_col_stats(cm_ctx* ctx, cm_problem* p, double spont_orthogonality);
 

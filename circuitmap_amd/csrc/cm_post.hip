@@ -5,31 +5,50 @@
 #include "cm_internal.h"
 
 // ------------------------------------------------------------------------------------------------
-// column statistics of the new lam: R_k = sum_n mu_n lam_nk (= lam.T @ mu), colany_k = any_n lam_nk >= spont_orthogonality
-// one thread per trial, entries in ascending neuron order (deterministic)
+// Statistics of the new lam, one launch, two roles (256-thread blocks):
+//   blocks [0, nbR): one wave per row  -> rs[n] = {sum lam, sum lam^2, sum y*lam, sum lam(1-lam) or -1 if the row is all zero}
+//   blocks [nbR, ..): one thread per trial -> R_k = sum_n mu_n lam_nk (= lam.T @ mu, ascending neuron order),
+//                     colany_k = any_n lam_nk >= spont_orthogonality
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_col_stats(const double* __restrict__ lam, const double* __restrict__ mu,
-                                                    const int* __restrict__ col_ptr, const int* __restrict__ csc_row,
-                                                    const int* __restrict__ csc_pos, int K, double orth,
-                                                    double* __restrict__ R, uint8_t* __restrict__ colany) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= K) return;
-  double s = 0.0;
-  int any = 0;
-  for (int ce = col_ptr[k]; ce < col_ptr[k + 1]; ++ce) {
-    const double l = lam[csc_pos[ce]];
-    s = fma(mu[csc_row[ce]], l, s);
-    any |= (l >= orth);
+__global__ __launch_bounds__(256) void k_stats(const double* __restrict__ lam, const int* __restrict__ row_ptr, const int* __restrict__ col,
+                                                const double* __restrict__ y, const double* __restrict__ mu, const int* __restrict__ col_ptr,
+                                                const int* __restrict__ csc_row, const int* __restrict__ csc_pos, int N, int K, int nbR,
+                                                double orth, double* __restrict__ rs, double* __restrict__ R, uint8_t* __restrict__ colany) {
+  if ((int)blockIdx.x < nbR) {
+    const int n = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE;
+    const int lane = threadIdx.x % CM_WAVE;
+    if (n >= N) return;
+    double s1 = 0.0, s2 = 0.0, sy = 0.0, d = 0.0;
+    int any = 0;
+    for (int e = row_ptr[n] + lane; e < row_ptr[n + 1]; e += CM_WAVE) {
+      const double l = lam[e];
+      s1 += l;
+      s2 = fma(l, l, s2);
+      sy = fma(y[col[e]], l, sy);
+      d = fma(l, 1.0 - l, d);
+      any |= (l != 0.0);
+    }
+    s1 = cm_wave_sum(s1); s2 = cm_wave_sum(s2); sy = cm_wave_sum(sy); d = cm_wave_sum(d);
+    any = __any(any);
+    if (lane == 0) {
+      rs[(size_t)n * 4 + 0] = s1;
+      rs[(size_t)n * 4 + 1] = s2;
+      rs[(size_t)n * 4 + 2] = sy;
+      rs[(size_t)n * 4 + 3] = any ? d : -1.0;   // sum lam(1-lam) for active rows, -1 marks an all-zero row
+    }
+  } else {
+    const int k = ((int)blockIdx.x - nbR) * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    double s = 0.0;
+    int any = 0;
+    for (int ce = col_ptr[k]; ce < col_ptr[k + 1]; ++ce) {
+      const double l = lam[csc_pos[ce]];
+      s = fma(mu[csc_row[ce]], l, s);
+      any |= (l >= orth);
+    }
+    R[k] = s;
+    colany[k] = (uint8_t)any;
   }
-  R[k] = s;
-  colany[k] = (uint8_t)any;
-}
-
-int cm_launch_col_stats(cm_ctx* ctx, cm_problem* p, double spont_orthogonality) {
-  hipLaunchKernelGGL(k_col_stats, dim3((p->K + 255) / 256), dim3(256), 0, ctx->stream, p->lam, p->mu, p->col_ptr, p->csc_row,
-                     p->csc_pos, p->K, spont_orthogonality, p->R, p->colany);
-  CM_HIP(hipGetLastError());
-  return CM_OK;
 }
 
 // block-wide sum (1024 threads), result valid in every thread
@@ -44,19 +63,62 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// update_sigma + soft-threshold + spont_rate in one single-workgroup kernel (all O(K + N) reductions)
-//   rate = rate0 + 1/2 ( sum_k (y_k - R_k)^2 - sum_n mu_n^2 sum_k lam_nk^2 + sum_n (mu_n^2 + beta_n^2) sum_k lam_nk )
-//   z: <= (max_iters - it) penalty steps pen_j = penalty * scale^j while err > tol (loop counter seeded with the OUTER
-//      iteration index and err with sum(y), caviar.py:86; quirk 4: nothing happens once it >= max_iters)
+// Everything of an iteration that is a single-workgroup reduction, in one kernel (1024 threads):
+//   1. ordered compaction of the active rows (lam row != 0) for the next block_update_mu, and the size of that set
+//      posted straight into host-mapped pinned memory (mailbox) so the host can size the next solve while 2-3 still run;
+//   2. update_sigma: rate = rate0 + 1/2 ( sum_k (y_k - R_k)^2 - sum_n mu_n^2 sum_k lam_nk^2 + sum_n (mu_n^2 + beta_n^2) sum_k lam_nk )
+//   3. z: <= (max_iters - it) penalty steps pen_j = penalty * scale^j while err > tol (the loop counter is seeded with
+//      the OUTER iteration index and err with sum(y), caviar.py:86; quirk 4: nothing happens once it >= max_iters),
+//      then spont_rate = mean(z != 0) (caviar.py:88).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_sigma_spont(const double* __restrict__ y, const double* __restrict__ R,
+__global__ __launch_bounds__(1024) void k_post_single(const double* __restrict__ y, const double* __restrict__ R,
                                                        const uint8_t* __restrict__ colany, const uint8_t* __restrict__ mask,
                                                        const double* __restrict__ mu, const double* __restrict__ beta,
                                                        const double* __restrict__ rs, const double* __restrict__ sum_y, int N, int K,
                                                        int it, int max_iters, double penalty, double scale_factor, double tol,
-                                                       double* __restrict__ z, double* __restrict__ scal) {
+                                                       int do_sigma, int seq, int* __restrict__ act_idx, int* __restrict__ act_inv,
+                                                       int* __restrict__ n_act, int* mailbox, double* __restrict__ z,
+                                                       double* __restrict__ scal) {
   __shared__ double sh[16];
-  // ---- update_sigma
+  __shared__ int wave_cnt[16];
+  __shared__ int base;
+  // ---- 1. active set
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  {
+    const int lane = threadIdx.x % CM_WAVE, w = threadIdx.x / CM_WAVE;
+    for (int n0 = 0; n0 < N; n0 += 1024) {
+      const int n = n0 + threadIdx.x;
+      const bool a = n < N && rs[(size_t)n * 4 + 3] >= 0.0;
+      const unsigned long long m = __ballot(a);
+      if (lane == 0) wave_cnt[w] = __popcll(m);
+      __syncthreads();
+      int off = base;
+      for (int i = 0; i < w; ++i) off += wave_cnt[i];
+      if (n < N) {
+        if (a) {
+          const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+          act_idx[pos] = n;
+          act_inv[n] = pos;
+        } else {
+          act_inv[n] = -1;
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) { int t = 0; for (int i = 0; i < 16; ++i) t += wave_cnt[i]; base += t; }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      n_act[0] = base;
+      if (mailbox) {                                  // host-mapped pinned memory; system-scope release on the sequence word
+        mailbox[0] = base;
+        mailbox[1] = n_act[1];
+        __hip_atomic_store(&mailbox[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
+  if (!do_sigma) return;
+  // ---- 2. update_sigma
   double a = 0.0;
   for (int k = threadIdx.x; k < K; k += blockDim.x) { const double r = y[k] - R[k]; a = fma(r, r, a); }
   double b = 0.0, c = 0.0;
@@ -70,12 +132,11 @@ __global__ __launch_bounds__(1024) void k_sigma_spont(const double* __restrict__
     scal[CM_S_SHAPE] = scal[CM_S_SHAPE_PRIOR] + (double)K / 2.0;
     scal[CM_S_RATE] = scal[CM_S_RATE_PRIOR] + 0.5 * (a - b + c);
   }
-  // ---- estimate_spont_act_soft_thresh
+  // ---- 3. estimate_spont_act_soft_thresh
   double err = sum_y[0];
   const double ysq = sum_y[1] + 1e-5;
   double pen = penalty;
   int itc = it;
-  bool ran = false;
   while (itc < max_iters && err > tol) {
     double e = 0.0;
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
@@ -91,15 +152,56 @@ __global__ __launch_bounds__(1024) void k_sigma_spont(const double* __restrict__
     err = block_sum(e, sh) / ysq;
     ++itc;
     pen *= scale_factor;
-    ran = true;
   }
-  (void)ran;
-  // ---- spont_rate = mean(z != 0)
   __syncthreads();
   double cnt = 0.0;
   for (int k = threadIdx.x; k < K; k += blockDim.x) cnt += (z[k] != 0.0) ? 1.0 : 0.0;
   cnt = block_sum(cnt, sh);
   if (threadIdx.x == 0) scal[CM_S_SPONT_RATE] = cnt / (double)K;
+}
+
+// Row + column statistics of the current lam.  The caller follows with cm_launch_post_single().
+int cm_launch_stats(cm_ctx* ctx, cm_problem* p, double spont_orthogonality) {
+  const int nbR = (p->N + 3) / 4, nbC = (p->K + 255) / 256;
+  hipLaunchKernelGGL(k_stats, dim3(nbR + nbC), dim3(256), 0, ctx->stream, p->lam, p->row_ptr, p->col, p->y, p->mu, p->col_ptr, p->csc_row,
+                     p->csc_pos, p->N, p->K, nbR, spont_orthogonality, p->rs, p->R, p->colany);
+  CM_HIP(hipGetLastError());
+  return CM_OK;
+}
+
+// Compaction (+ mailbox post) and, if do_sigma, update_sigma / z / spont_rate.  `it` < 0 means "state init".
+int cm_launch_post_single(cm_ctx* ctx, cm_problem* p, int it, const cm_options* o, int do_sigma) {
+  hipStream_t st = ctx->stream;
+  const int seq = ++ctx->mail_seq;
+  hipLaunchKernelGGL(k_post_single, dim3(1), dim3(1024), 0, st, p->y, p->R, p->colany, p->mask, p->mu, p->beta, p->rs, p->sum_y, p->N, p->K,
+                     it, o ? o->max_backtrack_iters : 0, o ? o->penalty : 0.0, o ? o->scale_factor : 0.0, o ? o->tol : 0.0, do_sigma, seq,
+                     p->act_idx, p->act_inv, p->n_act, ctx->use_mailbox ? ctx->d_mailbox : (int*)nullptr, p->z, p->scal);
+  CM_HIP(hipGetLastError());
+  if (!ctx->use_mailbox) {
+    CM_HIP(hipMemcpyAsync(ctx->h_pinned, p->n_act, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+    CM_HIP(hipEventRecord(ctx->ev[7], st));
+  }
+  return CM_OK;
+}
+
+// Host side of the mailbox: wait until the kernel launched by the last cm_launch_post_single() has posted the active-set size.
+int cm_wait_active(cm_ctx* ctx, cm_problem* p) {
+  (void)p;
+  if (!ctx->use_mailbox) { CM_HIP(hipEventSynchronize(ctx->ev[7])); return CM_OK; }
+  volatile int32_t* mb = ctx->h_pinned;
+  const int seq = ctx->mail_seq;
+  unsigned long long spins = 0;
+  while (__atomic_load_n(&mb[2], __ATOMIC_ACQUIRE) != seq) {
+    if ((++spins & 0xFFFFull) == 0) {                      // every 64k polls make sure the stream is still alive
+      hipError_t q = hipStreamQuery(ctx->stream);
+      if (q != hipErrorNotReady && q != hipSuccess) { cm_set_error("stream failed while waiting for the active set: %s", hipGetErrorString(q)); return CM_ERR_HIP; }
+      if (q == hipSuccess && __atomic_load_n(&mb[2], __ATOMIC_ACQUIRE) != seq) {
+        cm_set_error("active-set mailbox was not posted (seq %d, have %d)", seq, (int)mb[2]);
+        return CM_ERR_STATE;
+      }
+    }
+  }
+  return CM_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -259,10 +361,3 @@ int cm_launch_update_phi(cm_ctx* ctx, cm_problem* p, hipStream_t st) {
   return CM_OK;
 }
 
-int cm_launch_post(cm_ctx* ctx, cm_problem* p, int it, const cm_options* o) {
-  CM_TRY(cm_launch_col_stats(ctx, p, o->spont_orthogonality));
-  hipLaunchKernelGGL(k_sigma_spont, dim3(1), dim3(1024), 0, ctx->stream, p->y, p->R, p->colany, p->mask, p->mu, p->beta, p->rs, p->sum_y,
-                     p->N, p->K, it, o->max_backtrack_iters, o->penalty, o->scale_factor, o->tol, p->z, p->scal);
-  CM_HIP(hipGetLastError());
-  return CM_OK;     // update_phi runs on the side stream (cm_caviar_run)
-}

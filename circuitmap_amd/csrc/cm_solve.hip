@@ -15,68 +15,6 @@
 #define TP (CM_TILE + 1)   // padded LDS row (doubles)
 
 // ------------------------------------------------------------------------------------------------
-// row statistics + active flags (one wave per row)
-// rs[n] = {sum lam, sum lam^2, sum y*lam, any(lam != 0)}
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_row_stats(const double* __restrict__ lam, const int* __restrict__ row_ptr,
-                                                    const int* __restrict__ col, const double* __restrict__ y, int N,
-                                                    double* __restrict__ rs) {
-  const int n = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE;
-  const int lane = threadIdx.x % CM_WAVE;
-  if (n >= N) return;
-  double s1 = 0.0, s2 = 0.0, sy = 0.0, d = 0.0;
-  int any = 0;
-  for (int e = row_ptr[n] + lane; e < row_ptr[n + 1]; e += CM_WAVE) {
-    const double l = lam[e];
-    s1 += l;
-    s2 = fma(l, l, s2);
-    sy = fma(y[col[e]], l, sy);
-    d = fma(l, 1.0 - l, d);
-    any |= (l != 0.0);
-  }
-  s1 = cm_wave_sum(s1); s2 = cm_wave_sum(s2); sy = cm_wave_sum(sy); d = cm_wave_sum(d);
-  any = __any(any);
-  if (lane == 0) {
-    rs[(size_t)n * 4 + 0] = s1;
-    rs[(size_t)n * 4 + 1] = s2;
-    rs[(size_t)n * 4 + 2] = sy;
-    rs[(size_t)n * 4 + 3] = any ? d : -1.0;   // sum lam(1-lam) for active rows, -1 marks an all-zero row
-  }
-}
-
-// ordered compaction of the active rows; single workgroup
-__global__ __launch_bounds__(1024) void k_active_compact(const double* __restrict__ rs, int N, int* __restrict__ act_idx,
-                                                          int* __restrict__ act_inv, int* __restrict__ n_act) {
-  __shared__ int wave_cnt[16];
-  __shared__ int base;
-  if (threadIdx.x == 0) base = 0;
-  __syncthreads();
-  const int lane = threadIdx.x % CM_WAVE, w = threadIdx.x / CM_WAVE;
-  for (int n0 = 0; n0 < N; n0 += 1024) {
-    const int n = n0 + threadIdx.x;
-    const bool a = n < N && rs[(size_t)n * 4 + 3] >= 0.0;
-    const unsigned long long m = __ballot(a);
-    if (lane == 0) wave_cnt[w] = __popcll(m);
-    __syncthreads();
-    int off = base;
-    for (int i = 0; i < w; ++i) off += wave_cnt[i];
-    if (n < N) {
-      if (a) {
-        const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
-        act_idx[pos] = n;
-        act_inv[n] = pos;
-      } else {
-        act_inv[n] = -1;
-      }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) { int t = 0; for (int i = 0; i < 16; ++i) t += wave_cnt[i]; base += t; }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) n_act[0] = base;
-}
-
-// ------------------------------------------------------------------------------------------------
 // precision matrix over the active set; one wave per (padded) row, accumulator row in LDS
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_build_precision(const double* __restrict__ lam, const int* __restrict__ row_ptr,
@@ -448,27 +386,21 @@ static size_t small_lds_bytes(int n, int tot_cap) {
   return ((size_t)n * (n + 1) + 3 * CM_SMALL_MAX + tot_cap) * sizeof(double) + ((size_t)tot_cap + 2 * CM_SMALL_MAX + 1) * sizeof(int);
 }
 
-int cm_launch_row_stats(cm_ctx* ctx, cm_problem* p) {
-  hipLaunchKernelGGL(k_row_stats, dim3((p->N + 3) / 4), dim3(256), 0, ctx->stream, p->lam, p->row_ptr, p->col, p->y, p->N, p->rs);
-  hipLaunchKernelGGL(k_active_compact, dim3(1), dim3(1024), 0, ctx->stream, p->rs, p->N, p->act_idx, p->act_inv, p->n_act);
-  CM_HIP(hipGetLastError());
-  CM_HIP(hipMemcpyAsync(ctx->h_pinned, p->n_act, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  CM_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
-  return CM_OK;
-}
-
 // Expects cm_launch_row_stats() to have been enqueued after the last change of lam.
 int cm_solve_mu(cm_ctx* ctx, cm_problem* p, int* n_active_out) {
   hipStream_t st = ctx->stream;
-  CM_HIP(hipEventSynchronize(ctx->ev[7]));          // the only host wait of an iteration: size of the active set
+  CM_TRY(cm_wait_active(ctx, p));                   // the only host wait of an iteration: size of the active set
   const int na = ctx->h_pinned[0];
   if (n_active_out) *n_active_out = na;
   if (na > 0 && na <= CM_SMALL_MAX) {
     const int tot_cap = na * p->max_row_len;
     const size_t lds = small_lds_bytes(na, tot_cap);
     if (lds <= 150 * 1024) {
-      if (lds > 48 * 1024)
+      static thread_local size_t attr_set = 48 * 1024;
+      if (lds > attr_set) {
         CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_small), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = lds;
+      }
       hipLaunchKernelGGL(k_solve_small, dim3(1), dim3(1024), lds, st, p->lam, p->row_ptr, p->col, p->act_idx, p->rs, p->scal, p->mu_prior,
                          p->beta_prior, na, p->N, tot_cap, p->mu, p->beta, p->n_act + 1);
       CM_HIP(hipGetLastError());

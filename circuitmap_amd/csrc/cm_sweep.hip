@@ -182,49 +182,63 @@ __device__ __forceinline__ double cm_pava_last_dev(const double* y, int n, doubl
 // Gate of a row held one entry per lane (<= 64 targeted trials): per-power mean rates by wave reductions, isotonic
 // tail, minimum spike count (caviar.py:219-221).  For P <= 8 powers everything stays in registers and the isotonic
 // tail uses its closed form max_j mean(srates[j:]) (== the pool walk's last value; tests/test_oracle_golden.py).
-__device__ __forceinline__ double row_gate(bool valid, int g, double est, int P, double thresh, double min_count, double* scr) {
+// PS is the compile-time number of powers (straight-line code: the P + 1 reductions interleave); PS = 0 -> runtime P.
+template <int PS>
+__device__ __forceinline__ double row_gate_small(bool valid, int g, double est, int Prt, double thresh, double min_count) {
+  const int P = PS > 0 ? PS : Prt;
+  constexpr int PM = PS > 0 ? PS : 8;
   const double total = cm_wave_sum(est);
-  double iso;
-  if (P <= 8) {
-    // the P rate divisions run in P different lanes at once, and so do the P suffix-mean divisions
-    const int lane = (int)(threadIdx.x % CM_WAVE);
-    double num = 0.0, den = 1.0;
+  // the P rate divisions run in P different lanes at once, and so do the P suffix-mean divisions
+  const int lane = (int)(threadIdx.x % CM_WAVE);
+  double num = 0.0, den = 1.0;
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      if (p < P) {
-        const bool in = valid && g == p + 1;
-        const double s = cm_wave_sum(in ? est : 0.0);
-        const int cnt = __popcll(__ballot(in));
-        if (lane == p) { num = s; den = (double)cnt + 1e-4 * (double)(cnt == 0); }   // caviar.py:183
-      }
-    }
-    const double sr_l = num / den;                 // lane p: mean rate at power p
-    double S = 0.0, numj = 0.0, denj = 1.0;
-    int c = 0;
-#pragma unroll
-    for (int j = 7; j >= 0; --j) {
-      if (j < P) {
-        S += cm_readlane_f64(sr_l, j); ++c;
-        if (lane == j) { numj = S; denj = (double)c; }
-      }
-    }
-    const double m_l = numj / denj;                // lane j: mean(srates[j:])
-    double best = -1.0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (j < P) { const double m = cm_readlane_f64(m_l, j); best = m > best ? m : best; }
-    }
-    iso = P > 0 ? best : 0.0;
-  } else {                                   // many powers: rates and pool stacks in the wave's LDS scratch (3 x 64 doubles)
-    double* sr = scr;
-    for (int p = 0; p < P; ++p) {
+  for (int p = 0; p < PM; ++p) {
+    if (p < P) {
       const bool in = valid && g == p + 1;
       const double s = cm_wave_sum(in ? est : 0.0);
       const int cnt = __popcll(__ballot(in));
-      sr[p] = s / ((double)cnt + 1e-4 * (double)(cnt == 0));     // every lane writes the same value
+      if (lane == p) { num = s; den = (double)cnt + 1e-4 * (double)(cnt == 0); }   // caviar.py:183
     }
-    iso = cm_pava_last_dev(sr, P, scr + CM_MAX_VALS, scr + 2 * CM_MAX_VALS);
   }
+  const double sr_l = num / den;                 // lane p: mean rate at power p
+  double S = 0.0, numj = 0.0, denj = 1.0;
+  int c = 0;
+#pragma unroll
+  for (int j = PM - 1; j >= 0; --j) {
+    if (j < P) {
+      S += cm_readlane_f64(sr_l, j); ++c;
+      if (lane == j) { numj = S; denj = (double)c; }
+    }
+  }
+  const double m_l = numj / denj;                // lane j: mean(srates[j:])
+  double best = -1.0;
+#pragma unroll
+  for (int j = 0; j < PM; ++j) {
+    if (j < P) { const double m = cm_readlane_f64(m_l, j); best = m > best ? m : best; }
+  }
+  const double iso = P > 0 ? best : 0.0;
+  return (iso >= thresh && total >= min_count) ? 1.0 : 0.0;                // caviar.py:220
+}
+
+__device__ __forceinline__ double row_gate(bool valid, int g, double est, int P, double thresh, double min_count, double* scr) {
+  switch (P) {
+    case 1: return row_gate_small<1>(valid, g, est, P, thresh, min_count);
+    case 2: return row_gate_small<2>(valid, g, est, P, thresh, min_count);
+    case 3: return row_gate_small<3>(valid, g, est, P, thresh, min_count);
+    case 4: return row_gate_small<4>(valid, g, est, P, thresh, min_count);
+    default: break;
+  }
+  if (P <= 8) return row_gate_small<0>(valid, g, est, P, thresh, min_count);
+  // many powers: rates and pool stacks in the wave's LDS scratch (3 x 64 doubles), literal pool walk
+  const double total = cm_wave_sum(est);
+  double* sr = scr;
+  for (int p = 0; p < P; ++p) {
+    const bool in = valid && g == p + 1;
+    const double s = cm_wave_sum(in ? est : 0.0);
+    const int cnt = __popcll(__ballot(in));
+    sr[p] = s / ((double)cnt + 1e-4 * (double)(cnt == 0));     // every lane writes the same value
+  }
+  const double iso = cm_pava_last_dev(sr, P, scr + CM_MAX_VALS, scr + 2 * CM_MAX_VALS);
   return (iso >= thresh && total >= min_count) ? 1.0 : 0.0;                // caviar.py:220
 }
 
@@ -291,12 +305,7 @@ __device__ __forceinline__ void sweep_step_long(const SweepArgs& a, int n, RPtr 
 
 // rows with mu == 0: arg = sigma * beta^2 does not involve R and mu * lam contributes nothing to R, so these rows are
 // independent of the chain and of each other -> one wave each over the whole chip
-__global__ __launch_bounds__(256) void k_sweep_indep(SweepArgs a, int N) {
-  __shared__ double scr_all[4][3 * CM_MAX_VALS];
-  double* scr = scr_all[threadIdx.x / CM_WAVE];
-  const int n = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE;
-  const int lane = threadIdx.x % CM_WAVE;
-  if (n >= N) return;
+__device__ __forceinline__ void sweep_indep_row(const SweepArgs& a, int n, int lane, double* scr) {
   if (a.mu[n] != 0.0) return;
   const double sig = a.scal[CM_S_SHAPE] / a.scal[CM_S_RATE];
   const double thresh = a.msrmp + a.scal[CM_S_SPONT_RATE];
@@ -338,11 +347,10 @@ struct __align__(16) SeqRec {
 #define CM_SEQ_B (CM_SEQ_CAP - CM_WAVE - 1)   // chunking granule: a chunk spans < B + 65 <= CAP records
 #define CM_SEQ_LDS_CHUNKS 512
 
-__global__ __launch_bounds__(1024) void k_seq_scan(const int* __restrict__ order, const double* __restrict__ mu,
-                                                    const int* __restrict__ row_ptr, int N, int* __restrict__ seq_n,
-                                                    int* __restrict__ seq_off, int* __restrict__ chunk_first, int* __restrict__ meta) {
-  __shared__ int wsum[2][16];
-  __shared__ int carry[2];
+__device__ __forceinline__ void seq_scan_body(const int* __restrict__ order, const double* __restrict__ mu,
+                                              const int* __restrict__ row_ptr, int N, int* __restrict__ seq_n,
+                                              int* __restrict__ seq_off, int* __restrict__ chunk_first, int* __restrict__ meta,
+                                              int (*wsum)[16], int* carry) {
   if (threadIdx.x < 2) carry[threadIdx.x] = 0;
   __syncthreads();
   const int lane = threadIdx.x % CM_WAVE, w = threadIdx.x / CM_WAVE;
@@ -387,6 +395,34 @@ __global__ __launch_bounds__(1024) void k_seq_scan(const int* __restrict__ order
     seq_off[nseq] = total;
     chunk_first[nchunks] = nseq;
     meta[0] = nseq; meta[1] = total; meta[2] = nchunks;
+  }
+}
+
+// One launch, three independent roles (1024-thread blocks):
+//   blocks [0, nbI)        rows with mu == 0, one wave per row (they neither read nor change R)
+//   blocks [nbI, nbI+nbC)  R_k = sum_n mu_n lam_nk per trial (= lam.T @ mu, ascending neuron order).  Rows handled by the
+//                          first role have mu == 0, so whichever of their old/new lam is read contributes exactly 0.
+//   last block             ordered compaction of the mu != 0 rows + record offsets + chunk table of the chain
+__global__ __launch_bounds__(1024) void k_presweep(SweepArgs a, int N, int K, int nbI, int nbC, const int* __restrict__ order,
+                                                    const int* __restrict__ col_ptr, const int* __restrict__ csc_row,
+                                                    const int* __restrict__ csc_pos, double* __restrict__ R, int* __restrict__ seq_n,
+                                                    int* __restrict__ seq_off, int* __restrict__ chunk_first, int* __restrict__ meta) {
+  __shared__ double scr_all[16][3 * CM_MAX_VALS];
+  __shared__ int wsum[2][16];
+  __shared__ int carry[2];
+  const int b = blockIdx.x;
+  if (b < nbI) {
+    const int n = b * 16 + threadIdx.x / CM_WAVE;
+    if (n < N) sweep_indep_row(a, n, threadIdx.x % CM_WAVE, scr_all[threadIdx.x / CM_WAVE]);
+  } else if (b < nbI + nbC) {
+    const int k = (b - nbI) * 1024 + threadIdx.x;
+    if (k < K) {
+      double s = 0.0;
+      for (int ce = col_ptr[k]; ce < col_ptr[k + 1]; ++ce) s = fma(a.mu[csc_row[ce]], a.lam[csc_pos[ce]], s);
+      R[k] = s;
+    }
+  } else {
+    seq_scan_body(order, a.mu, a.row_ptr, N, seq_n, seq_off, chunk_first, meta, wsum, carry);
   }
 }
 
@@ -550,15 +586,18 @@ int cm_launch_sweep(cm_ctx* ctx, cm_problem* p, int it, const cm_options* o, hip
   a.msrmp = o->msrmp; a.min_count = o->minimum_spike_count;
   hipStream_t st = ctx->stream;
   const int N = p->N;
-  hipLaunchKernelGGL(k_sweep_indep, dim3((N + 3) / 4), dim3(256), 0, st, a, N);
-  hipLaunchKernelGGL(k_seq_scan, dim3(1), dim3(1024), 0, st, p->order, p->mu, p->row_ptr, N, p->seq_n, p->seq_off, p->chunk_first, p->seq_meta);
+  const int nbI = (N + 15) / 16, nbC = (p->K + 1023) / 1024;
+  hipLaunchKernelGGL(k_presweep, dim3(nbI + nbC + 1), dim3(1024), 0, st, a, N, p->K, nbI, nbC, p->order, p->col_ptr, p->csc_row,
+                     p->csc_pos, p->R, p->seq_n, p->seq_off, p->chunk_first, p->seq_meta);
   hipLaunchKernelGGL(k_seq_pack, dim3((N + 3) / 4), dim3(256), 0, st, a, p->seq_n, p->seq_off, p->seq_meta, (SeqRec*)p->packed);
-  CM_TRY(cm_launch_col_stats(ctx, p, o->spont_orthogonality));     // R = lam.T @ mu with the new mu (colany is recomputed later)
   if (mid) CM_HIP(hipEventRecord(mid, st));
   const size_t lds = (size_t)p->K * sizeof(double);
   if (lds <= 88 * 1024) {     // 64 KiB of record buffers + R must fit the CU's 160 KiB
-    if (lds > 0)
+    static thread_local size_t attr_set = 0;      // raise the dynamic-LDS cap only when it has to grow
+    if (lds > attr_set) {
       CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_seq<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set = lds;
+    }
     hipLaunchKernelGGL(k_sweep_seq<true>, dim3(1), dim3(1024), lds, st, a, (const SeqRec*)p->packed, p->seq_off, p->chunk_first,
                        p->seq_meta, p->K, p->col_ptr, p->csc_row, p->csc_pos, p->R);
   } else {
