@@ -102,7 +102,7 @@ extern "C" int cm_problem_destroy(cm_problem* p) {
   void* ptrs[] = {p->y, p->ss, p->sum_y, p->vals, p->row_ptr, p->col, p->grp, p->rowcnt, p->col_ptr, p->csc_row, p->csc_pos,
                   p->mask, p->lam, p->mu, p->beta, p->mu_prior, p->beta_prior, p->phi, p->phi_cov, p->phi_prior, p->phi_cov_prior,
                   p->scal, p->R, p->colany, p->z, p->mcE, p->rs, p->act_idx, p->act_inv, p->n_act, p->orders_all, p->orders_tmp,
-                  p->keys, p->uexp, p->A, p->X, p->Dinv, p->rhs, p->seq_n, p->seq_off, p->chunk_first,
+                  p->keys, p->uexp, p->A, p->X, p->Lf, p->Dinv, p->rhs, p->seq_n, p->seq_off, p->chunk_first,
                   p->seq_meta, p->packed};
   for (void* q : ptrs) if (q) hipFree(q);
   free_hist(p);
@@ -145,7 +145,7 @@ extern "C" int cm_problem_create(cm_ctx* ctx, int32_t N, int32_t K, int32_t T, c
       (rc = dmalloc(&p->phi_cov_prior, 4 * (size_t)N)) || (rc = dmalloc(&p->scal, CM_S_COUNT)) || (rc = dmalloc(&p->R, K)) ||
       (rc = dmalloc(&p->colany, K)) || (rc = dmalloc(&p->z, K)) || (rc = dmalloc(&p->mcE, (size_t)N * CM_MAX_VALS)) ||
       (rc = dmalloc(&p->rs, 4 * (size_t)N)) || (rc = dmalloc(&p->act_idx, N)) || (rc = dmalloc(&p->act_inv, N)) ||
-      (rc = dmalloc(&p->n_act, 4)) || (rc = dmalloc(&p->A, ld * ld)) || (rc = dmalloc(&p->X, ld * ld)) ||
+      (rc = dmalloc(&p->n_act, 4)) || (rc = dmalloc(&p->A, ld * ld)) || (rc = dmalloc(&p->X, ld * ld)) || (rc = dmalloc(&p->Lf, ld * ld)) ||
       (rc = dmalloc(&p->Dinv, ld * CM_TILE)) || (rc = dmalloc(&p->rhs, 2 * ld)) || (rc = dmalloc(&p->seq_n, N)) ||
       (rc = dmalloc(&p->seq_off, (size_t)N + 1)) || (rc = dmalloc(&p->chunk_first, ((size_t)N + p->nnz) / 512 + 8)) ||
       (rc = dmalloc(&p->seq_meta, 4)) || (rc = dmalloc((char**)&p->packed, ((size_t)N + p->nnz) * 32)))

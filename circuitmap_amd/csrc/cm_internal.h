@@ -99,6 +99,7 @@ struct cm_problem {
   double* uexp = nullptr;     // explicit uniforms (device copy) or nullptr
   double* A = nullptr;        // [ld*ld] precision matrix / Cholesky factor
   double* X = nullptr;        // [ld*ld] inverse factor
+  double* Lf = nullptr;       // [ld*ld] Cholesky factor (panel tiles below the diagonal)
   double* Dinv = nullptr;     // [ld*CM_TILE] inverses of the diagonal tiles
   double* rhs = nullptr;      // [ld*2]
   // histories

@@ -59,10 +59,10 @@ __global__ __launch_bounds__(64) void k_build_precision(const double* __restrict
 // 32x32 tile helpers (256 threads, each owns a 2x2 patch)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void tile_load(double (*dst)[TP], const double* __restrict__ src, int ld) {
-  for (int i = threadIdx.x; i < TS * TS; i += 256) dst[i / TS][i % TS] = src[(size_t)(i / TS) * ld + (i % TS)];
+  for (int i = threadIdx.x; i < TS * TS; i += blockDim.x) dst[i / TS][i % TS] = src[(size_t)(i / TS) * ld + (i % TS)];
 }
 __device__ __forceinline__ void tile_store(double* __restrict__ dst, int ld, const double (*src)[TP]) {
-  for (int i = threadIdx.x; i < TS * TS; i += 256) dst[(size_t)(i / TS) * ld + (i % TS)] = src[i / TS][i % TS];
+  for (int i = threadIdx.x; i < TS * TS; i += blockDim.x) dst[(size_t)(i / TS) * ld + (i % TS)] = src[i / TS][i % TS];
 }
 // c[2][2] += A(rows r0..r0+1, :) * B(rows c0..c0+1, :)^T
 __device__ __forceinline__ void tile_mma_nt(double c[2][2], const double (*A)[TP], const double (*B)[TP], int r0, int c0) {
@@ -89,8 +89,8 @@ __device__ __forceinline__ void tile_mma_nn(double c[2][2], const double (*A)[TP
 // C is destroyed; Rt is scratch; Li receives L^-1 (lower triangular).
 __device__ __forceinline__ void tile_linv(double (*C)[TP], double (*Rt)[TP], double (*Li)[TP], int* __restrict__ flag) {
   __shared__ double dk[TS];
-  const int tid = threadIdx.x;
-  for (int i = tid; i < TS * TS; i += 256) Rt[i / TS][i % TS] = (i / TS == i % TS) ? 1.0 : 0.0;
+  const int tid = threadIdx.x, nt = blockDim.x;       // 256 or 1024 threads
+  for (int i = tid; i < TS * TS; i += nt) Rt[i / TS][i % TS] = (i / TS == i % TS) ? 1.0 : 0.0;
   bool bad = false;
   for (int k = 0; k < TS; ++k) {
     __syncthreads();
@@ -99,7 +99,7 @@ __device__ __forceinline__ void tile_linv(double (*C)[TP], double (*Rt)[TP], dou
     const double rd = 1.0 / d;
     if (tid == 0) dk[k] = d;
     const int rem = TS - 1 - k;                    // rows below the pivot
-    for (int idx = tid; idx < rem * TS; idx += 256) {
+    for (int idx = tid; idx < rem * TS; idx += nt) {
       const int i = k + 1 + idx / TS, q = idx % TS;
       const double m = C[i][k] * rd;
       if (q < rem) { const int j = k + 1 + q; C[i][j] = fma(-m, C[k][j], C[i][j]); }
@@ -107,7 +107,7 @@ __device__ __forceinline__ void tile_linv(double (*C)[TP], double (*Rt)[TP], dou
     }
   }
   __syncthreads();
-  for (int i = tid; i < TS * TS; i += 256) {
+  for (int i = tid; i < TS * TS; i += nt) {
     const int r = i / TS, c = i % TS;
     Li[r][c] = (c <= r) ? Rt[r][c] / sqrt(dk[r]) : 0.0;
   }
@@ -116,36 +116,22 @@ __device__ __forceinline__ void tile_linv(double (*C)[TP], double (*Rt)[TP], dou
 }
 
 // factor the first diagonal tile
-__global__ __launch_bounds__(256) void k_chol_first(double* __restrict__ A, int ld, double* __restrict__ Dinv, int* __restrict__ flag) {
+__global__ __launch_bounds__(1024) void k_chol_first(double* __restrict__ A, int ld, double* __restrict__ Dinv, int* __restrict__ flag) {
   __shared__ double C[TS][TP], Rt[TS][TP], Li[TS][TP];
   tile_load(C, A, ld);
   tile_linv(C, Rt, Li, flag);
   tile_store(Dinv, TS, Li);
 }
 
-// panel j: A[i][j] <- A[i][j] * L_jj^-T for i > j   (one workgroup per tile row)
-__global__ __launch_bounds__(256) void k_chol_trsm(double* __restrict__ A, int ld, const double* __restrict__ Dinv, int j) {
-  __shared__ double P[TS][TP], Li[TS][TP];
-  const int i = j + 1 + blockIdx.x;
-  double* tile = A + (size_t)i * TS * ld + (size_t)j * TS;
-  tile_load(P, tile, ld);
-  tile_load(Li, Dinv + (size_t)j * TS * TS, TS);
-  __syncthreads();
-  const int r0 = 2 * (threadIdx.x / 16), c0 = 2 * (threadIdx.x % 16);
-  double c[2][2] = {{0, 0}, {0, 0}};
-  tile_mma_nt(c, P, Li, r0, c0);       // X = P * Li^T
-  __syncthreads();
-  P[r0][c0] = c[0][0]; P[r0][c0 + 1] = c[0][1]; P[r0 + 1][c0] = c[1][0]; P[r0 + 1][c0 + 1] = c[1][1];
-  __syncthreads();
-  tile_store(tile, ld, P);
-}
-
-// trailing update by panel j: A[i][l] -= A[i][j] A[l][j]^T for j < l <= i; the workgroup that owns the next
-// diagonal tile (j+1, j+1) factors it on the spot, so each panel costs two launches.
-__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int ld, double* __restrict__ Dinv, int j, int nblk,
-                                                      int* __restrict__ flag) {
-  __shared__ double Pi[TS][TP], Pl[TS][TP], Rt[TS][TP];
-  // linear block id -> (i, l) with 0 <= l' <= i' in the trailing (nblk - j - 1) tile rows
+// Panel j in ONE launch (1024-thread workgroups, one per trailing tile (i, l), j < l <= i):
+//   X_i = A[i][j] L_jj^-T, X_l = A[l][j] L_jj^-T     (panel solve, recomputed per workgroup from the read-only panel tiles)
+//   A[i][l] -= X_i X_l^T                             (trailing update, in place: the tile is owned by this workgroup)
+//   l == j + 1: Lf[i][j] = X_i                       (the factor's panel goes to a separate matrix: A[i][j] is still being read)
+//   i == l == j + 1: factor the next diagonal tile on the spot -> Dinv[j + 1]
+// The 32x32x32 tile products use the first 256 threads (2x2 register patches); the diagonal elimination uses all 1024.
+__global__ __launch_bounds__(1024) void k_chol_panel(double* __restrict__ A, double* __restrict__ Lf, int ld, double* __restrict__ Dinv,
+                                                      int j, int nblk, int* __restrict__ flag) {
+  __shared__ double Pi[TS][TP], Pl[TS][TP], Li[TS][TP], Xi[TS][TP], Xl[TS][TP];
   const int t = blockIdx.x;
   int ip = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
   while ((ip + 1) * (ip + 2) / 2 <= t) ++ip;
@@ -153,25 +139,36 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int
   const int lp = t - ip * (ip + 1) / 2;
   const int i = j + 1 + ip, l = j + 1 + lp;
   tile_load(Pi, A + (size_t)i * TS * ld + (size_t)j * TS, ld);
-  tile_load(Pl, A + (size_t)l * TS * ld + (size_t)j * TS, ld);
+  if (l != i) tile_load(Pl, A + (size_t)l * TS * ld + (size_t)j * TS, ld);
+  tile_load(Li, Dinv + (size_t)j * TS * TS, TS);
   __syncthreads();
-  const int r0 = 2 * (threadIdx.x / 16), c0 = 2 * (threadIdx.x % 16);
-  double c[2][2] = {{0, 0}, {0, 0}};
-  tile_mma_nt(c, Pi, Pl, r0, c0);
+  const bool mm = threadIdx.x < 256;
+  const int r0 = 2 * ((threadIdx.x & 255) / 16), c0 = 2 * ((threadIdx.x & 255) % 16);
+  if (mm) {
+    double c[2][2] = {{0, 0}, {0, 0}};
+    tile_mma_nt(c, Pi, Li, r0, c0);                  // X_i = P_i Linv^T
+    Xi[r0][c0] = c[0][0]; Xi[r0][c0 + 1] = c[0][1]; Xi[r0 + 1][c0] = c[1][0]; Xi[r0 + 1][c0 + 1] = c[1][1];
+    if (l != i) {
+      double e[2][2] = {{0, 0}, {0, 0}};
+      tile_mma_nt(e, Pl, Li, r0, c0);
+      Xl[r0][c0] = e[0][0]; Xl[r0][c0 + 1] = e[0][1]; Xl[r0 + 1][c0] = e[1][0]; Xl[r0 + 1][c0 + 1] = e[1][1];
+    }
+  }
+  __syncthreads();
+  if (l == j + 1) tile_store(Lf + (size_t)i * TS * ld + (size_t)j * TS, ld, Xi);
   double* out = A + (size_t)i * TS * ld + (size_t)l * TS;
-  if (i == j + 1 && l == j + 1) {
-    __syncthreads();
-    Pi[r0][c0] = out[(size_t)r0 * ld + c0] - c[0][0];
-    Pi[r0][c0 + 1] = out[(size_t)r0 * ld + c0 + 1] - c[0][1];
-    Pi[r0 + 1][c0] = out[(size_t)(r0 + 1) * ld + c0] - c[1][0];
-    Pi[r0 + 1][c0 + 1] = out[(size_t)(r0 + 1) * ld + c0 + 1] - c[1][1];
-    tile_linv(Pi, Rt, Pl, flag);
-    tile_store(Dinv + (size_t)(j + 1) * TS * TS, TS, Pl);
-  } else {
-    out[(size_t)r0 * ld + c0] -= c[0][0];
-    out[(size_t)r0 * ld + c0 + 1] -= c[0][1];
-    out[(size_t)(r0 + 1) * ld + c0] -= c[1][0];
-    out[(size_t)(r0 + 1) * ld + c0 + 1] -= c[1][1];
+  const bool diag = (i == j + 1 && l == j + 1);
+  if (mm) {
+    double c[2][2] = {{0, 0}, {0, 0}};
+    if (l != i) tile_mma_nt(c, Xi, Xl, r0, c0); else tile_mma_nt(c, Xi, Xi, r0, c0);
+    const double o00 = out[(size_t)r0 * ld + c0] - c[0][0], o01 = out[(size_t)r0 * ld + c0 + 1] - c[0][1];
+    const double o10 = out[(size_t)(r0 + 1) * ld + c0] - c[1][0], o11 = out[(size_t)(r0 + 1) * ld + c0 + 1] - c[1][1];
+    if (diag) { Pi[r0][c0] = o00; Pi[r0][c0 + 1] = o01; Pi[r0 + 1][c0] = o10; Pi[r0 + 1][c0 + 1] = o11; }
+    else { out[(size_t)r0 * ld + c0] = o00; out[(size_t)r0 * ld + c0 + 1] = o01; out[(size_t)(r0 + 1) * ld + c0] = o10; out[(size_t)(r0 + 1) * ld + c0 + 1] = o11; }
+  }
+  if (diag) {
+    tile_linv(Pi, Pl, Li, flag);                     // Pi holds the updated SPD tile (written before the barrier inside)
+    tile_store(Dinv + (size_t)(j + 1) * TS * TS, TS, Li);
   }
 }
 
@@ -188,7 +185,7 @@ __global__ __launch_bounds__(256) void k_inv_seed(const double* __restrict__ Din
   tile_store(X + (size_t)d * TS * ld + (size_t)d * TS, ld, Tm);
 }
 
-__global__ __launch_bounds__(256) void k_inv_T(double* __restrict__ A, const double* __restrict__ X, int ld, int b, int nblk) {
+__global__ __launch_bounds__(256) void k_inv_T(double* __restrict__ A, const double* __restrict__ Lf, const double* __restrict__ X, int ld, int b, int nblk) {
   __shared__ double Lt[TS][TP], Xt[TS][TP];
   const int per = b * b;
   const int q = blockIdx.x / per, rem = blockIdx.x % per;
@@ -199,7 +196,7 @@ __global__ __launch_bounds__(256) void k_inv_T(double* __restrict__ A, const dou
   double acc[2][2] = {{0, 0}, {0, 0}};
   for (int j1 = c; j1 < (2 * q + 1) * b; ++j1) {    // X11[j1][c] is non-zero only for j1 >= c
     __syncthreads();
-    tile_load(Lt, A + (size_t)j2 * TS * ld + (size_t)j1 * TS, ld);
+    tile_load(Lt, Lf + (size_t)j2 * TS * ld + (size_t)j1 * TS, ld);
     tile_load(Xt, X + (size_t)j1 * TS * ld + (size_t)c * TS, ld);
     __syncthreads();
     tile_mma_nn(acc, Lt, Xt, r0, c0);
@@ -419,18 +416,17 @@ int cm_solve_mu(cm_ctx* ctx, cm_problem* p, int* n_active_out) {
   hipLaunchKernelGGL(k_build_precision, dim3(ld), dim3(64), (size_t)ld * sizeof(double), st, p->lam, p->row_ptr, p->col, p->col_ptr,
                      p->csc_row, p->csc_pos, p->act_idx, p->act_inv, p->rs, p->scal, p->mu_prior, p->beta_prior, na, ld, A, p->rhs);
   // Cholesky
-  hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(256), 0, st, A, ld, p->Dinv, p->n_act + 1);
+  hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(1024), 0, st, A, ld, p->Dinv, p->n_act + 1);
   for (int j = 0; j + 1 < nblk; ++j) {
     const int t = nblk - j - 1;
-    hipLaunchKernelGGL(k_chol_trsm, dim3(t), dim3(256), 0, st, A, ld, p->Dinv, j);
-    hipLaunchKernelGGL(k_chol_update, dim3(t * (t + 1) / 2), dim3(256), 0, st, A, ld, p->Dinv, j, nblk, p->n_act + 1);
+    hipLaunchKernelGGL(k_chol_panel, dim3(t * (t + 1) / 2), dim3(1024), 0, st, A, p->Lf, ld, p->Dinv, j, nblk, p->n_act + 1);
   }
   // inverse of the factor
   CM_HIP(hipMemsetAsync(X, 0, (size_t)ld * ld * sizeof(double), st));
   hipLaunchKernelGGL(k_inv_seed, dim3(nblk), dim3(256), 0, st, p->Dinv, X, ld);
   for (int b = 1; b < nblk; b *= 2) {
     const int npairs = (nblk + 2 * b - 1) / (2 * b);
-    hipLaunchKernelGGL(k_inv_T, dim3(npairs * b * b), dim3(256), 0, st, A, X, ld, b, nblk);
+    hipLaunchKernelGGL(k_inv_T, dim3(npairs * b * b), dim3(256), 0, st, A, p->Lf, X, ld, b, nblk);
     hipLaunchKernelGGL(k_inv_X21, dim3(npairs * b * b), dim3(256), 0, st, A, X, ld, b, nblk);
   }
   // mu, beta
