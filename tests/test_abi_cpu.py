@@ -1,0 +1,120 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads, exports every symbol that include/caviar_hip.h
+declares, reports the reference's defaults, and refuses loudly to run without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    ge.build()
+    from circuitmap_amd import _lib
+    return _lib.load()
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "caviar_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported(lib):
+    from circuitmap_amd import _lib
+    names = declared_functions()
+    assert len(names) >= 17
+    for name in names:
+        assert hasattr(lib, name), "libcaviar_hip.so does not export %s" % name
+        assert name in _lib.SYMBOLS, "circuitmap_amd/_lib.py has no ctypes prototype for %s" % name
+    assert sorted(_lib.SYMBOLS) == names
+
+
+def test_struct_layouts_match_header():
+    """Field order of the ctypes mirrors == field order of the C structs (a silent mismatch would corrupt arguments)."""
+    from circuitmap_amd import _lib
+    text = open(os.path.join(ROOT, "include", "caviar_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    for cname, cls in [("cm_priors", _lib.CmPriors), ("cm_options", _lib.CmOptions), ("cm_result", _lib.CmResult),
+                       ("cm_timings", _lib.CmTimings)]:
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), text, flags=re.S).group(1)
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(","):
+                fields.append(re.findall(r"[A-Za-z_][A-Za-z0-9_]*", part)[-1])
+        assert fields == [f for f, _ in cls._fields_], cname
+
+
+def test_defaults_are_the_reference_defaults(lib):
+    """cm_options_default == keyword defaults of caviar() (reference circuitmap/optimise/caviar.py:21-23)."""
+    from circuitmap_amd import _lib
+    o = _lib.CmOptions()
+    lib.cm_options_default(C.byref(o))
+    ref = dict(iters=50, num_mc_samples=100, seed=0, y_xcorr_thresh=1e-2, minimum_spike_count=3, delay_spont_est=1, msrmp=0.3,
+               scale_factor=0.75, penalty=5e0, save_histories=0, max_backtrack_iters=20, tol=0.05, spont_orthogonality=0.1, fn_scan=1)
+    for k, v in ref.items():
+        assert getattr(o, k) == v, k
+    assert o.rng_mode == _lib.CM_RNG_THREEFRY
+
+
+def test_host_side_pava_matches_golden(lib):
+    from circuitmap_amd import _lib
+    g = np.load(os.path.join(ROOT, "tests", "golden", "pava.npz"))
+    for y, o in zip(g["y"], g["out"]):
+        y, o = np.ascontiguousarray(y[~np.isnan(y)]), o[~np.isnan(o)]
+        out = C.c_double()
+        assert lib.cm_pava_last(_lib.dptr(y), len(y), C.byref(out)) == 0
+        assert out.value == o[-1]                      # literal pool walk: bit-exact with the reference's pava.py
+    assert lib.cm_pava_last(None, 0, None) != 0         # argument errors are codes, not crashes
+
+
+def test_no_cpu_fallback(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from circuitmap_amd import _lib
+    assert lib.cm_device_count() == 0
+    with pytest.raises(_lib.CaviarHipError, match="no CPU fallback"):
+        _lib.Context(0)
+    import circuitmap_amd as cm
+    sim_psc, stim = np.zeros((4, 5)), np.zeros((2, 4))
+    with pytest.raises(_lib.CaviarHipError):
+        cm.Model(2).fit(sim_psc, stim, method="caviar")
+
+
+def test_model_defaults_and_dispatch():
+    """Priors of Model == reference circuitmap/model.py:24-31; unknown method raises like model.py:44."""
+    import circuitmap_amd as cm
+    m = cm.Model(7)
+    assert np.array_equal(m.state["mu"], np.zeros(7)) and np.array_equal(m.state["beta"], 10 * np.ones(7))
+    assert m.state["shape"] == 1.0 and m.state["rate"] == 0.1
+    assert np.array_equal(m.state["phi"], np.c_[0.1 * np.ones(7), 5 * np.ones(7)])
+    assert m.state["phi_cov"].shape == (7, 2, 2) and np.array_equal(m.state["phi_cov"][3], np.diag([0.1, 1.0]))
+    assert np.array_equal(m.state["alpha"], 0.25 * np.ones(7))
+    with pytest.raises(Exception):
+        m.fit(None, None, method="bogus")
+    with pytest.raises(NotImplementedError):
+        m.fit(None, None, method="mbcs")
+
+
+def test_simulate_contract():
+    """Seeded generator: same keys/shapes as the reference's simulate(), blockwise design invariants."""
+    import circuitmap_amd as cm
+    sim = cm.simulate(N=40, trials=90, H=5, seed=3)
+    sim2 = cm.simulate(N=40, trials=90, H=5, seed=3)
+    assert set(sim) == {"weights", "phi_0", "phi_1", "mult_noise", "sigma", "stim_matrix", "psc", "gp_noise", "kernel", "spks",
+                        "spk_times", "spont_pscs", "I"}
+    assert np.array_equal(sim["psc"], sim2["psc"]) and np.array_equal(sim["stim_matrix"], sim2["stim_matrix"])
+    stim = sim["stim_matrix"]
+    assert stim.shape == (40, 90) and sim["psc"].shape == (90, 900)
+    assert np.all((stim > 0).sum(axis=0) == 5)                       # H targets per trial
+    assert set(np.unique(stim)) == {0.0, 45.0, 55.0, 65.0}
+    assert int((sim["weights"] > 0).sum()) == 2                      # connection_prob 0.05
+    assert np.all(sim["spks"][stim == 0] == 0)
