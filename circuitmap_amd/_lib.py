@@ -68,6 +68,7 @@ SYMBOLS = {
     "cm_pava_last": (C.c_int, [_dp, C.c_int32, _dp]),
     "cm_k_block_update_mu": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, _dp, C.c_double, C.c_double, _dp, _dp, _dp, _dp]),
     "cm_k_update_phi": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, _dp, _dp, _dp, _dp]),
+    "cm_k_reconnect": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_double]),
     "cm_k_rng_streams": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, _ip, _dp]),
 }
 

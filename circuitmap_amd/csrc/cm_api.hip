@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <queue>
 
 #include "cm_internal.h"
 
@@ -218,37 +219,43 @@ static void host_reconnect(const cm_problem* p, std::vector<double>& mu, std::ve
   const size_t init = disc.size();
   // np.where(stim_matrix[n]) selects NON-ZERO entries; targeted entries (> 0) are the CSR row.  Negative stimulus values
   // are outside the reference's contract (powers are non-negative) and are treated as untargeted here.
-  // The reference recounts, for every remaining cell, the spontaneous events on its targeted trials in every pass
-  // (:112-114).  The counts only change when a reconnection clears events, so they are kept and refreshed then.
+  // The reference re-scans all remaining cells in every pass (:109-117): it takes the cell with the most spontaneous events on
+  // its targeted trials (first maximum in ascending cell order), tests it, and removes it.  Counts only ever decrease (a
+  // reconnection clears events from z), so a max-heap keyed (count desc, cell asc) with lazy refresh of stale entries visits
+  // the cells in exactly that order; a reconnection updates the counts of the cells sharing the cleared trials (host CSC).
   long nz = 0;
   for (int k = 0; k < K; ++k) nz += (z[k] != 0.0);
-  std::vector<long> cnt(disc.size());
-  auto recount = [&]() {
-    for (size_t i = 0; i < disc.size(); ++i) {
-      long c = 0;
-      for (int e = p->h_row_ptr[disc[i]]; e < p->h_row_ptr[disc[i] + 1]; ++e) c += (z[p->h_col[e]] != 0.0);
-      cnt[i] = c;
-    }
-  };
-  recount();
-  while (!disc.empty()) {
+  std::vector<long> cnt(N, -1);                         // -1: not a candidate (connected, or already visited)
+  struct Ent { long c; int n; };
+  auto worse = [](const Ent& a, const Ent& b) { return a.c < b.c || (a.c == b.c && a.n > b.n); };
+  std::priority_queue<Ent, std::vector<Ent>, decltype(worse)> heap(worse);
+  for (int n : disc) {
+    long c = 0;
+    for (int e = p->h_row_ptr[n]; e < p->h_row_ptr[n + 1]; ++e) c += (z[p->h_col[e]] != 0.0);
+    cnt[n] = c;
+    heap.push({c, n});
+  }
+  std::vector<double> srates(P > 0 ? P : 0);
+  std::vector<int> locs;
+  while (!heap.empty()) {
     if (!((double)nz > minimum_spike_count)) break;                           // :111,141
-    int focus_indx = 0; long best = -1;
-    for (size_t i = 0; i < disc.size(); ++i)                                  // :117 (argmax takes the first maximum)
-      if (cnt[i] > best) { best = cnt[i]; focus_indx = (int)i; }
-    const int focus = disc[focus_indx];
-    std::vector<double> srates(P > 0 ? P : 0, 0.0);
+    const Ent top = heap.top();
+    heap.pop();
+    if (cnt[top.n] < 0) continue;                                             // already visited
+    if (top.c != cnt[top.n]) { heap.push({cnt[top.n], top.n}); continue; }    // stale: re-queue with the current count
+    const int focus = top.n;
     double spike_count = 0.0;
     for (int i = 0; i < P; ++i) {                                             // :121-127
       long c = 0, hit = 0;
       for (int e = p->h_row_ptr[focus]; e < p->h_row_ptr[focus + 1]; ++e)
         if (p->h_grp[e] == i + 1) { ++c; hit += (z[p->h_col[e]] != 0.0); }
-      if (c > 0) { srates[i] = (double)hit / (double)c; spike_count += (double)hit; }
+      srates[i] = c > 0 ? (double)hit / (double)c : 0.0;
+      if (c > 0) spike_count += (double)hit;
     }
     const double pava = P > 0 ? cm_host_pava_last(srates.data(), P) : 0.0;    // :128
-    bool changed = false;
+    cnt[focus] = -1;                                                          // :139 (removed whether or not it reconnects)
     if (pava >= minimax_spk_prob && spike_count >= minimum_spike_count) {     // :130
-      std::vector<int> locs;
+      locs.clear();
       for (int e = p->h_row_ptr[focus]; e < p->h_row_ptr[focus + 1]; ++e) if (z[p->h_col[e]] != 0.0) locs.push_back(e);
       const size_t m = locs.size();
       double s = 0.0;
@@ -258,14 +265,14 @@ static void host_reconnect(const cm_problem* p, std::vector<double>& mu, std::ve
       for (int e : locs) { const double d = z[p->h_col[e]] - mean; ssd += d * d; }
       mu[focus] = mean;                                                        // :134
       beta[focus] = m > 1 ? sqrt(ssd / (double)(m - 1)) / sqrt((double)m) : NAN;   // :135 scipy.stats.sem, ddof = 1
-      for (int e : locs) { lam[e] = 1.0; z[p->h_col[e]] = 0.0; }               // :136-137
+      for (int e : locs) {                                                     // :136-137
+        const int k = p->h_col[e];
+        lam[e] = 1.0; z[k] = 0.0;
+        for (int ce = p->h_col_ptr[k]; ce < p->h_col_ptr[k + 1]; ++ce) { const int mrow = p->h_csc_row[ce]; if (cnt[mrow] > 0) --cnt[mrow]; }
+      }
       nz -= (long)m;
-      changed = m > 0;
       if (verbose) fprintf(stderr, "Reconnecting cell %d with maximal pava spike rate %.2f\n", focus, pava);
     }
-    disc.erase(disc.begin() + focus_indx);                                     // :139
-    cnt.erase(cnt.begin() + focus_indx);
-    if (changed) recount();
   }
   if (verbose) fprintf(stderr, "Examined %zu/%d cells for false negatives. Cell reconnection complete.\n", init, N);
 }
@@ -574,6 +581,23 @@ extern "C" int cm_k_update_phi(cm_ctx* ctx, int32_t N, int32_t K, const double* 
               hipStreamSynchronize(st) != hipSuccess)) { cm_set_error("download failed: %s", hipGetErrorString(hipGetLastError())); rc = CM_ERR_HIP; }
   cm_problem_destroy(p);
   return rc;
+}
+
+extern "C" int cm_k_reconnect(cm_ctx* ctx, int32_t N, int32_t K, const double* stim, double* lam, double* mu, double* beta, double* z,
+                              double minimax_spk_prob, double minimum_spike_count) {
+  if (!ctx || !stim || !lam || !mu || !beta || !z) { cm_set_error("cm_k_reconnect: NULL argument"); return CM_ERR_INVALID; }
+  cm_problem* p = nullptr;
+  CM_TRY(problem_from_dense(ctx, N, K, stim, lam, nullptr, &p));     // builds the compressed rows (device) + host mirror
+  const size_t nnz = p->nnz;
+  std::vector<double> vm(mu, mu + N), vb(beta, beta + N), vz(z, z + K), vl(nnz ? nnz : 1);
+  for (int n = 0; n < N; ++n)
+    for (int e = p->h_row_ptr[n]; e < p->h_row_ptr[n + 1]; ++e) vl[e] = lam[(size_t)n * K + p->h_col[e]];
+  host_reconnect(p, vm, vb, vl, vz, minimax_spk_prob, minimum_spike_count, 0);
+  for (int n = 0; n < N; ++n)
+    for (int e = p->h_row_ptr[n]; e < p->h_row_ptr[n + 1]; ++e) lam[(size_t)n * K + p->h_col[e]] = vl[e];
+  std::copy(vm.begin(), vm.end(), mu); std::copy(vb.begin(), vb.end(), beta); std::copy(vz.begin(), vz.end(), z);
+  cm_problem_destroy(p);
+  return CM_OK;
 }
 
 extern "C" int cm_k_rng_streams(cm_ctx* ctx, uint64_t seed, int32_t it, int32_t N, int32_t S, int32_t* order, double* u) {

@@ -63,7 +63,7 @@ struct cm_problem {
   int32_t* csc_row = nullptr; // [nnz] neuron index
   int32_t* csc_pos = nullptr; // [nnz] position of the entry in CSR order
   // host mirror of the CSR (for reconnect_spont_cells and dense expansion)
-  std::vector<int32_t> h_row_ptr, h_col;
+  std::vector<int32_t> h_row_ptr, h_col, h_col_ptr, h_csc_row;
   std::vector<uint8_t> h_grp;
   std::vector<double> h_vals;
   // --- CAVIaR state ---

@@ -274,6 +274,10 @@ int cm_encode_stim(cm_ctx* ctx, cm_problem* p, const double* d_stim) {
   CM_HIP(hipMemcpyAsync(p->h_col.data(), p->col, (size_t)p->nnz * sizeof(int), hipMemcpyDeviceToHost, st));
   CM_HIP(hipMemcpyAsync(p->h_grp.data(), p->grp, (size_t)p->nnz, hipMemcpyDeviceToHost, st));
   CM_HIP(hipMemcpyAsync(p->h_vals.data(), p->vals, CM_MAX_VALS * sizeof(double), hipMemcpyDeviceToHost, st));
+  p->h_col_ptr.resize(K + 1);
+  p->h_csc_row.resize(nnz_alloc);
+  CM_HIP(hipMemcpyAsync(p->h_col_ptr.data(), p->col_ptr, (size_t)(K + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
+  CM_HIP(hipMemcpyAsync(p->h_csc_row.data(), p->csc_row, (size_t)p->nnz * sizeof(int), hipMemcpyDeviceToHost, st));
   CM_HIP(hipStreamSynchronize(st));
   hipFree(d_table); hipFree(d_flags); hipFree(d_row_nnz); hipFree(d_col_cnt);
   return CM_OK;

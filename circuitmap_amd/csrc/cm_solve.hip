@@ -123,12 +123,31 @@ __global__ __launch_bounds__(1024) void k_chol_first(double* __restrict__ A, int
   tile_store(Dinv, TS, Li);
 }
 
+// panel solve for large matrices: Lf[i][j] = A[i][j] * L_jj^-T for i > j   (one 256-thread workgroup per tile row)
+__global__ __launch_bounds__(256) void k_chol_trsm(const double* __restrict__ A, double* __restrict__ Lf, int ld,
+                                                    const double* __restrict__ Dinv, int j) {
+  __shared__ double P[TS][TP], Li[TS][TP];
+  const int i = j + 1 + blockIdx.x;
+  tile_load(P, A + (size_t)i * TS * ld + (size_t)j * TS, ld);
+  tile_load(Li, Dinv + (size_t)j * TS * TS, TS);
+  __syncthreads();
+  const int r0 = 2 * (threadIdx.x / 16), c0 = 2 * (threadIdx.x % 16);
+  double c[2][2] = {{0, 0}, {0, 0}};
+  tile_mma_nt(c, P, Li, r0, c0);       // X = P * Li^T
+  double* out = Lf + (size_t)i * TS * ld + (size_t)j * TS;
+  out[(size_t)r0 * ld + c0] = c[0][0]; out[(size_t)r0 * ld + c0 + 1] = c[0][1];
+  out[(size_t)(r0 + 1) * ld + c0] = c[1][0]; out[(size_t)(r0 + 1) * ld + c0 + 1] = c[1][1];
+}
+
 // Panel j in ONE launch (1024-thread workgroups, one per trailing tile (i, l), j < l <= i):
 //   X_i = A[i][j] L_jj^-T, X_l = A[l][j] L_jj^-T     (panel solve, recomputed per workgroup from the read-only panel tiles)
 //   A[i][l] -= X_i X_l^T                             (trailing update, in place: the tile is owned by this workgroup)
 //   l == j + 1: Lf[i][j] = X_i                       (the factor's panel goes to a separate matrix: A[i][j] is still being read)
 //   i == l == j + 1: factor the next diagonal tile on the spot -> Dinv[j + 1]
 // The 32x32x32 tile products use the first 256 threads (2x2 register patches); the diagonal elimination uses all 1024.
+// SOLVED = true: the panel tiles A[.][j] were already solved (k_chol_trsm wrote X into Lf), so the workgroup only does the
+// trailing update -- used for large matrices where recomputing the panel solve per tile pair would triple the flops.
+template <bool SOLVED>
 __global__ __launch_bounds__(1024) void k_chol_panel(double* __restrict__ A, double* __restrict__ Lf, int ld, double* __restrict__ Dinv,
                                                       int j, int nblk, int* __restrict__ flag) {
   __shared__ double Pi[TS][TP], Pl[TS][TP], Li[TS][TP], Xi[TS][TP], Xl[TS][TP];
@@ -138,13 +157,18 @@ __global__ __launch_bounds__(1024) void k_chol_panel(double* __restrict__ A, dou
   while (ip * (ip + 1) / 2 > t) --ip;
   const int lp = t - ip * (ip + 1) / 2;
   const int i = j + 1 + ip, l = j + 1 + lp;
-  tile_load(Pi, A + (size_t)i * TS * ld + (size_t)j * TS, ld);
-  if (l != i) tile_load(Pl, A + (size_t)l * TS * ld + (size_t)j * TS, ld);
-  tile_load(Li, Dinv + (size_t)j * TS * TS, TS);
-  __syncthreads();
   const bool mm = threadIdx.x < 256;
   const int r0 = 2 * ((threadIdx.x & 255) / 16), c0 = 2 * ((threadIdx.x & 255) % 16);
-  if (mm) {
+  if (SOLVED) {
+    tile_load(Xi, Lf + (size_t)i * TS * ld + (size_t)j * TS, ld);
+    if (l != i) tile_load(Xl, Lf + (size_t)l * TS * ld + (size_t)j * TS, ld);
+  } else {
+    tile_load(Pi, A + (size_t)i * TS * ld + (size_t)j * TS, ld);
+    if (l != i) tile_load(Pl, A + (size_t)l * TS * ld + (size_t)j * TS, ld);
+    tile_load(Li, Dinv + (size_t)j * TS * TS, TS);
+  }
+  __syncthreads();
+  if (mm && !SOLVED) {
     double c[2][2] = {{0, 0}, {0, 0}};
     tile_mma_nt(c, Pi, Li, r0, c0);                  // X_i = P_i Linv^T
     Xi[r0][c0] = c[0][0]; Xi[r0][c0 + 1] = c[0][1]; Xi[r0 + 1][c0] = c[1][0]; Xi[r0 + 1][c0 + 1] = c[1][1];
@@ -155,7 +179,7 @@ __global__ __launch_bounds__(1024) void k_chol_panel(double* __restrict__ A, dou
     }
   }
   __syncthreads();
-  if (l == j + 1) tile_store(Lf + (size_t)i * TS * ld + (size_t)j * TS, ld, Xi);
+  if (!SOLVED && l == j + 1) tile_store(Lf + (size_t)i * TS * ld + (size_t)j * TS, ld, Xi);
   double* out = A + (size_t)i * TS * ld + (size_t)l * TS;
   const bool diag = (i == j + 1 && l == j + 1);
   if (mm) {
@@ -419,7 +443,12 @@ int cm_solve_mu(cm_ctx* ctx, cm_problem* p, int* n_active_out) {
   hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(1024), 0, st, A, ld, p->Dinv, p->n_act + 1);
   for (int j = 0; j + 1 < nblk; ++j) {
     const int t = nblk - j - 1;
-    hipLaunchKernelGGL(k_chol_panel, dim3(t * (t + 1) / 2), dim3(1024), 0, st, A, p->Lf, ld, p->Dinv, j, nblk, p->n_act + 1);
+    if (nblk > 48) {                                 // large: solve the panel once, then a pure trailing update
+      hipLaunchKernelGGL(k_chol_trsm, dim3(t), dim3(256), 0, st, A, p->Lf, ld, p->Dinv, j);
+      hipLaunchKernelGGL(k_chol_panel<true>, dim3(t * (t + 1) / 2), dim3(1024), 0, st, A, p->Lf, ld, p->Dinv, j, nblk, p->n_act + 1);
+    } else {                                         // small / medium: one launch per panel
+      hipLaunchKernelGGL(k_chol_panel<false>, dim3(t * (t + 1) / 2), dim3(1024), 0, st, A, p->Lf, ld, p->Dinv, j, nblk, p->n_act + 1);
+    }
   }
   // inverse of the factor
   CM_HIP(hipMemsetAsync(X, 0, (size_t)ld * ld * sizeof(double), st));

@@ -161,6 +161,9 @@ int cm_k_block_update_mu(cm_ctx* ctx, int32_t N, int32_t K, const double* stim, 
 /* caviar.py:246-316 on dense lam/stim */
 int cm_k_update_phi(cm_ctx* ctx, int32_t N, int32_t K, const double* stim, const double* lam,
                     const double* phi_prior, const double* phi_cov_prior, double* phi, double* phi_cov);
+/* caviar.py:102-144 reconnect_spont_cells on dense lam (in/out: mu, beta, lam[N*K], z are updated in place) */
+int cm_k_reconnect(cm_ctx* ctx, int32_t N, int32_t K, const double* stim, double* lam, double* mu, double* beta, double* z,
+                   double minimax_spk_prob, double minimum_spike_count);
 /* Threefry streams as the device generates them (for comparison with oracle/threefry.py): order[N], u[N*S*2] of iteration `it` */
 int cm_k_rng_streams(cm_ctx* ctx, uint64_t seed, int32_t it, int32_t N, int32_t S, int32_t* order, double* u);
 

@@ -61,6 +61,11 @@ def test_unit_phases_vs_golden(ctx):
     _lib.check(ctx.lib.cm_k_update_phi(ctx.handle, N, K, _lib.dptr(stim), _lib.dptr(lam), _lib.dptr(pri["phi"]), _lib.dptr(pri["phi_cov"]),
                                        _lib.dptr(phi), _lib.dptr(cov)))
     assert rel_err(phi, g["phi"]) < 1e-9 and rel_err(cov, g["phi_cov"]) < 1e-9
+    # reconnect_spont_cells (host C++ on the compressed rows): integer / rational arithmetic -> bit-exact
+    rl, rm, rb, rz = lam.copy(), g["rec_mu_in"].copy(), g["bum_beta"].copy(), g["rec_z_in"].copy()
+    _lib.check(ctx.lib.cm_k_reconnect(ctx.handle, N, K, _lib.dptr(stim), _lib.dptr(rl), _lib.dptr(rm), _lib.dptr(rb), _lib.dptr(rz), 0.3, 3.0))
+    assert np.array_equal(rm, g["rec_mu"]) and np.array_equal(rl, g["rec_lam"]) and np.array_equal(rz, g["rec_z"])
+    assert rel_err(rb, g["rec_beta"]) < 1e-14
 
 
 @pytest.mark.parametrize("name", ["caviar_tiny", "caviar_tiny_noscan", "caviar_cfg1"])
@@ -92,10 +97,11 @@ def _sim_case(N, K, seed, **kw):
     return sim, default_priors(N)
 
 
-@pytest.mark.parametrize("N,K,iters", [(300, 1000, 50), (1000, 2000, 12)])
+@pytest.mark.parametrize("N,K,iters", [(300, 1000, 50), (1000, 2000, 12), (2000, 4000, 3)])
 def test_caviar_vs_oracle_bench_sizes(N, K, iters):
     """BASELINE configs[1] (full) and configs[2] (first 12 iterations: covers the ungated full-size solves, the gating
-    transition and the shrinking active set) against the running-residual oracle on identical inputs."""
+    transition and the shrinking active set) against the running-residual oracle on identical inputs; N = 2000 exercises
+    the two-round shuffle (N > 1625), the large-matrix Cholesky path (63 tiles) and K > 2048."""
     from circuitmap_amd.optimise import caviar
     from oracle import caviar_oracle as co
     sim, pri = _sim_case(N, K, 1000 + N)
