@@ -140,13 +140,19 @@ def main():
     if rank == 0:
         its = a.iters
         value = world * a.steps * its / dt
-        # --- dominant kernel: k_sweep_seq, one launch per iteration (timed by HIP events on the library's stream)
+        # --- dominant kernel: k_sweep_seq, one launch per iteration (timed by HIP events on the library's stream).
+        # Algorithmic bytes of a launch = the packed 32-B records of the rows in the chain (header + one per targeted
+        # trial: trial, power, mask, slot, lam_old, MC logit, -2*sigma*y*mu) + 8 B lam write per trial + the K-vector R.
+        # The library reports how many rows / records the chain actually held in each fit (it shrinks as cells are pruned).
         seq_ms = float(np.mean([t["sweep_seq_ms"] for t in tms])) / its          # average launch duration, ms
-        # algorithmic bytes of one sweep launch on the compressed encoding: every targeted entry's trial index (4 B),
-        # power code (1 B), lam read + write (16 B), plus y / mask / R-init gathers per column entry (8 + 1 + 8 + 4 + 4 B)
-        sparse_bytes = nnz * (4 + 1 + 16) + nnz * (8 + 4 + 4) + K * (8 + 1 + 8)
+        recs = float(np.mean([t["sum_seq_records"] for t in tms])) / its         # records per launch (average over the fit)
+        rows = float(np.mean([t["sum_seq_rows"] for t in tms])) / its
+        sparse_bytes = recs * 32 + (recs - rows) * 8 + K * 8
         dense_equiv_bytes = 12 * N * K                                             # I + lam read + lam write, fp32 dense
         achieved = sparse_bytes / (seq_ms * 1e-3) / 1e9
+        # HBM traffic of the same kernel from rocprofv3 PMC passes (profiles/r01_pmc_*; FETCH_SIZE doubled as the gfx950 guide
+        # prescribes): measured for cfg3 only
+        traffic = {"cfg3": int((2 * 45.21 + 13.32) * 1024)}.get(a.workload)
         phase = {k: float(np.mean([t[k] for t in tms])) for k in
                  ("total_ms", "iters_ms", "fn_scan_ms", "solve_ms", "mc_ms", "mc_wait_ms", "sweep_indep_ms", "sweep_seq_ms", "post_ms")}
         out = {
@@ -159,8 +165,8 @@ def main():
                        "nnz_targeted": int(nnz), "distinct_powers": int(nvals) - 1,
                        "mean_active_set": float(np.mean([t["sum_active"] for t in tms])) / max(its, 1)},
             "roofline": {"bound": "hbm", "kernel": "k_sweep_seq", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "avg_launch_ms": seq_ms, "algorithmic_bytes_per_launch": int(sparse_bytes),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "avg_launch_ms": seq_ms, "algorithmic_bytes_per_launch": int(sparse_bytes), "chain_rows_per_launch": rows,
                          "dense_equiv_bytes_per_launch": int(dense_equiv_bytes),
                          "dense_equiv_achieved": dense_equiv_bytes / (seq_ms * 1e-3) / 1e9,
                          "note": "latency-bound sequential Gauss-Seidel chain (one workgroup); see DESIGN.md"},

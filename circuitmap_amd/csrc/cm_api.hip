@@ -102,7 +102,7 @@ extern "C" int cm_problem_destroy(cm_problem* p) {
   hipStreamSynchronize(p->ctx->stream);
   void* ptrs[] = {p->y, p->ss, p->sum_y, p->vals, p->row_ptr, p->col, p->grp, p->rowcnt, p->col_ptr, p->csc_row, p->csc_pos,
                   p->mask, p->lam, p->mu, p->beta, p->mu_prior, p->beta_prior, p->phi, p->phi_cov, p->phi_prior, p->phi_cov_prior,
-                  p->scal, p->R, p->colany, p->z, p->mcE, p->rs, p->act_idx, p->act_inv, p->n_act, p->orders_all, p->orders_tmp,
+                  p->scal, p->R, p->colany, p->z, p->mcE, p->rs, p->act_idx, p->act_inv, p->n_act, p->orders_all, p->orders_tmp, p->inv_all, p->wtab,
                   p->keys, p->uexp, p->A, p->X, p->Lf, p->Dinv, p->rhs, p->seq_n, p->seq_off, p->chunk_first,
                   p->seq_meta, p->packed};
   for (void* q : ptrs) if (q) hipFree(q);
@@ -149,7 +149,7 @@ extern "C" int cm_problem_create(cm_ctx* ctx, int32_t N, int32_t K, int32_t T, c
       (rc = dmalloc(&p->n_act, 4)) || (rc = dmalloc(&p->A, ld * ld)) || (rc = dmalloc(&p->X, ld * ld)) || (rc = dmalloc(&p->Lf, ld * ld)) ||
       (rc = dmalloc(&p->Dinv, ld * CM_TILE)) || (rc = dmalloc(&p->rhs, 2 * ld)) || (rc = dmalloc(&p->seq_n, N)) ||
       (rc = dmalloc(&p->seq_off, (size_t)N + 1)) || (rc = dmalloc(&p->chunk_first, ((size_t)N + p->nnz) / 512 + 8)) ||
-      (rc = dmalloc(&p->seq_meta, 4)) || (rc = dmalloc((char**)&p->packed, ((size_t)N + p->nnz) * 32)))
+      (rc = dmalloc(&p->seq_meta, 8)) || (rc = dmalloc((char**)&p->packed, ((size_t)N + p->nnz) * 32)))
     return fail(rc);
   if (hipMemsetAsync(p->mcE, 0, (size_t)N * CM_MAX_VALS * sizeof(double), st) != hipSuccess) return fail(CM_ERR_HIP);
   if (hipStreamSynchronize(st) != hipSuccess) { cm_set_error("prologue failed: %s", hipGetErrorString(hipGetLastError())); return fail(CM_ERR_HIP); }
@@ -287,13 +287,16 @@ static int alloc_hist(cm_problem* p, int iters) {
   return CM_OK;
 }
 
-static int record_hist(cm_ctx* ctx, cm_problem* p, int it) {
+static int record_hist(cm_ctx* ctx, cm_problem* p, int it, int part) {
   hipStream_t st = ctx->stream;
   const size_t N = p->N, K = p->K, nnz = p->nnz;
   const hipMemcpyKind k = hipMemcpyDeviceToDevice;
-  CM_HIP(hipMemcpyAsync(p->h_mu + it * N, p->mu, N * 8, k, st));
-  CM_HIP(hipMemcpyAsync(p->h_beta + it * N, p->beta, N * 8, k, st));
-  if (nnz) CM_HIP(hipMemcpyAsync(p->h_lam + it * nnz, p->lam, nnz * 8, k, st));
+  if (part == 0) {     // before the fused mid-iteration kernel overwrites mu / beta with the next iteration's solve
+    CM_HIP(hipMemcpyAsync(p->h_mu + it * N, p->mu, N * 8, k, st));
+    CM_HIP(hipMemcpyAsync(p->h_beta + it * N, p->beta, N * 8, k, st));
+    if (nnz) CM_HIP(hipMemcpyAsync(p->h_lam + it * nnz, p->lam, nnz * 8, k, st));
+    return CM_OK;
+  }
   CM_HIP(hipMemcpyAsync(p->h_shape + it, p->scal + CM_S_SHAPE, 8, k, st));
   CM_HIP(hipMemcpyAsync(p->h_rate + it, p->scal + CM_S_RATE, 8, k, st));
   CM_HIP(hipMemcpyAsync(p->h_phi + it * 2 * N, p->phi, 2 * N * 8, k, st));
@@ -319,10 +322,18 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
   if (p->orders_cap < iters) {
     if (p->orders_all) hipFree(p->orders_all);
     if (p->orders_tmp) hipFree(p->orders_tmp);
-    p->orders_all = p->orders_tmp = nullptr;
+    if (p->inv_all) hipFree(p->inv_all);
+    p->orders_all = p->orders_tmp = p->inv_all = nullptr;
     CM_TRY(dmalloc(&p->orders_all, (size_t)iters * N));
     CM_TRY(dmalloc(&p->orders_tmp, (size_t)iters * N));
+    CM_TRY(dmalloc(&p->inv_all, (size_t)iters * N));
     p->orders_cap = iters;
+  }
+  if (p->wtab_cap < (size_t)iters * N * S * 2) {
+    if (p->wtab) hipFree(p->wtab);
+    p->wtab = nullptr;
+    CM_TRY(dmalloc(&p->wtab, (size_t)iters * N * S * 2));
+    p->wtab_cap = (size_t)iters * N * S * 2;
   }
   if (o->rng_mode == CM_RNG_EXPLICIT) {
     if (p->uexp) { hipFree(p->uexp); p->uexp = nullptr; }
@@ -333,8 +344,7 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
   CM_TRY(upload_priors(ctx, p, pr));
   CM_TRY(cm_launch_init_state(ctx, p, o->y_xcorr_thresh));
   CM_HIP(hipMemsetAsync(p->n_act, 0, 4 * sizeof(int), st));
-  CM_TRY(cm_launch_stats(ctx, p, o->spont_orthogonality));   // row sums + active set of lam0 for the first solve
-  CM_TRY(cm_launch_post_single(ctx, p, -1, o, 0));
+  CM_HIP(hipMemsetAsync(p->seq_meta, 0, 8 * sizeof(int), st));
   std::vector<uint32_t> keys;
   if (o->rng_mode == CM_RNG_THREEFRY && iters > 0) {
     cm_host_key_schedule(o->seed, iters, N, keys);      // overlaps with the init kernels above
@@ -347,54 +357,51 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
     CM_HIP(hipMemcpyAsync(p->keys, keys.data(), keys.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     CM_TRY(cm_launch_rng(ctx, p, 0, iters));           // :196 update orders of every iteration (data independent)
   }
+  CM_TRY(cm_launch_ndtri_table(ctx, p, iters, S, o->rng_mode));   // ndtri(u) of every draw of the run (data independent)
   if (o->save_histories && iters > 0) CM_TRY(alloc_hist(p, iters)); else free_hist(p);
 
   const bool timed = tm != nullptr;              // stamps around k_sweep_seq (events 3, 4)
-  const bool phases = timed && o->verbose >= 1;  // all phase stamps (adds ~6 host API calls per iteration)
+  const bool phases = timed && o->verbose >= 1;  // all phase stamps (adds host API calls per iteration)
   while (ctx->pool.size() < (size_t)(iters + 1) * CM_EV_PER_IT) { hipEvent_t e; CM_HIP(hipEventCreate(&e)); ctx->pool.push_back(e); }
-  // Two streams.  Main: solve -> sweep -> row/col stats -> sigma, z.  Side: update_phi(it) -> MC logit(it + 1); neither is
-  // needed by the next solve, so they overlap with it.  Per-iteration events: [0..5] phase stamps on the main stream,
-  // [6] lam(it) final (main -> side), [7] MC logit(it) ready (side -> main), [8] side-stream start stamp.
-  hipStream_t sb = ctx->side;
   auto EV = [&](int it, int j) { return ctx->pool[(size_t)it * CM_EV_PER_IT + j]; };
+  auto post_wait_fallback = [&]() -> int {       // CAVIAR_HIP_NO_MAILBOX=1: classic copy + event instead of the mapped mailbox
+    if (!ctx->use_mailbox) {
+      CM_HIP(hipMemcpyAsync(ctx->h_pinned, p->n_act, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+      CM_HIP(hipEventRecord(ctx->ev[7], st));
+    }
+    return CM_OK;
+  };
   CM_HIP(hipEventRecord(ctx->ev[1], st));
-  if (iters > 0) {
-    CM_HIP(hipStreamWaitEvent(sb, ctx->ev[1], 0));                   // priors, keys and orders are in place
-    CM_TRY(cm_launch_mc_logit(ctx, p, 0, S, o->rng_mode, sb));       // :209-215 for iteration 0 (phi = prior)
-    CM_HIP(hipEventRecord(EV(0, 7), sb));
+  CM_TRY(cm_launch_stats(ctx, p, o->spont_orthogonality));           // row sums of lam0
+  if (iters > 0) {                                                   // active set + block_update_mu + MC logit of iteration 0
+    CM_TRY(cm_launch_iter_mid(ctx, p, -1, iters, S, o->rng_mode, o, 0, 0));
+    CM_TRY(post_wait_fallback());
   }
   int last_active = 0;
   long long sum_active = 0;
   for (int it = 0; it < iters; ++it) {                               // caviar.py:79
     p->order = p->orders_all + (size_t)it * N;
     if (phases) CM_HIP(hipEventRecord(EV(it, 0), st));
-    CM_TRY(cm_solve_mu(ctx, p, &last_active));                       // :80  block_update_mu
+    CM_TRY(cm_wait_active(ctx, p));                                  // the one host wait of an iteration: size of the active set
+    last_active = ctx->h_pinned[0];
     sum_active += last_active;
     if (ctx->h_pinned[1]) { cm_set_error("iteration %d: weight precision matrix not positive definite", it); return CM_ERR_NOT_SPD; }
+    if (last_active > p->small_cap) CM_TRY(cm_solve_launch(ctx, p, last_active));   // :80 block_update_mu, large active set
     if (phases) CM_HIP(hipEventRecord(EV(it, 1), st));
-    CM_HIP(hipStreamWaitEvent(st, EV(it, 7), 0));                    // MC logit of this iteration (and phi(it - 1)) done
-    if (phases) CM_HIP(hipEventRecord(EV(it, 2), st));
-    CM_TRY(cm_launch_sweep(ctx, p, it, o, timed ? EV(it, 3) : nullptr)); // :81  update_lam
+    CM_TRY(cm_launch_sweep(ctx, p, it, o, timed ? EV(it, 3) : nullptr));  // :81  update_lam
     if (timed) CM_HIP(hipEventRecord(EV(it, 4), st));
     CM_TRY(cm_launch_stats(ctx, p, o->spont_orthogonality));         // row + column statistics of the new lam
-    CM_HIP(hipEventRecord(EV(it, 6), st));
-    CM_HIP(hipStreamWaitEvent(sb, EV(it, 6), 0));
-    if (phases) CM_HIP(hipEventRecord(EV(it, 8), sb));
-    CM_TRY(cm_launch_update_phi(ctx, p, sb));                        // :85  update_phi            (side stream)
-    if (it + 1 < iters) CM_TRY(cm_launch_mc_logit(ctx, p, it + 1, S, o->rng_mode, sb));   // next iteration's MC logit
-    CM_HIP(hipEventRecord(EV(it + 1, 7), sb));
-    CM_TRY(cm_launch_post_single(ctx, p, it, o, 1));                 // next active set (posted to the host), :84,86-88 sigma, z, spont_rate
-    if (o->save_histories) {                                         // :90-92
-      CM_HIP(hipStreamWaitEvent(st, EV(it + 1, 7), 0));
-      CM_TRY(record_hist(ctx, p, it));
-    }
+    if (o->save_histories) CM_TRY(record_hist(ctx, p, it, 0));       // mu, beta, lam of this iteration (:90-92)
+    // :84-88 update_sigma, update_phi, z, spont_rate; then block_update_mu (small sets) and the MC logit of iteration it + 1
+    CM_TRY(cm_launch_iter_mid(ctx, p, it, iters, S, o->rng_mode, o, 1, 1));
+    CM_TRY(post_wait_fallback());
+    if (o->save_histories) CM_TRY(record_hist(ctx, p, it, 1));       // shape, rate, phi, phi_cov, z
     if (phases) CM_HIP(hipEventRecord(EV(it, 5), st));
     if (o->verbose >= 2) {
       CM_HIP(hipStreamSynchronize(st));
       fprintf(stderr, "[caviar_hip] it %d active %d\n", it, last_active);
     }
   }
-  if (iters > 0) CM_HIP(hipStreamWaitEvent(st, EV(iters, 7), 0));   // last update_phi
   CM_HIP(hipEventRecord(ctx->ev[2], st));
 
   if (o->fn_scan) {                                                  // caviar.py:94-98
@@ -427,15 +434,16 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
     memset(tm, 0, sizeof(*tm));
     tm->total_ms = a; tm->iters_ms = b; tm->fn_scan_ms = c; tm->iters = iters; tm->last_active = last_active;
     tm->sum_active = sum_active;
+    int meta[8] = {0};
+    if (hipMemcpy(meta, p->seq_meta, sizeof(meta), hipMemcpyDeviceToHost) == hipSuccess) { tm->sum_seq_rows = meta[4]; tm->sum_seq_records = meta[5]; }
     for (int it = 0; it < iters; ++it) {
-      float d[5] = {0, 0, 0, 0, 0}, sd = 0;
-      hipEventElapsedTime(&d[3], EV(it, 3), EV(it, 4));
-      tm->sweep_seq_ms += d[3];
+      float d = 0;
+      hipEventElapsedTime(&d, EV(it, 3), EV(it, 4));
+      tm->sweep_seq_ms += d;
       if (!phases) continue;
-      for (int j = 0; j < 5; ++j) if (j != 3) hipEventElapsedTime(&d[j], EV(it, j), EV(it, j + 1));
-      hipEventElapsedTime(&sd, EV(it, 8), EV(it + 1, 7));
-      tm->solve_ms += d[0]; tm->sweep_indep_ms += d[2]; tm->post_ms += d[4];
-      tm->mc_wait_ms += d[1]; tm->mc_ms += sd;
+      hipEventElapsedTime(&d, EV(it, 0), EV(it, 1)); tm->solve_ms += d;        // host wait + large-set solve (small sets are fused)
+      hipEventElapsedTime(&d, EV(it, 1), EV(it, 3)); tm->sweep_indep_ms += d;  // pre-sweep + pack
+      hipEventElapsedTime(&d, EV(it, 4), EV(it, 5)); tm->post_ms += d;         // stats + fused mid-iteration kernel
     }
   }
   p->ran = true;

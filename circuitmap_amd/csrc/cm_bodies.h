@@ -1,0 +1,407 @@
+// Device bodies shared by the stand-alone kernels and the fused mid-iteration kernel (cm_iter.hip).
+#pragma once
+#include "cm_internal.h"
+
+// block-wide sum (1024 threads), result valid in every thread
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+  v = cm_wave_sum(v);
+  __syncthreads();
+  if (threadIdx.x % CM_WAVE == 0) sh[threadIdx.x / CM_WAVE] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int w = 0; w < (int)(blockDim.x / CM_WAVE); ++w) t += sh[w];
+  return t;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Everything of an iteration that is a single-workgroup reduction (1024 threads):
+//   1. ordered compaction of the active rows (lam row != 0) for the next block_update_mu, and the size of that set
+//      posted straight into host-mapped pinned memory (mailbox) so the host can size the next solve while 2-3 still run;
+//   2. update_sigma: rate = rate0 + 1/2 ( sum_k (y_k - R_k)^2 - sum_n mu_n^2 sum_k lam_nk^2 + sum_n (mu_n^2 + beta_n^2) sum_k lam_nk )
+//   3. z: <= (max_iters - it) penalty steps pen_j = penalty * scale^j while err > tol (the loop counter is seeded with
+//      the OUTER iteration index and err with sum(y), caviar.py:86; quirk 4: nothing happens once it >= max_iters),
+//      then spont_rate = mean(z != 0) (caviar.py:88).
+// Returns the size of the active set (same value in every thread).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int post_single_body(const double* __restrict__ y, const double* __restrict__ R,
+                                                 const uint8_t* __restrict__ colany, const uint8_t* __restrict__ mask,
+                                                 const double* __restrict__ mu, const double* __restrict__ beta,
+                                                 const double* __restrict__ rs, const double* __restrict__ sum_y, int N, int K,
+                                                 int it, int max_iters, double penalty, double scale_factor, double tol,
+                                                 int do_sigma, int seq, int* __restrict__ act_idx, int* __restrict__ act_inv,
+                                                 int* __restrict__ n_act, int* mailbox, double* __restrict__ z,
+                                                 double* __restrict__ scal) {
+  __shared__ double sh[16];
+  __shared__ int wave_cnt[16];
+  __shared__ int base;
+  // ---- 1. active set
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  {
+    const int lane = threadIdx.x % CM_WAVE, w = threadIdx.x / CM_WAVE;
+    const int nthr = blockDim.x, nwv = blockDim.x / CM_WAVE;
+    for (int n0 = 0; n0 < N; n0 += nthr) {
+      const int n = n0 + threadIdx.x;
+      const bool a = n < N && rs[(size_t)n * 4 + 3] >= 0.0;
+      const unsigned long long m = __ballot(a);
+      if (lane == 0) wave_cnt[w] = __popcll(m);
+      __syncthreads();
+      int off = base;
+      for (int i = 0; i < w; ++i) off += wave_cnt[i];
+      if (n < N) {
+        if (a) {
+          const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+          act_idx[pos] = n;
+          act_inv[n] = pos;
+        } else {
+          act_inv[n] = -1;
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) { int t = 0; for (int i = 0; i < nwv; ++i) t += wave_cnt[i]; base += t; }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      n_act[0] = base;
+      if (mailbox) {                                  // host-mapped pinned memory; system-scope release on the sequence word
+        mailbox[0] = base;
+        mailbox[1] = n_act[1];
+        __hip_atomic_store(&mailbox[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
+  __syncthreads();
+  const int n_active = base;
+  if (!do_sigma) return n_active;
+  // ---- 2. update_sigma
+  double a = 0.0;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) { const double r = y[k] - R[k]; a = fma(r, r, a); }
+  double b = 0.0, c = 0.0;
+  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    const double m = mu[n], be = beta[n];
+    b = fma(m * m, rs[(size_t)n * 4 + 1], b);
+    c = fma(m * m + be * be, rs[(size_t)n * 4 + 0], c);
+  }
+  a = block_sum(a, sh); b = block_sum(b, sh); c = block_sum(c, sh);
+  if (threadIdx.x == 0) {
+    scal[CM_S_SHAPE] = scal[CM_S_SHAPE_PRIOR] + (double)K / 2.0;
+    scal[CM_S_RATE] = scal[CM_S_RATE_PRIOR] + 0.5 * (a - b + c);
+  }
+  // ---- 3. estimate_spont_act_soft_thresh
+  double err = sum_y[0];
+  const double ysq = sum_y[1] + 1e-5;
+  double pen = penalty;
+  int itc = it;
+  while (itc < max_iters && err > tol) {
+    double e = 0.0;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+      const double resid = y[k] - R[k];
+      double zz = resid < pen ? 0.0 : resid - pen;
+      zz = zz < 0.0 ? 0.0 : zz;
+      zz = colany[k] ? 0.0 : zz;
+      zz *= (double)mask[k];
+      z[k] = zz;
+      const double d = resid - zz;
+      e = fma(d, d, e);
+    }
+    err = block_sum(e, sh) / ysq;
+    ++itc;
+    pen *= scale_factor;
+  }
+  __syncthreads();
+  double cnt = 0.0;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) cnt += (z[k] != 0.0) ? 1.0 : 0.0;
+  cnt = block_sum(cnt, sh);
+  if (threadIdx.x == 0) scal[CM_S_SPONT_RATE] = cnt / (double)K;
+  return n_active;
+}
+
+// ------------------------------------------------------------------------------------------------
+// update_phi (caviar.py:246-316).  The K-sums of the Newton iteration collapse onto per-stimulus-value sufficient
+// statistics because I[n,:] takes <= V distinct values.  nan_to_num is applied per ELEMENT in the reference objective
+// (quirk 11) so elements are classed by y == 0, y == 1, 0 < y < 1.
+// ------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ void inv2x2(double h11, double h12, double h21, double h22, double o[4]) {
+  // LU with partial pivoting on the 2x2 (what LAPACK getrf/getri do for jnp.linalg.inv)
+  double a = h11, b = h12, c = h21, d = h22;
+  bool sw = fabs(c) > fabs(a);
+  if (sw) { double t = a; a = c; c = t; t = b; b = d; d = t; }
+  const double l = c / a;
+  const double u22 = d - l * b;
+  // solve for unit vectors (with row swap applied to the right-hand side)
+  // column 0 of inverse: rhs = P e0
+  double r0 = sw ? 0.0 : 1.0, r1 = sw ? 1.0 : 0.0;
+  double y1 = r1 - l * r0;
+  double x1 = y1 / u22;
+  double x0 = (r0 - b * x1) / a;
+  o[0] = x0; o[2] = x1;
+  r0 = sw ? 1.0 : 0.0; r1 = sw ? 0.0 : 1.0;
+  y1 = r1 - l * r0;
+  x1 = y1 / u22;
+  x0 = (r0 - b * x1) / a;
+  o[1] = x0; o[3] = x1;
+}
+
+template <int SEG>
+__device__ __forceinline__ double phi_nll(double p0, double p1, double val, double n0, double n1, double smid, double nmid,
+                                          bool lane_on, double pr0, double pr1, const double prec[4], double t) {
+  double tot = 0.0;
+  if (lane_on) {
+    const double s = cm_sigmoid(p0 * val - p1);
+    const double ls = log(s), l1s = log(1.0 - s);
+    if (n0 > 0.0) tot += n0 * cm_nan_to_num(0.0 * ls + 1.0 * l1s);
+    if (n1 > 0.0) tot += n1 * cm_nan_to_num(1.0 * ls + 0.0 * l1s);
+    if (nmid > 0.0) {
+      if (isfinite(ls) && isfinite(l1s)) tot += smid * ls + (nmid - smid) * l1s;
+      else tot += nmid * cm_nan_to_num(0.5 * ls + 0.5 * l1s);
+    }
+  }
+  tot = cm_seg_sum<SEG>(tot);
+  const double d0 = p0 - pr0, d1 = p1 - pr1;
+  const double quad = d0 * (prec[0] * d0 + prec[1] * d1) + d1 * (prec[2] * d0 + prec[3] * d1);
+  return -tot - (log(p0) + log(p1)) / t + 0.5 * quad;
+}
+
+// One wavefront per neuron.  SEG = lanes per evaluation point (power of two >= V; lane g of a segment owns stimulus
+// value g) and E = 64 / SEG evaluation points per wave: in one pass segment 0 evaluates the objective at phi (the
+// right-hand side of the Armijo test) while segments 1..E-1 evaluate it at phi + 2^-b v for consecutive b, so the
+// reference's sequential backtracking (caviar.py:259-268: accept the first b whose test passes, at most 40 halvings)
+// collapses into one parallel evaluation per Newton step in the common case.
+template <int SEG>
+__device__ __forceinline__ void phi_body(int n, int lane, const double* __restrict__ lam, const int* __restrict__ row_ptr,
+                                         const uint8_t* __restrict__ grp, const int* __restrict__ rowcnt,
+                                         const double* __restrict__ vals, int V,
+                                         const double* __restrict__ phi_prior, const double* __restrict__ phi_cov_prior,
+                                         double* __restrict__ phi, double* __restrict__ phi_cov, double out[4]) {
+  constexpr int E = CM_WAVE / SEG;
+  const int g = lane % SEG, ev = lane / SEG;
+  // sufficient statistics of value g: segment `ev` scans entries ev, ev + E, ...; partial sums are then combined
+  // across the segments (lanes at stride SEG)
+  const bool on = g < V;
+  const double val = on ? vals[g] : 0.0;
+  const double cnt = on ? (double)rowcnt[(size_t)n * CM_MAX_VALS + g] : 0.0;
+  double n1 = 0.0, nmid = 0.0, smid = 0.0;
+  if (on && val > 0.0) {                       // untargeted values carry lam == 0 on every trial
+    for (int e = row_ptr[n] + ev; e < row_ptr[n + 1]; e += E) {
+      if (grp[e] != g) continue;
+      const double l = lam[e];
+      if (l == 1.0) n1 += 1.0;
+      else if (l > 0.0 && l < 1.0) { nmid += 1.0; smid += l; }
+    }
+  }
+#pragma unroll
+  for (int o = SEG; o < CM_WAVE; o <<= 1) {
+    n1 += __shfl_xor(n1, o, CM_WAVE); nmid += __shfl_xor(nmid, o, CM_WAVE); smid += __shfl_xor(smid, o, CM_WAVE);
+  }
+  const double n0 = cnt - n1 - nmid;
+  const double sy = n1 + smid;
+
+  const double pr0 = phi_prior[2 * n], pr1 = phi_prior[2 * n + 1];
+  double prec[4];
+  inv2x2(phi_cov_prior[4 * n], phi_cov_prior[4 * n + 1], phi_cov_prior[4 * n + 2], phi_cov_prior[4 * n + 3], prec);   // caviar.py:306
+  const double t = 1e1, alpha = 0.25;
+  double p0 = pr0, p1 = pr1;                     // caviar.py:305: restart from the prior every call (quirk 3)
+  double cov[4] = {0, 0, 0, 0};
+  for (int stepi = 0; stepi < 10; ++stepi) {     // caviar.py:308
+    double j1 = 0.0, j2 = 0.0, h11 = 0.0, h12 = 0.0, h22 = 0.0;
+    if (on) {
+      const double f = cm_sigmoid(p0 * val - p1);
+      const double r = sy - cnt * f;
+      j1 = -val * r; j2 = r;
+      const double ff = cnt * f * (1.0 - f);
+      h11 = val * val * ff; h12 = -val * ff; h22 = ff;
+    }
+    j1 = cm_seg_sum<SEG>(j1); j2 = cm_seg_sum<SEG>(j2);
+    h11 = cm_seg_sum<SEG>(h11); h12 = cm_seg_sum<SEG>(h12); h22 = cm_seg_sum<SEG>(h22);
+    const double d0 = p0 - pr0, d1 = p1 - pr1;
+    const double J0 = j1 + (prec[0] * d0 + prec[1] * d1) - 1.0 / (t * p0);      // caviar.py:278-280
+    const double J1 = j2 + (prec[2] * d0 + prec[3] * d1) - 1.0 / (t * p1);
+    inv2x2(h11 + prec[0] + 1.0 / (t * p0 * p0), h12 + prec[1], h12 + prec[2], h22 + prec[3] + 1.0 / (t * p1 * p1), cov);   // :283-289
+    const double v0 = -(cov[0] * J0 + cov[1] * J1), v1 = -(cov[2] * J0 + cov[3] * J1);
+    const double Jv = J0 * v0 + J1 * v1;
+    // candidates b = 0..40 (step 2^-b); b <= 39 needs its Armijo test to pass, b = 40 is taken unconditionally
+    int accepted = -1;
+    double f0 = 0.0;
+    int base = 0;                                 // first candidate of this round
+    bool first = true;
+    while (accepted < 0 && base < 40) {
+      const int b = first ? base + ev - 1 : base + ev;       // first round: segment 0 evaluates phi itself
+      const bool is_f0 = first && ev == 0;
+      const double st = is_f0 ? 0.0 : ldexp(1.0, -b);
+      const double q0 = is_f0 ? p0 : p0 + st * v0, q1 = is_f0 ? p1 : p1 + st * v1;
+      const double fv = phi_nll<SEG>(q0, q1, val, n0, n1, smid, nmid, on, pr0, pr1, prec, t);
+      if (first) f0 = cm_readlane_f64(fv, 0);
+      const double rhs = f0 + alpha * st * Jv;
+      const bool ok = !is_f0 && b <= 39 && !(isnan(fv) || fv > rhs);
+      const unsigned long long m = __ballot(ok);
+      if (m) accepted = (first ? base - 1 : base) + (int)(__ffsll((long long)m) - 1) / SEG;
+      base += first ? E - 1 : E;
+      first = false;
+    }
+    if (accepted < 0) accepted = 40;
+    const double step = ldexp(1.0, -accepted);
+    p0 += step * v0; p1 += step * v1;                                             // caviar.py:301
+  }
+  if (lane == 0) {
+    phi[2 * n] = p0; phi[2 * n + 1] = p1;
+    phi_cov[4 * n] = cov[0]; phi_cov[4 * n + 1] = cov[1]; phi_cov[4 * n + 2] = cov[2]; phi_cov[4 * n + 3] = cov[3];
+  }
+  out[0] = p0; out[1] = p1; out[2] = cov[0]; out[3] = cov[3];     // mean and variance diagonal, for the MC logit that follows
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Small active sets (the steady state of a fit): the whole block_update_mu (caviar.py:166-172) in ONE workgroup, in LDS.
+//   1. stage the active rows' (trial, lam) lists;  2. A_ab = sigma * sum_k lam_ak lam_bk by merge-intersection of the two
+//   sorted trial lists (ascending trial order -> deterministic);  3. A^-1 in place by the sweep operator (n pivots, two
+//   barriers each; pivots of an SPD matrix are positive, no pivoting needed);  4. mu = A^-1 rhs, beta = diag(A^-1).
+// n == 0 only fills the priors.
+// ------------------------------------------------------------------------------------------------
+#define CM_SMALL_MAX 128
+__device__ __forceinline__ void solve_small_body(double* sm, const double* __restrict__ lam, const int* __restrict__ row_ptr,
+                                                 const int* __restrict__ col, const int* __restrict__ act_idx,
+                                                 const double* __restrict__ rs, const double* __restrict__ scal,
+                                                 const double* __restrict__ mu_prior, const double* __restrict__ beta_prior,
+                                                 int n, int N, int tot_cap, double* __restrict__ mu, double* __restrict__ beta,
+                                                 int* __restrict__ flag) {
+  const int ldA = n + 1;
+  double* A = sm;                              // [n][n+1]
+  double* rowk = A + (size_t)n * ldA;          // [CM_SMALL_MAX]
+  double* colk = rowk + CM_SMALL_MAX;
+  double* rhs = colk + CM_SMALL_MAX;
+  double* lams = rhs + CM_SMALL_MAX;           // [tot_cap]
+  int* cols = (int*)(lams + tot_cap);          // [tot_cap]
+  int* rp = cols + tot_cap;                    // [CM_SMALL_MAX + 1]
+  int* nidx = rp + CM_SMALL_MAX + 1;           // [CM_SMALL_MAX]
+  __shared__ int bad;
+  const int tid = threadIdx.x;
+  // inactive rows: mu = mu0, beta = beta0^2 exactly (their rows of the precision matrix are diagonal)
+  for (int i = tid; i < N; i += blockDim.x) { mu[i] = mu_prior[i]; const double b0 = beta_prior[i]; beta[i] = b0 * b0; }
+  if (tid == 0) bad = 0;
+  // ---- 1. stage
+  if (tid < n) { const int nn = act_idx[tid]; nidx[tid] = nn; rp[tid + 1] = row_ptr[nn + 1] - row_ptr[nn]; }
+  if (tid == 0) rp[0] = 0;
+  __syncthreads();
+  for (int o = 1; o < n; o <<= 1) {            // inclusive scan of the row lengths
+    int v = 0;
+    if (tid < n && tid >= o) v = rp[tid + 1 - o];
+    __syncthreads();
+    if (tid < n && tid >= o) rp[tid + 1] += v;
+    __syncthreads();
+  }
+  const int wave = tid / CM_WAVE, lane = tid % CM_WAVE, nw = blockDim.x / CM_WAVE;
+  for (int a = wave; a < n; a += nw) {
+    const int g0 = row_ptr[nidx[a]], len = rp[a + 1] - rp[a], o0 = rp[a];
+    for (int e = lane; e < len; e += CM_WAVE) { cols[o0 + e] = col[g0 + e]; lams[o0 + e] = lam[g0 + e]; }
+  }
+  __syncthreads();
+  // ---- 2. build (lower triangle pairs, mirrored)
+  const double sig = scal[CM_S_SHAPE] / scal[CM_S_RATE];
+  const int npairs = n * (n + 1) / 2;
+  for (int q = tid; q < npairs; q += blockDim.x) {
+    int a = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
+    while ((a + 1) * (a + 2) / 2 <= q) ++a;
+    while (a * (a + 1) / 2 > q) --a;
+    const int b = q - a * (a + 1) / 2;
+    int ia = rp[a], ib = rp[b];
+    const int ea = rp[a + 1], eb = rp[b + 1];
+    double acc = 0.0;
+    while (ia < ea && ib < eb) {
+      const int ka = cols[ia], kb = cols[ib];
+      if (ka == kb) { acc = fma(lams[ia], lams[ib], acc); ++ia; ++ib; }
+      else if (ka < kb) ++ia; else ++ib;
+    }
+    double v = sig * acc;
+    if (a == b) {
+      const int nn = nidx[a];
+      const double b0 = beta_prior[nn], prec0 = 1.0 / (b0 * b0);
+      v = sig * (rs[(size_t)nn * 4 + 3] + acc) + prec0;
+      rhs[a] = sig * rs[(size_t)nn * 4 + 2] + prec0 * mu_prior[nn];
+    }
+    A[a * ldA + b] = v;
+    A[b * ldA + a] = v;
+  }
+  // ---- 3. sweep-operator inverse
+  for (int k = 0; k < n; ++k) {
+    __syncthreads();
+    const double d = A[k * ldA + k];
+    const double inv = 1.0 / d;
+    if (tid == 0 && !(d > 0.0)) bad = 1;
+    if (tid < n) { rowk[tid] = A[k * ldA + tid] * inv; colk[tid] = A[tid * ldA + k]; }
+    __syncthreads();
+    for (int idx = tid; idx < n * n; idx += blockDim.x) {
+      const int i = idx / n, j = idx % n;
+      double v;
+      if (i == k) v = (j == k) ? inv : rowk[j];
+      else if (j == k) v = -colk[i] * inv;
+      else v = fma(-colk[i], rowk[j], A[i * ldA + j]);
+      A[i * ldA + j] = v;
+    }
+  }
+  __syncthreads();
+  // ---- 4. mu = A^-1 rhs (one wave per row), beta = diag(A^-1)
+  for (int a = wave; a < n; a += nw) {
+    double sacc = 0.0;
+    for (int b = lane; b < n; b += CM_WAVE) sacc = fma(A[a * ldA + b], rhs[b], sacc);
+    sacc = cm_wave_sum(sacc);
+    if (lane == 0) { mu[nidx[a]] = sacc; beta[nidx[a]] = A[a * ldA + a]; }
+  }
+  if (tid == 0 && bad) *flag = 1;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Monte-Carlo logit pieces shared by cm_sweep.hip (table kernel) and cm_iter.hip (fused kernel)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double cm_uniform64(uint32_t k0, uint32_t k1, int j, int S) {
+  uint32_t x0 = (uint32_t)j, x1 = (uint32_t)(2 * S + j);   // 64-bit draw j: hi = word j, lo = word 2S + j
+  cm_threefry2x32(k0, k1, x0, x1);
+  const unsigned long long bits = ((unsigned long long)x0 << 32) | (unsigned long long)x1;
+  return __longlong_as_double((long long)((bits >> 12) | 0x3FF0000000000000ull)) - 1.0;
+}
+
+
+// rare path of the steady-state kernel, kept out of line so that its registers do not burden the common path
+__device__ __noinline__ double cm_quantile_slow(double arg) { return normcdfinv(arg); }
+
+// one wavefront; mc is the wave's LDS scratch [2*S]; (mean0, mean1, sd0, sd1) = phi[n], diag(phi_cov[n]).
+// arg = c + u (1 - c) equals u bit for bit whenever c is below half an ulp of u (c = ndtr(-mean/sdev) is 0 or ~1e-30 once
+// phi comes from the Laplace step), and then ndtri(arg) is the tabulated ndtri(u).  FULL = true inlines the quantile
+// function (iteration 0, where phi is the prior and c is not small); FULL = false calls it out of line on a miss.
+template <bool FULL>
+__device__ __forceinline__ void mc_logit_body(int n, int m, int lane, double mean0, double mean1, double sd0, double sd1,
+                                              const uint32_t* __restrict__ keys, const double* __restrict__ uexp,
+                                              const double* __restrict__ wrow, const double* __restrict__ vals, int V, int S,
+                                              double* mc, double* __restrict__ mcE) {
+  const double c0 = normcdf(-mean0 / sd0), c1 = normcdf(-mean1 / sd1);
+  uint32_t k0 = 0, k1 = 0;
+  if (!uexp) { k0 = keys[2 * (3 + m)]; k1 = keys[2 * (3 + m) + 1]; }
+  for (int j = lane; j < 2 * S; j += CM_WAVE) {
+    const bool second = j & 1;
+    const double c = second ? c1 : c0, sd = second ? sd1 : sd0, mean = second ? mean1 : mean0;
+    const double u = uexp ? uexp[j] : cm_uniform64(k0, k1, j, S);
+    const double arg = c + u * (1.0 - c);                      // caviar.py:212
+    double q;
+    if (FULL) q = normcdfinv(arg);
+    else q = (arg == u) ? wrow[j] : cm_quantile_slow(arg);
+    mc[j] = q * sd + mean;
+  }
+  // same-wave LDS write -> read: the LDS pipe is in order for one wave
+  for (int g = 0; g < V; ++g) {
+    const double v = vals[g];
+    if (!(v > 0.0)) continue;
+    double acc = 0.0;
+    for (int s = lane; s < S; s += CM_WAVE) {
+      const double f = cm_sigmoid(mc[2 * s] * v - mc[2 * s + 1]);
+      acc += log(f / (1.0 - f));
+    }
+    acc = cm_wave_sum(acc);
+    if (lane == 0) mcE[(size_t)n * CM_MAX_VALS + g] = acc / (double)S;
+  }
+}
+
+
+static inline size_t small_lds_bytes(int n, int tot_cap) {
+  return ((size_t)n * (n + 1) + 3 * CM_SMALL_MAX + tot_cap) * sizeof(double) + ((size_t)tot_cap + 2 * CM_SMALL_MAX + 1) * sizeof(int);
+}

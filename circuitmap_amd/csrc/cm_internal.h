@@ -50,6 +50,7 @@ struct cm_problem {
   int32_t V = 0;         // number of distinct stimulus values (sorted ascending; powers = vals[1:])
   int32_t ld = 0;        // leading dimension of the solve matrices (multiple of CM_TILE), sized for N
   int32_t max_row_len = 0; // longest CSR row (targeted trials of one neuron)
+  int32_t small_cap = 0;   // largest active set solved inside the fused mid-iteration kernel
   // --- static encoding (built once by cm_problem_create) ---
   double* y = nullptr;        // [K]  trapz(psc)
   double* ss = nullptr;       // [K]  sum psc^2
@@ -89,6 +90,9 @@ struct cm_problem {
   int32_t* order = nullptr;   // sweep order of the current iteration (points into orders_all)
   int32_t* orders_all = nullptr; // [iters*N] sweep orders of every iteration (device generated, or the explicit stream)
   int32_t* orders_tmp = nullptr; // [iters*N] ping-pong buffer of the shuffle rounds
+  int32_t* inv_all = nullptr;    // [iters*N] inverse of every sweep order: position of neuron n in iteration it
+  double* wtab = nullptr;        // [iters*N*2S] ndtri(u) of every uniform of the run (data independent)
+  size_t wtab_cap = 0;
   int32_t orders_cap = 0;     // iterations the two buffers are sized for
   int32_t* seq_n = nullptr;   // [N]   neurons with mu != 0 in sweep order
   int32_t* seq_off = nullptr; // [N+1] record offset of each such row in `packed`
@@ -217,6 +221,10 @@ int cm_launch_scatter_dense_lam(cm_ctx* ctx, cm_problem* p, const double* d_lam_
 int cm_launch_expand_lam(cm_ctx* ctx, cm_problem* p, const double* d_lam_sparse, double* d_dense);
 
 int cm_solve_mu(cm_ctx* ctx, cm_problem* p, int* n_active_out);                      // syncs once (active-set size)
+int cm_solve_launch(cm_ctx* ctx, cm_problem* p, int na);
+int cm_small_cap(const cm_problem* p);
+int cm_launch_iter_mid(cm_ctx* ctx, cm_problem* p, int it, int iters, int S, int rng_mode, const cm_options* o, int do_sigma, int do_phi);
+int cm_launch_ndtri_table(cm_ctx* ctx, cm_problem* p, int iters, int S, int rng_mode);
 int cm_launch_rng(cm_ctx* ctx, cm_problem* p, int it0, int n_it);
 int cm_launch_mc_logit(cm_ctx* ctx, cm_problem* p, int it, int S, int rng_mode, hipStream_t st);
 int cm_launch_sweep(cm_ctx* ctx, cm_problem* p, int it, const cm_options* o, hipEvent_t mid);

@@ -259,6 +259,7 @@ int cm_encode_stim(cm_ctx* ctx, cm_problem* p, const double* d_stim) {
   p->nnz = p->h_row_ptr[N];
   p->max_row_len = 0;
   for (int n = 0; n < N; ++n) p->max_row_len = std::max(p->max_row_len, p->h_row_ptr[n + 1] - p->h_row_ptr[n]);
+  p->small_cap = cm_small_cap(p);
   const size_t nnz_alloc = p->nnz > 0 ? (size_t)p->nnz : 1;
   CM_HIP(hipMalloc(&p->col, nnz_alloc * sizeof(int)));
   CM_HIP(hipMalloc(&p->grp, nnz_alloc));

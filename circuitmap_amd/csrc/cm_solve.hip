@@ -9,7 +9,7 @@
 // blocked Cholesky on 32x32 tiles; L^-1 comes from recursive doubling of triangular blocks (GEMM-shaped),
 // and mu, diag(Sigma) are column reductions of L^-1.  Everything fp64: the early iterations are
 // ill-conditioned enough (SURVEY 8c / tests) that fp32 would not hold the 1e-4 parity target.
-#include "cm_internal.h"
+#include "cm_bodies.h"
 
 #define TS CM_TILE
 #define TP (CM_TILE + 1)   // padded LDS row (doubles)
@@ -304,13 +304,7 @@ __global__ __launch_bounds__(256) void k_fill_prior(const double* __restrict__ m
   if (n < N) { mu[n] = mu_prior[n]; beta[n] = beta_prior[n] * beta_prior[n]; }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Small active sets (the steady state of a fit): the whole block_update_mu in ONE workgroup, everything in LDS.
-//   1. stage the active rows' (trial, lam) lists;  2. A_ab = sigma * sum_k lam_ak lam_bk by merge-intersection of the two
-//   sorted trial lists (ascending trial order -> deterministic);  3. A^-1 in place by the sweep operator (n pivots, two
-//   barriers each; pivots of an SPD matrix are positive, no pivoting needed);  4. mu = A^-1 rhs, beta = diag(A^-1).
-// ------------------------------------------------------------------------------------------------
-#define CM_SMALL_MAX 128
+// stand-alone launch of the small solve (per-phase test hook, and active sets between the fused kernel's cap and 128)
 __global__ __launch_bounds__(1024) void k_solve_small(const double* __restrict__ lam, const int* __restrict__ row_ptr,
                                                        const int* __restrict__ col, const int* __restrict__ act_idx,
                                                        const double* __restrict__ rs, const double* __restrict__ scal,
@@ -318,101 +312,20 @@ __global__ __launch_bounds__(1024) void k_solve_small(const double* __restrict__
                                                        int n, int N, int tot_cap, double* __restrict__ mu, double* __restrict__ beta,
                                                        int* __restrict__ flag) {
   extern __shared__ double sm[];
-  const int ldA = n + 1;
-  double* A = sm;                              // [n][n+1]
-  double* rowk = A + (size_t)n * ldA;          // [CM_SMALL_MAX]
-  double* colk = rowk + CM_SMALL_MAX;
-  double* rhs = colk + CM_SMALL_MAX;
-  double* lams = rhs + CM_SMALL_MAX;           // [tot_cap]
-  int* cols = (int*)(lams + tot_cap);          // [tot_cap]
-  int* rp = cols + tot_cap;                    // [CM_SMALL_MAX + 1]
-  int* nidx = rp + CM_SMALL_MAX + 1;           // [CM_SMALL_MAX]
-  __shared__ int bad;
-  const int tid = threadIdx.x;
-  // inactive rows: mu = mu0, beta = beta0^2 exactly (their rows of the precision matrix are diagonal)
-  for (int i = tid; i < N; i += blockDim.x) { mu[i] = mu_prior[i]; const double b0 = beta_prior[i]; beta[i] = b0 * b0; }
-  if (tid == 0) bad = 0;
-  // ---- 1. stage
-  if (tid < n) { const int nn = act_idx[tid]; nidx[tid] = nn; rp[tid + 1] = row_ptr[nn + 1] - row_ptr[nn]; }
-  if (tid == 0) rp[0] = 0;
-  __syncthreads();
-  for (int o = 1; o < n; o <<= 1) {            // inclusive scan of the row lengths
-    int v = 0;
-    if (tid < n && tid >= o) v = rp[tid + 1 - o];
-    __syncthreads();
-    if (tid < n && tid >= o) rp[tid + 1] += v;
-    __syncthreads();
-  }
-  const int wave = tid / CM_WAVE, lane = tid % CM_WAVE, nw = blockDim.x / CM_WAVE;
-  for (int a = wave; a < n; a += nw) {
-    const int g0 = row_ptr[nidx[a]], len = rp[a + 1] - rp[a], o0 = rp[a];
-    for (int e = lane; e < len; e += CM_WAVE) { cols[o0 + e] = col[g0 + e]; lams[o0 + e] = lam[g0 + e]; }
-  }
-  __syncthreads();
-  // ---- 2. build (lower triangle pairs, mirrored)
-  const double sig = scal[CM_S_SHAPE] / scal[CM_S_RATE];
-  const int npairs = n * (n + 1) / 2;
-  for (int q = tid; q < npairs; q += blockDim.x) {
-    int a = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
-    while ((a + 1) * (a + 2) / 2 <= q) ++a;
-    while (a * (a + 1) / 2 > q) --a;
-    const int b = q - a * (a + 1) / 2;
-    int ia = rp[a], ib = rp[b];
-    const int ea = rp[a + 1], eb = rp[b + 1];
-    double acc = 0.0;
-    while (ia < ea && ib < eb) {
-      const int ka = cols[ia], kb = cols[ib];
-      if (ka == kb) { acc = fma(lams[ia], lams[ib], acc); ++ia; ++ib; }
-      else if (ka < kb) ++ia; else ++ib;
-    }
-    double v = sig * acc;
-    if (a == b) {
-      const int nn = nidx[a];
-      const double b0 = beta_prior[nn], prec0 = 1.0 / (b0 * b0);
-      v = sig * (rs[(size_t)nn * 4 + 3] + acc) + prec0;
-      rhs[a] = sig * rs[(size_t)nn * 4 + 2] + prec0 * mu_prior[nn];
-    }
-    A[a * ldA + b] = v;
-    A[b * ldA + a] = v;
-  }
-  // ---- 3. sweep-operator inverse
-  for (int k = 0; k < n; ++k) {
-    __syncthreads();
-    const double d = A[k * ldA + k];
-    const double inv = 1.0 / d;
-    if (tid == 0 && !(d > 0.0)) bad = 1;
-    if (tid < n) { rowk[tid] = A[k * ldA + tid] * inv; colk[tid] = A[tid * ldA + k]; }
-    __syncthreads();
-    for (int idx = tid; idx < n * n; idx += blockDim.x) {
-      const int i = idx / n, j = idx % n;
-      double v;
-      if (i == k) v = (j == k) ? inv : rowk[j];
-      else if (j == k) v = -colk[i] * inv;
-      else v = fma(-colk[i], rowk[j], A[i * ldA + j]);
-      A[i * ldA + j] = v;
-    }
-  }
-  __syncthreads();
-  // ---- 4. mu = A^-1 rhs (one wave per row), beta = diag(A^-1)
-  for (int a = wave; a < n; a += nw) {
-    double sacc = 0.0;
-    for (int b = lane; b < n; b += CM_WAVE) sacc = fma(A[a * ldA + b], rhs[b], sacc);
-    sacc = cm_wave_sum(sacc);
-    if (lane == 0) { mu[nidx[a]] = sacc; beta[nidx[a]] = A[a * ldA + a]; }
-  }
-  if (tid == 0 && bad) *flag = 1;
-}
-
-static size_t small_lds_bytes(int n, int tot_cap) {
-  return ((size_t)n * (n + 1) + 3 * CM_SMALL_MAX + tot_cap) * sizeof(double) + ((size_t)tot_cap + 2 * CM_SMALL_MAX + 1) * sizeof(int);
+  solve_small_body(sm, lam, row_ptr, col, act_idx, rs, scal, mu_prior, beta_prior, n, N, tot_cap, mu, beta, flag);
 }
 
 // Expects cm_launch_row_stats() to have been enqueued after the last change of lam.
 int cm_solve_mu(cm_ctx* ctx, cm_problem* p, int* n_active_out) {
-  hipStream_t st = ctx->stream;
   CM_TRY(cm_wait_active(ctx, p));                   // the only host wait of an iteration: size of the active set
   const int na = ctx->h_pinned[0];
   if (n_active_out) *n_active_out = na;
+  return cm_solve_launch(ctx, p, na);
+}
+
+// block_update_mu for an active set of known size: small sets in one workgroup, larger ones by the tiled factorisation
+int cm_solve_launch(cm_ctx* ctx, cm_problem* p, int na) {
+  hipStream_t st = ctx->stream;
   if (na > 0 && na <= CM_SMALL_MAX) {
     const int tot_cap = na * p->max_row_len;
     const size_t lds = small_lds_bytes(na, tot_cap);

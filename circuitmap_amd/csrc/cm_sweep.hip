@@ -11,7 +11,7 @@
 //      samples only on phi of the PREVIOUS iteration, so all N x S x P transcendental evaluations run as one
 //      embarrassingly parallel kernel before the sweep; a neuron with mu_n == 0 neither reads nor changes R, so
 //      those rows are swept in parallel and only the mu_n != 0 rows form the sequential chain (one workgroup).
-#include "cm_internal.h"
+#include "cm_bodies.h"
 
 // ------------------------------------------------------------------------------------------------
 // RNG.  Key schedule (host, cm_host_key_schedule): per iteration (3 + N) threefry keys:
@@ -76,7 +76,8 @@ __device__ __forceinline__ uint32_t cm_bits32(uint32_t k0, uint32_t k1, int i, i
 // `in` by fresh 32-bit keys, done as rank-by-counting.  grid = (ceil(N / 64), iters); a block ranks 64 elements, its
 // four waves each scanning a quarter of every 1024-key tile (same-address LDS reads broadcast).
 __global__ __launch_bounds__(256) void k_perm_batch(const uint32_t* __restrict__ keys_all, int key_stride, int round,
-                                                     const int* __restrict__ in_all, int* __restrict__ out_all, int N) {
+                                                     const int* __restrict__ in_all, int* __restrict__ out_all, int* __restrict__ inv_all,
+                                                     int N) {
   __shared__ uint32_t tile[1024];
   __shared__ int part_rank[4][64];
   const int it = blockIdx.y;
@@ -101,54 +102,37 @@ __global__ __launch_bounds__(256) void k_perm_batch(const uint32_t* __restrict__
   __syncthreads();
   if (part == 0 && i < N) {
     const int r = part_rank[0][li] + part_rank[1][li] + part_rank[2][li] + part_rank[3][li];
-    out_all[(size_t)it * N + r] = in_all ? in_all[(size_t)it * N + i] : i;
+    const int v = in_all ? in_all[(size_t)it * N + i] : i;
+    out_all[(size_t)it * N + r] = v;
+    if (inv_all) inv_all[(size_t)it * N + v] = r;          // last round: position of neuron v in the sweep
   }
 }
 
+__global__ __launch_bounds__(256) void k_invert_orders(const int* __restrict__ orders, int* __restrict__ inv, int N, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) { const long long it = i / N; inv[it * N + orders[i]] = (int)(i - it * N); }
+}
+
 // ------------------------------------------------------------------------------------------------
-// Monte-Carlo logit  (caviar.py:209-215, 233-236); one wave per sweep step m (neuron n = order[m])
+// Monte-Carlo logit  (caviar.py:209-215, 233-236)
 //   u ~ U[0,1)^{S x 2}   (threefry 64-bit draws, or host supplied)
 //   mc = ndtri(c + u (1 - c)) * sdev + mean,  c = ndtr(-mean/sdev),  mean = phi[n],  sdev = diag(phi_cov[n])  (a VARIANCE, quirk 2)
 //   mcE[n][g] = mean_s log(f / (1 - f)),  f = sigmoid(mc_s0 * vals[g] - mc_s1)
+// The uniforms do not depend on the data, so w = ndtri(u) is tabulated once per run (k_ndtri_table) for every
+// (iteration, sweep step, sample); when c underflows to exactly 0 -- the normal case, mean/sdev >> 1 -- the sample is
+// w * sdev + mean bit for bit and the quantile function leaves the per-iteration critical path.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_mc_logit(const uint32_t* __restrict__ keys, const double* __restrict__ uexp,
-                                                  const int* __restrict__ order, const double* __restrict__ phi,
-                                                  const double* __restrict__ phi_cov, const double* __restrict__ vals, int V, int S, int N,
-                                                  double* __restrict__ mcE, double* __restrict__ u_out) {
-  extern __shared__ double mc[];   // [2*S]
-  const int m = blockIdx.x, lane = threadIdx.x;
-  const int n = order[m];
-  const double mean0 = phi[2 * n], mean1 = phi[2 * n + 1];
-  const double sd0 = phi_cov[4 * n], sd1 = phi_cov[4 * n + 3];
-  const double c0 = normcdf(-mean0 / sd0), c1 = normcdf(-mean1 / sd1);
+// grid (N, n_it): block (m, it) tabulates ndtri(u) of sweep step m of iteration it0 + it
+__global__ __launch_bounds__(64) void k_ndtri_table(const uint32_t* __restrict__ keys_all, const double* __restrict__ uexp_all, int it0,
+                                                     int N, int S, double* __restrict__ wtab, double* __restrict__ u_out) {
+  const int m = blockIdx.x, it = it0 + blockIdx.y;
+  const size_t base = ((size_t)it * N + m) * 2 * S;
   uint32_t k0 = 0, k1 = 0;
-  if (!uexp) { k0 = keys[2 * (3 + m)]; k1 = keys[2 * (3 + m) + 1]; }
-  for (int j = lane; j < 2 * S; j += CM_WAVE) {
-    double u;
-    if (uexp) {
-      u = uexp[(size_t)m * 2 * S + j];
-    } else {
-      uint32_t x0 = (uint32_t)j, x1 = (uint32_t)(2 * S + j);   // 64-bit draw j: hi = word j, lo = word 2S + j
-      cm_threefry2x32(k0, k1, x0, x1);
-      const unsigned long long bits = ((unsigned long long)x0 << 32) | (unsigned long long)x1;
-      u = __longlong_as_double((long long)((bits >> 12) | 0x3FF0000000000000ull)) - 1.0;
-    }
+  if (!uexp_all) { const uint32_t* keys = keys_all + (size_t)it * (N + 3) * 2; k0 = keys[2 * (3 + m)]; k1 = keys[2 * (3 + m) + 1]; }
+  for (int j = threadIdx.x; j < 2 * S; j += CM_WAVE) {
+    const double u = uexp_all ? uexp_all[base + j] : cm_uniform64(k0, k1, j, S);
+    if (wtab) wtab[base + j] = normcdfinv(u);
     if (u_out) u_out[(size_t)m * 2 * S + j] = u;
-    const bool second = j & 1;
-    const double c = second ? c1 : c0, sd = second ? sd1 : sd0, mean = second ? mean1 : mean0;
-    mc[j] = normcdfinv(c + u * (1.0 - c)) * sd + mean;
-  }
-  __syncthreads();
-  for (int g = 0; g < V; ++g) {
-    const double v = vals[g];
-    if (!(v > 0.0)) continue;
-    double acc = 0.0;
-    for (int s = lane; s < S; s += CM_WAVE) {
-      const double f = cm_sigmoid(mc[2 * s] * v - mc[2 * s + 1]);
-      acc += log(f / (1.0 - f));
-    }
-    acc = cm_wave_sum(acc);
-    if (lane == 0) mcE[(size_t)n * CM_MAX_VALS + g] = acc / (double)S;
   }
 }
 
@@ -395,6 +379,7 @@ __device__ __forceinline__ void seq_scan_body(const int* __restrict__ order, con
     seq_off[nseq] = total;
     chunk_first[nchunks] = nseq;
     meta[0] = nseq; meta[1] = total; meta[2] = nchunks;
+    meta[4] += nseq; meta[5] += total;            // per-run totals (reported in cm_timings)
   }
 }
 
@@ -550,29 +535,29 @@ int cm_launch_rng(cm_ctx* ctx, cm_problem* p, int it0, int n_it) {
   const int* in = nullptr;                        // nullptr = identity (jnp.arange(N))
   for (int r = 0; r < rounds; ++r) {
     int* out = ((rounds - 1 - r) % 2 == 0) ? fin : tmp;    // ping-pong so the last round lands in orders_all
-    hipLaunchKernelGGL(k_perm_batch, dim3((N + 63) / 64, n_it), dim3(256), 0, st, keys, (N + 3) * 2, r, in, out, N);
+    int* inv = (r == rounds - 1) ? p->inv_all + (size_t)it0 * N : (int*)nullptr;
+    hipLaunchKernelGGL(k_perm_batch, dim3((N + 63) / 64, n_it), dim3(256), 0, st, keys, (N + 3) * 2, r, in, out, inv, N);
     in = out;
   }
   CM_HIP(hipGetLastError());
   return CM_OK;
 }
 
-int cm_launch_mc_logit(cm_ctx* ctx, cm_problem* p, int it, int S, int rng_mode, hipStream_t st) {
-  const int N = p->N;
-  const uint32_t* keys = (rng_mode == CM_RNG_EXPLICIT) ? nullptr : p->keys + (size_t)it * (N + 3) * 2;
-  const double* uexp = (rng_mode == CM_RNG_EXPLICIT) ? p->uexp + (size_t)it * N * 2 * S : nullptr;
-  const int* order = p->orders_all + (size_t)it * N;
-  hipLaunchKernelGGL(k_mc_logit, dim3(N), dim3(64), (size_t)2 * S * sizeof(double), st, keys, uexp, order, p->phi,
-                     p->phi_cov, p->vals, p->V, S, N, p->mcE, (double*)nullptr);
+// w = ndtri(u) for every (iteration, sweep step, sample) of the run; explicit streams are tabulated from the uploaded uniforms
+int cm_launch_ndtri_table(cm_ctx* ctx, cm_problem* p, int iters, int S, int rng_mode) {
+  if (iters <= 0) return CM_OK;
+  const double* uexp = (rng_mode == CM_RNG_EXPLICIT) ? p->uexp : nullptr;
+  hipLaunchKernelGGL(k_ndtri_table, dim3(p->N, iters), dim3(64), 0, ctx->stream, p->keys, uexp, 0, p->N, S, p->wtab, (double*)nullptr);
+  if (rng_mode == CM_RNG_EXPLICIT) {
+    const long long total = (long long)iters * p->N;
+    hipLaunchKernelGGL(k_invert_orders, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, p->orders_all, p->inv_all, p->N, total);
+  }
   CM_HIP(hipGetLastError());
   return CM_OK;
 }
 
 int cm_k_rng_streams_impl(cm_ctx* ctx, cm_problem* p, int it, int S, double* d_u) {
-  const int N = p->N;
-  const uint32_t* keys = p->keys + (size_t)it * (N + 3) * 2;
-  hipLaunchKernelGGL(k_mc_logit, dim3(N), dim3(64), (size_t)2 * S * sizeof(double), ctx->stream, keys, (const double*)nullptr, p->order,
-                     p->phi, p->phi_cov, p->vals, 0, S, N, p->mcE, d_u);
+  hipLaunchKernelGGL(k_ndtri_table, dim3(p->N, 1), dim3(64), 0, ctx->stream, p->keys, (const double*)nullptr, it, p->N, S, (double*)nullptr, d_u);
   CM_HIP(hipGetLastError());
   return CM_OK;
 }

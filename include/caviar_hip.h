@@ -115,7 +115,8 @@ typedef struct cm_timings {
   int32_t iters;
   int32_t last_active;   /* size of the active (lam row != 0) set in the last iteration       */
   int64_t sum_active;    /* sum over iterations of the active-set size                        */
-  int64_t sum_seq_rows;  /* reserved                                                          */
+  int64_t sum_seq_rows;  /* sum over iterations: rows in the sequential chain (mu != 0)        */
+  int64_t sum_seq_records; /* sum over iterations: 32-byte records streamed by k_sweep_seq (rows + their trials) */
 } cm_timings;
 
 const char* cm_last_error(void);
