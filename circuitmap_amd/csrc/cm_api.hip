@@ -345,19 +345,28 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
   CM_TRY(cm_launch_init_state(ctx, p, o->y_xcorr_thresh));
   CM_HIP(hipMemsetAsync(p->n_act, 0, 4 * sizeof(int), st));
   CM_HIP(hipMemsetAsync(p->seq_meta, 0, 8 * sizeof(int), st));
+  // Threefry key chain (host, sequential by nature): only iteration 0's keys are produced here; the rest is computed while
+  // the GPU works on iteration 0 and turned into permutations / ndtri tables on the side stream (see the loop below).
   std::vector<uint32_t> keys;
+  uint32_t chain[2] = {(uint32_t)(o->seed >> 32), (uint32_t)(o->seed & 0xFFFFFFFFull)};
+  const size_t key_per = (size_t)(N + 3) * 2;
+  bool rng_deferred = false;
   if (o->rng_mode == CM_RNG_THREEFRY && iters > 0) {
-    cm_host_key_schedule(o->seed, iters, N, keys);      // overlaps with the init kernels above
+    keys.assign(key_per * iters, 0u);
     if (p->keys_iters < iters) {
       if (p->keys) hipFree(p->keys);
       p->keys = nullptr;
       CM_TRY(dmalloc(&p->keys, keys.size()));
       p->keys_iters = iters;
     }
-    CM_HIP(hipMemcpyAsync(p->keys, keys.data(), keys.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    CM_TRY(cm_launch_rng(ctx, p, 0, iters));           // :196 update orders of every iteration (data independent)
+    cm_host_key_schedule_range(chain, 0, 1, N, keys.data());
+    CM_HIP(hipMemcpyAsync(p->keys, keys.data(), key_per * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    CM_TRY(cm_launch_rng(ctx, p, 0, 1, st));                       // :196 update order of iteration 0
+    CM_TRY(cm_launch_ndtri_table(ctx, p, 0, 1, S, o->rng_mode, st));
+    rng_deferred = iters > 1;
+  } else {
+    CM_TRY(cm_launch_ndtri_table(ctx, p, 0, iters, S, o->rng_mode, st));   // explicit streams: tabulate the uploaded uniforms
   }
-  CM_TRY(cm_launch_ndtri_table(ctx, p, iters, S, o->rng_mode));   // ndtri(u) of every draw of the run (data independent)
   if (o->save_histories && iters > 0) CM_TRY(alloc_hist(p, iters)); else free_hist(p);
 
   const bool timed = tm != nullptr;              // stamps around k_sweep_seq (events 3, 4)
@@ -391,6 +400,16 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
     CM_TRY(cm_launch_sweep(ctx, p, it, o, timed ? EV(it, 3) : nullptr));  // :81  update_lam
     if (timed) CM_HIP(hipEventRecord(EV(it, 4), st));
     CM_TRY(cm_launch_stats(ctx, p, o->spont_orthogonality));         // row + column statistics of the new lam
+    if (rng_deferred) {                                              // iteration 0 is enqueued: the GPU is busy, finish the key chain now
+      cm_host_key_schedule_range(chain, 1, iters - 1, N, keys.data());
+      CM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev[1], 0));          // (ev[1]: first part of the keys is uploaded)
+      CM_HIP(hipMemcpyAsync(p->keys + key_per, keys.data() + key_per, key_per * (iters - 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->side));
+      CM_TRY(cm_launch_rng(ctx, p, 1, iters - 1, ctx->side));        // orders of iterations 1.. (:196)
+      CM_TRY(cm_launch_ndtri_table(ctx, p, 1, iters - 1, S, o->rng_mode, ctx->side));
+      CM_HIP(hipEventRecord(ctx->ev[6], ctx->side));
+      CM_HIP(hipStreamWaitEvent(st, ctx->ev[6], 0));                 // the MC logit of iteration 1 (next kernel) needs them
+      rng_deferred = false;
+    }
     if (o->save_histories) CM_TRY(record_hist(ctx, p, it, 0));       // mu, beta, lam of this iteration (:90-92)
     // :84-88 update_sigma, update_phi, z, spont_rate; then block_update_mu (small sets) and the MC logit of iteration it + 1
     CM_TRY(cm_launch_iter_mid(ctx, p, it, iters, S, o->rng_mode, o, 1, 1));
@@ -625,7 +644,7 @@ extern "C" int cm_k_rng_streams(cm_ctx* ctx, uint64_t seed, int32_t it, int32_t 
              hipMemsetAsync(q.phi, 0, (size_t)N * 16, st) != hipSuccess || hipMemsetAsync(q.phi_cov, 0, (size_t)N * 32, st) != hipSuccess) {
     cm_set_error("rng upload failed"); rc = CM_ERR_HIP;
   }
-  if (!rc) rc = cm_launch_rng(ctx, &q, 0, it + 1);
+  if (!rc) rc = cm_launch_rng(ctx, &q, 0, it + 1, st);
   q.order = q.orders_all + (size_t)it * N;
   if (!rc) rc = cm_k_rng_streams_impl(ctx, &q, it, S, d_u);
   if (!rc && (hipMemcpyAsync(order, q.order, (size_t)N * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||

@@ -2,6 +2,28 @@
 #pragma once
 #include "cm_internal.h"
 
+
+// sum over one trial column with the loads issued in chunks of 8 entries: indices first, then both operands, then the
+// adds in ascending entry order (same association as a plain loop) -- two dependent load levels per chunk instead of per entry
+__device__ __forceinline__ double cm_col_dot(const double* __restrict__ mu, const double* __restrict__ lam,
+                                             const int* __restrict__ csc_row, const int* __restrict__ csc_pos, int beg, int end,
+                                             double orth, int* any_out) {
+  double s = 0.0;
+  int any = 0;
+  for (int c0 = beg; c0 < end; c0 += 8) {
+    int r[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int ce = min(c0 + j, end - 1); r[j] = csc_row[ce]; q[j] = csc_pos[ce]; }
+    double m[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { m[j] = mu[r[j]]; l[j] = lam[q[j]]; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (c0 + j < end) { s = fma(m[j], l[j], s); any |= (l[j] >= orth); }
+  }
+  if (any_out) *any_out = any;
+  return s;
+}
+
 // block-wide sum (1024 threads), result valid in every thread
 __device__ __forceinline__ double block_sum(double v, double* sh) {
   v = cm_wave_sum(v);

@@ -224,8 +224,9 @@ int cm_solve_mu(cm_ctx* ctx, cm_problem* p, int* n_active_out);                 
 int cm_solve_launch(cm_ctx* ctx, cm_problem* p, int na);
 int cm_small_cap(const cm_problem* p);
 int cm_launch_iter_mid(cm_ctx* ctx, cm_problem* p, int it, int iters, int S, int rng_mode, const cm_options* o, int do_sigma, int do_phi);
-int cm_launch_ndtri_table(cm_ctx* ctx, cm_problem* p, int iters, int S, int rng_mode);
-int cm_launch_rng(cm_ctx* ctx, cm_problem* p, int it0, int n_it);
+int cm_launch_ndtri_table(cm_ctx* ctx, cm_problem* p, int it0, int n_it, int S, int rng_mode, hipStream_t st);
+void cm_host_key_schedule_range(uint32_t key[2], int it0, int n_it, int N, uint32_t* keys);
+int cm_launch_rng(cm_ctx* ctx, cm_problem* p, int it0, int n_it, hipStream_t st);
 int cm_launch_mc_logit(cm_ctx* ctx, cm_problem* p, int it, int S, int rng_mode, hipStream_t st);
 int cm_launch_sweep(cm_ctx* ctx, cm_problem* p, int it, const cm_options* o, hipEvent_t mid);
 int cm_launch_stats(cm_ctx* ctx, cm_problem* p, double spont_orthogonality);

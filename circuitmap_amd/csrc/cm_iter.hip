@@ -1,4 +1,4 @@
-// The middle of a CAVIaR iteration as ONE launch on ONE stream (512-thread workgroups, two roles):
+// The middle of a CAVIaR iteration as ONE launch on ONE stream (256-thread workgroups, two roles):
 //
 //   block 0       everything that is a single-workgroup reduction, back to back:
 //                 active-set compaction -> size posted to the host mailbox -> update_sigma (caviar.py:238-244) ->
@@ -12,7 +12,7 @@
 // streams or events; the launch is as long as its longer role (~phi + MC logit).
 #include "cm_bodies.h"
 
-#define CM_ITER_THREADS 512                     // 8 waves: 2 per SIMD -> 256 VGPRs for the phi / quantile code (no spills)
+#define CM_ITER_THREADS 256                     // 4 waves = one per SIMD; with <= ~50 KB of LDS the blocks spread one per CU
 #define CM_ITER_WAVES (CM_ITER_THREADS / CM_WAVE)
 
 struct IterArgs {
@@ -62,8 +62,8 @@ __global__ __launch_bounds__(CM_ITER_THREADS) void k_iter_mid(IterArgs a) {
 // largest active set the fused kernel may solve in LDS (0 = never): A (n x (n+1)) + staged rows must fit beside the statics
 int cm_small_cap(const cm_problem* p) {
   int cap = 0;
-  for (int n = 1; n <= CM_SMALL_MAX; ++n)
-    if (small_lds_bytes(n, n * p->max_row_len) <= 140 * 1024) cap = n; else break;
+  for (int n = 1; n <= 64; ++n)                 // 64: steady-state active sets fit, and the LDS footprint stays ~50 KB per block
+    if (small_lds_bytes(n, n * p->max_row_len) <= 56 * 1024) cap = n; else break;
   return cap;
 }
 

@@ -39,14 +39,8 @@ __global__ __launch_bounds__(256) void k_stats(const double* __restrict__ lam, c
   } else {
     const int k = ((int)blockIdx.x - nbR) * blockDim.x + threadIdx.x;
     if (k >= K) return;
-    double s = 0.0;
     int any = 0;
-    for (int ce = col_ptr[k]; ce < col_ptr[k + 1]; ++ce) {
-      const double l = lam[csc_pos[ce]];
-      s = fma(mu[csc_row[ce]], l, s);
-      any |= (l >= orth);
-    }
-    R[k] = s;
+    R[k] = cm_col_dot(mu, lam, csc_row, csc_pos, col_ptr[k], col_ptr[k + 1], orth, &any);
     colany[k] = (uint8_t)any;
   }
 }

@@ -32,13 +32,13 @@ static void host_split(const uint32_t key[2], uint32_t out0[2], uint32_t out1[2]
 }
 
 // jax key handling of caviar(): see oracle/threefry.py JaxLikeStream (caviar.py:76,196,209-210,227,251,304)
-void cm_host_key_schedule(uint64_t seed, int iters, int N, std::vector<uint32_t>& keys) {
+// Resumable: `key` is the carried jax key (PRNGKey(seed) before iteration 0), updated in place; writes the (3 + N) keys of
+// iterations [it0, it0 + n_it) at their place in `keys` (which holds all iterations).
+void cm_host_key_schedule_range(uint32_t key[2], int it0, int n_it, int N, uint32_t* keys) {
   const size_t per = (size_t)(N + 3) * 2;
-  keys.assign(per * iters, 0u);
-  uint32_t key[2] = {(uint32_t)(seed >> 32), (uint32_t)(seed & 0xFFFFFFFFull)};
   const int rounds = cm_perm_rounds(N);
-  for (int it = 0; it < iters; ++it) {
-    uint32_t* out = keys.data() + per * it;
+  for (int it = it0; it < it0 + n_it; ++it) {
+    uint32_t* out = keys + per * it;
     uint32_t k[2] = {key[0], key[1]}, s0[2], s1[2];
     for (int r = 0; r < rounds && r < 3; ++r) {       // key, subkey = split(key)
       host_split(k, s0, s1);
@@ -54,6 +54,12 @@ void cm_host_key_schedule(uint64_t seed, int iters, int N, std::vector<uint32_t>
     host_split(k, s0, s1);                             // update_phi returns split(key)[1]
     key[0] = s1[0]; key[1] = s1[1];
   }
+}
+
+void cm_host_key_schedule(uint64_t seed, int iters, int N, std::vector<uint32_t>& keys) {
+  keys.assign((size_t)(N + 3) * 2 * iters, 0u);
+  uint32_t key[2] = {(uint32_t)(seed >> 32), (uint32_t)(seed & 0xFFFFFFFFull)};
+  cm_host_key_schedule_range(key, 0, iters, N, keys.data());
 }
 
 // 32-bit sort keys: jax threefry_2x32(key, iota(n)) layout (odd n padded with one zero counter)
@@ -401,11 +407,7 @@ __global__ __launch_bounds__(1024) void k_presweep(SweepArgs a, int N, int K, in
     if (n < N) sweep_indep_row(a, n, threadIdx.x % CM_WAVE, scr_all[threadIdx.x / CM_WAVE]);
   } else if (b < nbI + nbC) {
     const int k = (b - nbI) * 1024 + threadIdx.x;
-    if (k < K) {
-      double s = 0.0;
-      for (int ce = col_ptr[k]; ce < col_ptr[k + 1]; ++ce) s = fma(a.mu[csc_row[ce]], a.lam[csc_pos[ce]], s);
-      R[k] = s;
-    }
+    if (k < K) R[k] = cm_col_dot(a.mu, a.lam, csc_row, csc_pos, col_ptr[k], col_ptr[k + 1], 0.0, nullptr);
   } else {
     seq_scan_body(order, a.mu, a.row_ptr, N, seq_n, seq_off, chunk_first, meta, wsum, carry);
   }
@@ -525,8 +527,8 @@ __global__ __launch_bounds__(1024) void k_sweep_seq(SweepArgs a, const SeqRec* _
 }
 
 // Sweep orders of iterations [it0, it0 + n_it) into p->orders_all (caviar.py:196); threefry mode only.
-int cm_launch_rng(cm_ctx* ctx, cm_problem* p, int it0, int n_it) {
-  hipStream_t st = ctx->stream;
+int cm_launch_rng(cm_ctx* ctx, cm_problem* p, int it0, int n_it, hipStream_t st) {
+  (void)ctx;
   const int N = p->N;
   const int rounds = cm_perm_rounds(N);           // >= 1 for N >= 2
   const uint32_t* keys = p->keys + (size_t)it0 * (N + 3) * 2;
@@ -544,13 +546,15 @@ int cm_launch_rng(cm_ctx* ctx, cm_problem* p, int it0, int n_it) {
 }
 
 // w = ndtri(u) for every (iteration, sweep step, sample) of the run; explicit streams are tabulated from the uploaded uniforms
-int cm_launch_ndtri_table(cm_ctx* ctx, cm_problem* p, int iters, int S, int rng_mode) {
-  if (iters <= 0) return CM_OK;
+int cm_launch_ndtri_table(cm_ctx* ctx, cm_problem* p, int it0, int n_it, int S, int rng_mode, hipStream_t st) {
+  (void)ctx;
+  if (n_it <= 0) return CM_OK;
   const double* uexp = (rng_mode == CM_RNG_EXPLICIT) ? p->uexp : nullptr;
-  hipLaunchKernelGGL(k_ndtri_table, dim3(p->N, iters), dim3(64), 0, ctx->stream, p->keys, uexp, 0, p->N, S, p->wtab, (double*)nullptr);
+  hipLaunchKernelGGL(k_ndtri_table, dim3(p->N, n_it), dim3(64), 0, st, p->keys, uexp, it0, p->N, S, p->wtab, (double*)nullptr);
   if (rng_mode == CM_RNG_EXPLICIT) {
-    const long long total = (long long)iters * p->N;
-    hipLaunchKernelGGL(k_invert_orders, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, p->orders_all, p->inv_all, p->N, total);
+    const long long total = (long long)n_it * p->N;
+    hipLaunchKernelGGL(k_invert_orders, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p->orders_all + (size_t)it0 * p->N,
+                       p->inv_all + (size_t)it0 * p->N, p->N, total);
   }
   CM_HIP(hipGetLastError());
   return CM_OK;
