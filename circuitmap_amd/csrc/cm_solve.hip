@@ -64,24 +64,31 @@ __device__ __forceinline__ void tile_load(double (*dst)[TP], const double* __res
 __device__ __forceinline__ void tile_store(double* __restrict__ dst, int ld, const double (*src)[TP]) {
   for (int i = threadIdx.x; i < TS * TS; i += blockDim.x) dst[(size_t)(i / TS) * ld + (i % TS)] = src[i / TS][i % TS];
 }
-// c[2][2] += A(rows r0..r0+1, :) * B(rows c0..c0+1, :)^T
-__device__ __forceinline__ void tile_mma_nt(double c[2][2], const double (*A)[TP], const double (*B)[TP], int r0, int c0) {
-#pragma unroll 8
-  for (int k = 0; k < TS; ++k) {
-    const double a0 = A[r0][k], a1 = A[r0 + 1][k], b0 = B[c0][k], b1 = B[c0 + 1][k];
-    c[0][0] = fma(a0, b0, c[0][0]); c[0][1] = fma(a0, b1, c[0][1]);
-    c[1][0] = fma(a1, b0, c[1][0]); c[1][1] = fma(a1, b1, c[1][1]);
-  }
+// fp64 matrix-core tile products.  A 32x32x32 tile product is 4 output blocks of 16x16, one wavefront each (waves 0-3 of the
+// workgroup), 8 x v_mfma_f64_16x16x4_f64 per block.  Operand layout (gfx950): lane l feeds A[row = l & 15][k = l >> 4] and
+// B[k = l >> 4][col = l & 15]; the 4 accumulator registers of lane l hold D[row = (l >> 4) + 4 * reg][col = l & 15].
+// Same peak rate as the vector FMA pipe on CDNA4, but each operand is read from LDS once per 16 products instead of once
+// per 2 -- the register-tiled FMA version of these products was LDS-bound.
+typedef double cm_d4 __attribute__((ext_vector_type(4)));
+// acc += A[16 rb .., :] * B[16 cb .., :]^T        (rows of B are output columns)
+__device__ __forceinline__ cm_d4 blk_mfma_nt(cm_d4 acc, const double (*A)[TP], const double (*B)[TP], int rb, int cb, int lane) {
+  const int r = lane & 15, kk = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < TS / 4; ++ks)
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[16 * rb + r][4 * ks + kk], B[16 * cb + r][4 * ks + kk], acc, 0, 0, 0);
+  return acc;
 }
-// c[2][2] += A(rows r0.., :) * B(:, cols c0..)
-__device__ __forceinline__ void tile_mma_nn(double c[2][2], const double (*A)[TP], const double (*B)[TP], int r0, int c0) {
-#pragma unroll 8
-  for (int k = 0; k < TS; ++k) {
-    const double a0 = A[r0][k], a1 = A[r0 + 1][k], b0 = B[k][c0], b1 = B[k][c0 + 1];
-    c[0][0] = fma(a0, b0, c[0][0]); c[0][1] = fma(a0, b1, c[0][1]);
-    c[1][0] = fma(a1, b0, c[1][0]); c[1][1] = fma(a1, b1, c[1][1]);
-  }
+// acc += A[16 rb .., :] * B[:, 16 cb ..]
+__device__ __forceinline__ cm_d4 blk_mfma_nn(cm_d4 acc, const double (*A)[TP], const double (*B)[TP], int rb, int cb, int lane) {
+  const int r = lane & 15, kk = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < TS / 4; ++ks)
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[16 * rb + r][4 * ks + kk], B[4 * ks + kk][16 * cb + r], acc, 0, 0, 0);
+  return acc;
 }
+// element (reg) of a lane's accumulator <-> tile coordinates
+#define BLK_ROW(rb, lane, reg) (16 * (rb) + ((lane) >> 4) + 4 * (reg))
+#define BLK_COL(cb, lane) (16 * (cb) + ((lane) & 15))
 
 // L^-1 of a 32x32 SPD tile (C = L L^T) by forward elimination of the augmented matrix [C | I] in LDS, all 256 threads,
 // ONE barrier per pivot: after the sweep the right half holds Ltilde^-1 (unit lower, C = Ltilde D Ltilde^T) and
@@ -131,12 +138,12 @@ __global__ __launch_bounds__(256) void k_chol_trsm(const double* __restrict__ A,
   tile_load(P, A + (size_t)i * TS * ld + (size_t)j * TS, ld);
   tile_load(Li, Dinv + (size_t)j * TS * TS, TS);
   __syncthreads();
-  const int r0 = 2 * (threadIdx.x / 16), c0 = 2 * (threadIdx.x % 16);
-  double c[2][2] = {{0, 0}, {0, 0}};
-  tile_mma_nt(c, P, Li, r0, c0);       // X = P * Li^T
+  const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE, rb = wave >> 1, cb = wave & 1;
+  cm_d4 c = {0.0, 0.0, 0.0, 0.0};
+  c = blk_mfma_nt(c, P, Li, rb, cb, lane);       // X = P * Li^T
   double* out = Lf + (size_t)i * TS * ld + (size_t)j * TS;
-  out[(size_t)r0 * ld + c0] = c[0][0]; out[(size_t)r0 * ld + c0 + 1] = c[0][1];
-  out[(size_t)(r0 + 1) * ld + c0] = c[1][0]; out[(size_t)(r0 + 1) * ld + c0 + 1] = c[1][1];
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) out[(size_t)BLK_ROW(rb, lane, reg) * ld + BLK_COL(cb, lane)] = c[reg];
 }
 
 // Panel j in ONE launch (1024-thread workgroups, one per trailing tile (i, l), j < l <= i):
@@ -157,8 +164,8 @@ __global__ __launch_bounds__(1024) void k_chol_panel(double* __restrict__ A, dou
   while (ip * (ip + 1) / 2 > t) --ip;
   const int lp = t - ip * (ip + 1) / 2;
   const int i = j + 1 + ip, l = j + 1 + lp;
-  const bool mm = threadIdx.x < 256;
-  const int r0 = 2 * ((threadIdx.x & 255) / 16), c0 = 2 * ((threadIdx.x & 255) % 16);
+  const bool mm = threadIdx.x < 256;                 // waves 0-3 own the four 16x16 blocks of the tile products
+  const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE, rb = (wave >> 1) & 1, cb = wave & 1;
   if (SOLVED) {
     tile_load(Xi, Lf + (size_t)i * TS * ld + (size_t)j * TS, ld);
     if (l != i) tile_load(Xl, Lf + (size_t)l * TS * ld + (size_t)j * TS, ld);
@@ -169,13 +176,15 @@ __global__ __launch_bounds__(1024) void k_chol_panel(double* __restrict__ A, dou
   }
   __syncthreads();
   if (mm && !SOLVED) {
-    double c[2][2] = {{0, 0}, {0, 0}};
-    tile_mma_nt(c, Pi, Li, r0, c0);                  // X_i = P_i Linv^T
-    Xi[r0][c0] = c[0][0]; Xi[r0][c0 + 1] = c[0][1]; Xi[r0 + 1][c0] = c[1][0]; Xi[r0 + 1][c0 + 1] = c[1][1];
+    cm_d4 c = {0.0, 0.0, 0.0, 0.0};
+    c = blk_mfma_nt(c, Pi, Li, rb, cb, lane);          // X_i = P_i Linv^T
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) Xi[BLK_ROW(rb, lane, reg)][BLK_COL(cb, lane)] = c[reg];
     if (l != i) {
-      double e[2][2] = {{0, 0}, {0, 0}};
-      tile_mma_nt(e, Pl, Li, r0, c0);
-      Xl[r0][c0] = e[0][0]; Xl[r0][c0 + 1] = e[0][1]; Xl[r0 + 1][c0] = e[1][0]; Xl[r0 + 1][c0 + 1] = e[1][1];
+      cm_d4 e = {0.0, 0.0, 0.0, 0.0};
+      e = blk_mfma_nt(e, Pl, Li, rb, cb, lane);
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) Xl[BLK_ROW(rb, lane, reg)][BLK_COL(cb, lane)] = e[reg];
     }
   }
   __syncthreads();
@@ -183,12 +192,14 @@ __global__ __launch_bounds__(1024) void k_chol_panel(double* __restrict__ A, dou
   double* out = A + (size_t)i * TS * ld + (size_t)l * TS;
   const bool diag = (i == j + 1 && l == j + 1);
   if (mm) {
-    double c[2][2] = {{0, 0}, {0, 0}};
-    if (l != i) tile_mma_nt(c, Xi, Xl, r0, c0); else tile_mma_nt(c, Xi, Xi, r0, c0);
-    const double o00 = out[(size_t)r0 * ld + c0] - c[0][0], o01 = out[(size_t)r0 * ld + c0 + 1] - c[0][1];
-    const double o10 = out[(size_t)(r0 + 1) * ld + c0] - c[1][0], o11 = out[(size_t)(r0 + 1) * ld + c0 + 1] - c[1][1];
-    if (diag) { Pi[r0][c0] = o00; Pi[r0][c0 + 1] = o01; Pi[r0 + 1][c0] = o10; Pi[r0 + 1][c0 + 1] = o11; }
-    else { out[(size_t)r0 * ld + c0] = o00; out[(size_t)r0 * ld + c0 + 1] = o01; out[(size_t)(r0 + 1) * ld + c0] = o10; out[(size_t)(r0 + 1) * ld + c0 + 1] = o11; }
+    cm_d4 c = {0.0, 0.0, 0.0, 0.0};
+    c = (l != i) ? blk_mfma_nt(c, Xi, Xl, rb, cb, lane) : blk_mfma_nt(c, Xi, Xi, rb, cb, lane);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int rr = BLK_ROW(rb, lane, reg), cc = BLK_COL(cb, lane);
+      const double o = out[(size_t)rr * ld + cc] - c[reg];
+      if (diag) Pi[rr][cc] = o; else out[(size_t)rr * ld + cc] = o;
+    }
   }
   if (diag) {
     tile_linv(Pi, Pl, Li, flag);                     // Pi holds the updated SPD tile (written before the barrier inside)
@@ -216,18 +227,18 @@ __global__ __launch_bounds__(256) void k_inv_T(double* __restrict__ A, const dou
   const int j2 = (2 * q + 1) * b + rem / b;     // tile row in the second half
   const int c = 2 * q * b + rem % b;            // tile col in the first half
   if (j2 >= nblk) return;
-  const int r0 = 2 * (threadIdx.x / 16), c0 = 2 * (threadIdx.x % 16);
-  double acc[2][2] = {{0, 0}, {0, 0}};
+  const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE, rb = wave >> 1, cb = wave & 1;
+  cm_d4 acc = {0.0, 0.0, 0.0, 0.0};
   for (int j1 = c; j1 < (2 * q + 1) * b; ++j1) {    // X11[j1][c] is non-zero only for j1 >= c
     __syncthreads();
     tile_load(Lt, Lf + (size_t)j2 * TS * ld + (size_t)j1 * TS, ld);
     tile_load(Xt, X + (size_t)j1 * TS * ld + (size_t)c * TS, ld);
     __syncthreads();
-    tile_mma_nn(acc, Lt, Xt, r0, c0);
+    acc = blk_mfma_nn(acc, Lt, Xt, rb, cb, lane);
   }
   double* out = A + (size_t)c * TS * ld + (size_t)j2 * TS;    // scratch: strictly-upper tile (c, j2)
-  out[(size_t)r0 * ld + c0] = acc[0][0]; out[(size_t)r0 * ld + c0 + 1] = acc[0][1];
-  out[(size_t)(r0 + 1) * ld + c0] = acc[1][0]; out[(size_t)(r0 + 1) * ld + c0 + 1] = acc[1][1];
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) out[(size_t)BLK_ROW(rb, lane, reg) * ld + BLK_COL(cb, lane)] = acc[reg];
 }
 
 __global__ __launch_bounds__(256) void k_inv_X21(const double* __restrict__ A, double* __restrict__ X, int ld, int b, int nblk) {
@@ -237,18 +248,18 @@ __global__ __launch_bounds__(256) void k_inv_X21(const double* __restrict__ A, d
   const int i = (2 * q + 1) * b + rem / b;
   const int c = 2 * q * b + rem % b;
   if (i >= nblk) return;
-  const int r0 = 2 * (threadIdx.x / 16), c0 = 2 * (threadIdx.x % 16);
-  double acc[2][2] = {{0, 0}, {0, 0}};
+  const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE, rb = wave >> 1, cb = wave & 1;
+  cm_d4 acc = {0.0, 0.0, 0.0, 0.0};
   for (int j2 = (2 * q + 1) * b; j2 <= i; ++j2) {   // X22[i][j2] is non-zero only for j2 <= i
     __syncthreads();
     tile_load(Xa, X + (size_t)i * TS * ld + (size_t)j2 * TS, ld);
     tile_load(Tt, A + (size_t)c * TS * ld + (size_t)j2 * TS, ld);
     __syncthreads();
-    tile_mma_nn(acc, Xa, Tt, r0, c0);
+    acc = blk_mfma_nn(acc, Xa, Tt, rb, cb, lane);
   }
   double* out = X + (size_t)i * TS * ld + (size_t)c * TS;
-  out[(size_t)r0 * ld + c0] = -acc[0][0]; out[(size_t)r0 * ld + c0 + 1] = -acc[0][1];
-  out[(size_t)(r0 + 1) * ld + c0] = -acc[1][0]; out[(size_t)(r0 + 1) * ld + c0 + 1] = -acc[1][1];
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) out[(size_t)BLK_ROW(rb, lane, reg) * ld + BLK_COL(cb, lane)] = -acc[reg];
 }
 
 // ------------------------------------------------------------------------------------------------
