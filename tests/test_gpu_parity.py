@@ -176,3 +176,63 @@ def test_model_interface():
     assert model.history["lam"].shape == (5, 50, 200) and model.history["shape"].shape == (5, 200)
     with pytest.raises(Exception):
         model.fit(sim["psc"], sim["stim_matrix"], method="nope")
+
+
+def _edge_problem(seed, N, K, T, H, powers, dense_rows=False, no_zero=False):
+    rng = np.random.default_rng(seed)
+    stim = np.zeros((N, K))
+    for k in range(K):
+        tars = rng.choice(N, H, replace=False)
+        stim[tars, k] = powers[rng.integers(0, len(powers))]
+    if no_zero:
+        stim[stim == 0] = min(powers) / 2.0            # every entry targeted: unique(I)[1:] then drops the smallest power (quirk 8)
+    w = np.zeros(N)
+    w[: max(1, N // 4)] = rng.uniform(10, 30, max(1, N // 4))
+    spk = (rng.random((N, K)) < 1 / (1 + np.exp(-(0.2 * stim - 9.0)))) * (stim > 0)
+    t = np.arange(T)
+    kern = np.exp(-t / 20.0) - np.exp(-t / 5.0)
+    kern /= np.trapezoid(kern)
+    psc = (w @ spk)[:, None] * kern[None, :] + rng.normal(0, 5e-3, (K, T))
+    return psc, stim
+
+
+@pytest.mark.parametrize("case", ["long_rows", "many_powers", "no_zero_entries", "single_target", "long_rows_many_powers"])
+def test_rare_paths_vs_literal_oracle(case):
+    """Paths the synthetic benchmark shapes never take: rows with more than 64 targeted trials (two-pass row step, tiled
+    precision build with long rows), more than 8 distinct powers (literal pool-adjacent-violators walk on the device), a
+    stimulus matrix without zeros (the reference then drops the smallest power from `powers`), one target per trial."""
+    from circuitmap_amd.optimise import caviar
+    from oracle import caviar_oracle as co
+    cfg = {
+        "long_rows": dict(N=12, K=240, T=50, H=6, powers=[40.0, 55.0, 70.0]),
+        "many_powers": dict(N=16, K=200, T=50, H=3, powers=[30.0 + 4 * i for i in range(11)]),
+        "no_zero_entries": dict(N=5, K=60, T=50, H=2, powers=[40.0, 55.0, 70.0], no_zero=True),
+        "single_target": dict(N=20, K=160, T=50, H=1, powers=[45.0, 65.0]),
+        "long_rows_many_powers": dict(N=10, K=300, T=40, H=5, powers=[30.0 + 5 * i for i in range(9)]),
+    }[case]
+    psc, stim = _edge_problem(11, **cfg)
+    pri = default_priors(stim.shape[0])
+    opts = dict(iters=8, num_mc_samples=9, seed=5, minimum_spike_count=2, msrmp=0.15)
+    res = caviar(psc, stim, *prior_args(pri), **opts)
+    ref = co.caviar(psc, stim, *prior_args(pri), literal=True, **opts)
+    for i, nm in enumerate(OUT_NAMES):
+        assert rel_err(res[i], ref[i]) < 1e-7, (case, nm)
+
+
+def test_fit_batch_single_gpu_equals_direct():
+    """batch.fit_batch without a process group == a loop of caviar() calls, bit for bit."""
+    from circuitmap_amd import batch
+    from circuitmap_amd.optimise import caviar
+    from circuitmap_amd.simulation import simulate
+    circuits = []
+    for c in range(3):
+        sim = simulate(N=40, trials=120, seed=50 + c)
+        circuits.append((sim["psc"], sim["stim_matrix"]))
+    pri = default_priors(40)
+    opts = dict(iters=6, seed=1)
+    got = batch.fit_batch(circuits, priors=pri, fit_options=opts)
+    for (psc, stim), g in zip(circuits, got):
+        res = caviar(psc, stim, *prior_args(pri), **opts)
+        for i, nm in enumerate(OUT_NAMES):
+            if nm != "lam":
+                assert np.array_equal(np.asarray(res[i], dtype=float), np.asarray(g[nm], dtype=float), equal_nan=True), nm
