@@ -91,9 +91,12 @@ def main():
         sys.exit("bench.py needs an MI355X: no GPU visible (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or ("RANK" in os.environ and os.environ.get("CAVIAR_BENCH_FORCE_DIST") == "1"):
+        # one process per GPU under torch.distributed.run; backend "nccl" is RCCL on ROCm.  The data path has no collective
+        # (independent circuits): RCCL only carries the barriers and the max-over-ranks of the elapsed time.
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__ as ge
