@@ -3,25 +3,38 @@
 #include "cm_internal.h"
 
 
-// sum over one trial column with the loads issued in chunks of 8 entries: indices first, then both operands, then the
-// adds in ascending entry order (same association as a plain loop) -- two dependent load levels per chunk instead of per entry
-__device__ __forceinline__ double cm_col_dot(const double* __restrict__ mu, const double* __restrict__ lam,
-                                             const int* __restrict__ csc_row, const int* __restrict__ csc_pos, int beg, int end,
-                                             double orth, int* any_out) {
+// R_k = sum_n mu_n lam_nk (and colany_k = any lam_nk >= orth) with 16 lanes per trial column: lane j takes the column's j-th
+// entry (three dependent load levels in total: col_ptr -> indices -> operands), the 16 products are summed by a DPP segment
+// reduction (fixed tree -> deterministic); columns with more than 16 entries add their 16-entry partial sums in order.
+// `t` is the global thread index; every lane of the wave must call this (DPP), out-of-range columns just do not store.
+__device__ __forceinline__ void cm_col_dot16(int t, int K, const double* __restrict__ mu, const double* __restrict__ lam,
+                                             const int* __restrict__ col_ptr, const int* __restrict__ csc_row,
+                                             const int* __restrict__ csc_pos, double orth, double* __restrict__ R,
+                                             uint8_t* __restrict__ colany) {
+  const int k = t >> 4, j = t & 15;
+  const bool ok = k < K;
+  const int beg = ok ? col_ptr[k] : 0, end = ok ? col_ptr[k + 1] : 0;
+  int len = end - beg;
+  // the loop trip count must be uniform over the 16 lanes of a segment (it is: same column) but may differ between segments
+  // of a wave; DPP sources always lie inside the segment, so partial execution masks are safe
   double s = 0.0;
   int any = 0;
-  for (int c0 = beg; c0 < end; c0 += 8) {
-    int r[8], q[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { const int ce = min(c0 + j, end - 1); r[j] = csc_row[ce]; q[j] = csc_pos[ce]; }
-    double m[8], l[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { m[j] = mu[r[j]]; l[j] = lam[q[j]]; }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) if (c0 + j < end) { s = fma(m[j], l[j], s); any |= (l[j] >= orth); }
+  for (int c0 = 0; c0 < len; c0 += 16) {
+    const int ce = beg + c0 + j;
+    double v = 0.0;
+    if (ce < end) {
+      const double l = lam[csc_pos[ce]];
+      v = mu[csc_row[ce]] * l;
+      any |= (l >= orth);
+    }
+    s += cm_seg_sum<16>(v);
   }
-  if (any_out) *any_out = any;
-  return s;
+  // OR over the segment
+  any |= __builtin_amdgcn_update_dpp(0, any, CM_DPP_XOR1, 0xf, 0xf, true);
+  any |= __builtin_amdgcn_update_dpp(0, any, CM_DPP_XOR2, 0xf, 0xf, true);
+  any |= __builtin_amdgcn_update_dpp(0, any, CM_DPP_HALF_MIRROR, 0xf, 0xf, true);
+  any |= __builtin_amdgcn_update_dpp(0, any, CM_DPP_MIRROR, 0xf, 0xf, true);
+  if (ok && j == 0) { R[k] = s; if (colany) colany[k] = (uint8_t)(any != 0); }
 }
 
 // block-wide sum (1024 threads), result valid in every thread

@@ -7,7 +7,7 @@
 // ------------------------------------------------------------------------------------------------
 // Statistics of the new lam, one launch, two roles (256-thread blocks):
 //   blocks [0, nbR): one wave per row  -> rs[n] = {sum lam, sum lam^2, sum y*lam, sum lam(1-lam) or -1 if the row is all zero}
-//   blocks [nbR, ..): one thread per trial -> R_k = sum_n mu_n lam_nk (= lam.T @ mu, ascending neuron order),
+//   blocks [nbR, ..): 16 lanes per trial -> R_k = sum_n mu_n lam_nk (= lam.T @ mu),
 //                     colany_k = any_n lam_nk >= spont_orthogonality
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_stats(const double* __restrict__ lam, const int* __restrict__ row_ptr, const int* __restrict__ col,
@@ -37,11 +37,7 @@ __global__ __launch_bounds__(256) void k_stats(const double* __restrict__ lam, c
       rs[(size_t)n * 4 + 3] = any ? d : -1.0;   // sum lam(1-lam) for active rows, -1 marks an all-zero row
     }
   } else {
-    const int k = ((int)blockIdx.x - nbR) * blockDim.x + threadIdx.x;
-    if (k >= K) return;
-    int any = 0;
-    R[k] = cm_col_dot(mu, lam, csc_row, csc_pos, col_ptr[k], col_ptr[k + 1], orth, &any);
-    colany[k] = (uint8_t)any;
+    cm_col_dot16(((int)blockIdx.x - nbR) * blockDim.x + threadIdx.x, K, mu, lam, col_ptr, csc_row, csc_pos, orth, R, colany);
   }
 }
 
@@ -59,7 +55,7 @@ __global__ __launch_bounds__(1024) void k_post_single(const double* __restrict__
 
 // Row + column statistics of the current lam.  The caller follows with cm_launch_post_single().
 int cm_launch_stats(cm_ctx* ctx, cm_problem* p, double spont_orthogonality) {
-  const int nbR = (p->N + 3) / 4, nbC = (p->K + 255) / 256;
+  const int nbR = (p->N + 3) / 4, nbC = (p->K * 16 + 255) / 256;     // one wave per row; 16 lanes per trial column
   hipLaunchKernelGGL(k_stats, dim3(nbR + nbC), dim3(256), 0, ctx->stream, p->lam, p->row_ptr, p->col, p->y, p->mu, p->col_ptr, p->csc_row,
                      p->csc_pos, p->N, p->K, nbR, spont_orthogonality, p->rs, p->R, p->colany);
   CM_HIP(hipGetLastError());

@@ -11,6 +11,8 @@
 //      samples only on phi of the PREVIOUS iteration, so all N x S x P transcendental evaluations run as one
 //      embarrassingly parallel kernel before the sweep; a neuron with mu_n == 0 neither reads nor changes R, so
 //      those rows are swept in parallel and only the mu_n != 0 rows form the sequential chain (one workgroup).
+#include <stdlib.h>
+
 #include "cm_bodies.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -391,10 +393,10 @@ __device__ __forceinline__ void seq_scan_body(const int* __restrict__ order, con
 
 // One launch, three independent roles (1024-thread blocks):
 //   blocks [0, nbI)        rows with mu == 0, one wave per row (they neither read nor change R)
-//   blocks [nbI, nbI+nbC)  R_k = sum_n mu_n lam_nk per trial (= lam.T @ mu, ascending neuron order).  Rows handled by the
+//   blocks [nbI, nbI+nbC)  R_k = sum_n mu_n lam_nk per trial (= lam.T @ mu), 16 lanes per trial.  Rows handled by the
 //                          first role have mu == 0, so whichever of their old/new lam is read contributes exactly 0.
 //   last block             ordered compaction of the mu != 0 rows + record offsets + chunk table of the chain
-__global__ __launch_bounds__(1024) void k_presweep(SweepArgs a, int N, int K, int nbI, int nbC, const int* __restrict__ order,
+__global__ __launch_bounds__(1024) void k_presweep(SweepArgs a, int N, int K, int nbI, int nbC, int roles, const int* __restrict__ order,
                                                     const int* __restrict__ col_ptr, const int* __restrict__ csc_row,
                                                     const int* __restrict__ csc_pos, double* __restrict__ R, int* __restrict__ seq_n,
                                                     int* __restrict__ seq_off, int* __restrict__ chunk_first, int* __restrict__ meta) {
@@ -403,12 +405,14 @@ __global__ __launch_bounds__(1024) void k_presweep(SweepArgs a, int N, int K, in
   __shared__ int carry[2];
   const int b = blockIdx.x;
   if (b < nbI) {
+    if (!(roles & 1)) return;
     const int n = b * 16 + threadIdx.x / CM_WAVE;
     if (n < N) sweep_indep_row(a, n, threadIdx.x % CM_WAVE, scr_all[threadIdx.x / CM_WAVE]);
   } else if (b < nbI + nbC) {
-    const int k = (b - nbI) * 1024 + threadIdx.x;
-    if (k < K) R[k] = cm_col_dot(a.mu, a.lam, csc_row, csc_pos, col_ptr[k], col_ptr[k + 1], 0.0, nullptr);
+    if (!(roles & 2)) return;
+    cm_col_dot16((b - nbI) * 1024 + threadIdx.x, K, a.mu, a.lam, col_ptr, csc_row, csc_pos, 0.0, R, nullptr);
   } else {
+    if (!(roles & 4)) return;
     seq_scan_body(order, a.mu, a.row_ptr, N, seq_n, seq_off, chunk_first, meta, wsum, carry);
   }
 }
@@ -575,9 +579,11 @@ int cm_launch_sweep(cm_ctx* ctx, cm_problem* p, int it, const cm_options* o, hip
   a.msrmp = o->msrmp; a.min_count = o->minimum_spike_count;
   hipStream_t st = ctx->stream;
   const int N = p->N;
-  const int nbI = (N + 15) / 16, nbC = (p->K + 1023) / 1024;
-  hipLaunchKernelGGL(k_presweep, dim3(nbI + nbC + 1), dim3(1024), 0, st, a, N, p->K, nbI, nbC, p->order, p->col_ptr, p->csc_row,
-                     p->csc_pos, p->R, p->seq_n, p->seq_off, p->chunk_first, p->seq_meta);
+  const int nbI = (N + 15) / 16, nbC = (p->K * 16 + 1023) / 1024;    // 16 rows per block; 16 lanes per trial column
+  static const bool split = getenv("CAVIAR_HIP_SPLIT_PRESWEEP") != nullptr;     // diagnostic: one launch per role (profiling only)
+  for (int pass = 0; pass < (split ? 3 : 1); ++pass)
+    hipLaunchKernelGGL(k_presweep, dim3(nbI + nbC + 1), dim3(1024), 0, st, a, N, p->K, nbI, nbC, split ? (1 << pass) : 7, p->order,
+                       p->col_ptr, p->csc_row, p->csc_pos, p->R, p->seq_n, p->seq_off, p->chunk_first, p->seq_meta);
   hipLaunchKernelGGL(k_seq_pack, dim3((N + 3) / 4), dim3(256), 0, st, a, p->seq_n, p->seq_off, p->seq_meta, (SeqRec*)p->packed);
   if (mid) CM_HIP(hipEventRecord(mid, st));
   const size_t lds = (size_t)p->K * sizeof(double);
