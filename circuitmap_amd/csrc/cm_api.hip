@@ -375,7 +375,7 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
   auto EV = [&](int it, int j) { return ctx->pool[(size_t)it * CM_EV_PER_IT + j]; };
   auto post_wait_fallback = [&]() -> int {       // CAVIAR_HIP_NO_MAILBOX=1: classic copy + event instead of the mapped mailbox
     if (!ctx->use_mailbox) {
-      CM_HIP(hipMemcpyAsync(ctx->h_pinned, p->n_act, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+      CM_HIP(hipMemcpyAsync(ctx->h_pinned + 8, p->n_act, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
       CM_HIP(hipEventRecord(ctx->ev[7], st));
     }
     return CM_OK;
@@ -392,9 +392,9 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
     p->order = p->orders_all + (size_t)it * N;
     if (phases) CM_HIP(hipEventRecord(EV(it, 0), st));
     CM_TRY(cm_wait_active(ctx, p));                                  // the one host wait of an iteration: size of the active set
-    last_active = ctx->h_pinned[0];
+    last_active = ctx->mb_n;
     sum_active += last_active;
-    if (ctx->h_pinned[1]) { cm_set_error("iteration %d: weight precision matrix not positive definite", it); return CM_ERR_NOT_SPD; }
+    if (ctx->mb_flag) { cm_set_error("iteration %d: weight precision matrix not positive definite", it); return CM_ERR_NOT_SPD; }
     if (last_active > p->small_cap) CM_TRY(cm_solve_launch(ctx, p, last_active));   // :80 block_update_mu, large active set
     if (phases) CM_HIP(hipEventRecord(EV(it, 1), st));
     CM_TRY(cm_launch_sweep(ctx, p, it, o, timed ? EV(it, 3) : nullptr));  // :81  update_lam

@@ -65,7 +65,7 @@ __device__ __forceinline__ int post_single_body(const double* __restrict__ y, co
                                                  int it, int max_iters, double penalty, double scale_factor, double tol,
                                                  int do_sigma, int seq, int* __restrict__ act_idx, int* __restrict__ act_inv,
                                                  int* __restrict__ n_act, int* mailbox, double* __restrict__ z,
-                                                 double* __restrict__ scal) {
+                                                 double* __restrict__ scal, double* lds_scratch = nullptr) {
   __shared__ double sh[16];
   __shared__ int wave_cnt[16];
   __shared__ int base;
@@ -98,10 +98,13 @@ __device__ __forceinline__ int post_single_body(const double* __restrict__ y, co
     }
     if (threadIdx.x == 0) {
       n_act[0] = base;
-      if (mailbox) {                                  // host-mapped pinned memory; system-scope release on the sequence word
-        mailbox[0] = base;
-        mailbox[1] = n_act[1];
-        __hip_atomic_store(&mailbox[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (mailbox) {
+        // host-mapped (fine-grained) pinned memory.  Everything the host needs travels in ONE naturally aligned 64-bit word
+        // [seq : 32 | not-SPD flag : 1 | active-set size : 31], stored relaxed at system scope: single-copy atomic, so no
+        // release fence (= no L2 write-back, which costs tens of microseconds right after kernels that dirtied a lot of L2).
+        const unsigned long long word = ((unsigned long long)(unsigned)seq << 32) | ((unsigned long long)(n_act[1] != 0) << 31) |
+                                        (unsigned long long)(unsigned)base;
+        __hip_atomic_store((unsigned long long*)mailbox, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
   }
@@ -122,22 +125,31 @@ __device__ __forceinline__ int post_single_body(const double* __restrict__ y, co
     scal[CM_S_SHAPE] = scal[CM_S_SHAPE_PRIOR] + (double)K / 2.0;
     scal[CM_S_RATE] = scal[CM_S_RATE_PRIOR] + 0.5 * (a - b + c);
   }
-  // ---- 3. estimate_spont_act_soft_thresh
+  // ---- 3. estimate_spont_act_soft_thresh.  The residual and the "blocked" flag (column has a confident spike, or trial
+  // masked out) do not change across the penalty steps: with LDS scratch they are staged once and the up-to-20 steps run
+  // out of LDS instead of re-reading four global arrays each.
   double err = sum_y[0];
   const double ysq = sum_y[1] + 1e-5;
   double pen = penalty;
   int itc = it;
+  const bool staged = lds_scratch != nullptr && itc < max_iters && err > tol;
+  double* rl = lds_scratch;
+  uint8_t* bl = (uint8_t*)(lds_scratch + K);
+  if (staged) {
+    for (int k = threadIdx.x; k < K; k += blockDim.x) { rl[k] = y[k] - R[k]; bl[k] = (uint8_t)(colany[k] || !mask[k]); }
+    __syncthreads();
+  }
   while (itc < max_iters && err > tol) {
     double e = 0.0;
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
-      const double resid = y[k] - R[k];
-      double zz = resid < pen ? 0.0 : resid - pen;
-      zz = zz < 0.0 ? 0.0 : zz;
-      zz = colany[k] ? 0.0 : zz;
-      zz *= (double)mask[k];
+      const double resid = staged ? rl[k] : y[k] - R[k];
+      const bool blocked = staged ? (bl[k] != 0) : (colany[k] || !mask[k]);
+      double zz = resid < pen ? 0.0 : resid - pen;                       // :154
+      zz = zz < 0.0 ? 0.0 : zz;                                          // :155
+      zz = blocked ? 0.0 : zz;                                           // :156-157
       z[k] = zz;
       const double d = resid - zz;
-      e = fma(d, d, e);
+      e = fma(d, d, e);                                                  // :158
     }
     err = block_sum(e, sh) / ysq;
     ++itc;

@@ -34,9 +34,10 @@ struct cm_ctx {
   hipStream_t side = nullptr;     // side stream: update_phi(it) -> MC logit(it + 1), overlapped with sigma/z and the next solve
   bool own_stream = false;
   hipEvent_t ev[8] = {};
-  int32_t* h_pinned = nullptr;   // host-mapped pinned mailbox: [0] active-set size, [1] SPD flag, [2] sequence number
+  int32_t* h_pinned = nullptr;   // host-mapped pinned memory: words [0..1] = 64-bit mailbox (seq | flag | active-set size); [8..11] scratch for copies
   int32_t* d_mailbox = nullptr;  // device address of h_pinned
   int mail_seq = 0;
+  int mb_n = 0, mb_flag = 0;     // last values read from the mailbox (active-set size, not-SPD flag)
   bool use_mailbox = true;
   int num_cus = 256;
   std::vector<hipEvent_t> pool;   // per-iteration events (CM_EV_PER_IT per iteration): phase stamps + cross-stream edges

@@ -10,6 +10,8 @@
 //
 // Neither role reads what the other writes (sigma/z/mu/beta vs phi/mcE), so they overlap inside the launch without
 // streams or events; the launch is as long as its longer role (~phi + MC logit).
+#include <stdlib.h>
+
 #include "cm_bodies.h"
 
 #define CM_ITER_THREADS 256                     // 4 waves = one per SIMD; with <= ~50 KB of LDS the blocks spread one per CU
@@ -22,10 +24,10 @@ struct IterArgs {
   int* act_idx; int* act_inv; int* n_act; int* mailbox; double* z; double* scal;
   // block 0: next block_update_mu
   const double* lam; const int* row_ptr; const int* col; const double* mu_prior; const double* beta_prior;
-  int small_cap, max_row_len, do_solve; double* mu; double* beta;
+  int small_cap, max_row_len, do_solve, stage_ok; double* mu; double* beta;
   // blocks 1..: update_phi + next MC logit
   const uint8_t* grp; const int* rowcnt; const double* vals; int V; const double* phi_prior; const double* phi_cov_prior;
-  double* phi; double* phi_cov; int do_phi, do_mc, S;
+  double* phi; double* phi_cov; int do_phi, do_mc, S, roles;
   const uint32_t* keys_next; const double* uexp_next; const double* wtab_next; const int* inv_next; double* mcE;
 };
 
@@ -33,8 +35,10 @@ template <int SEG, bool FULLMC>
 __global__ __launch_bounds__(CM_ITER_THREADS) void k_iter_mid(IterArgs a) {
   extern __shared__ double sm[];
   if (blockIdx.x == 0) {
+    if (!(a.roles & 1)) return;
     const int n = post_single_body(a.y, a.R, a.colany, a.mask, a.mu, a.beta, a.rs, a.sum_y, a.N, a.K, a.it, a.max_iters, a.penalty,
-                                   a.scale_factor, a.tol, a.do_sigma, a.seq, a.act_idx, a.act_inv, a.n_act, a.mailbox, a.z, a.scal);
+                                   a.scale_factor, a.tol, a.do_sigma, a.seq, a.act_idx, a.act_inv, a.n_act, a.mailbox, a.z, a.scal,
+                                   a.stage_ok ? sm : nullptr);
     if (a.do_solve && n <= a.small_cap) {
       __syncthreads();
       solve_small_body(sm, a.lam, a.row_ptr, a.col, a.act_idx, a.rs, a.scal, a.mu_prior, a.beta_prior, n, a.N, n * a.max_row_len, a.mu,
@@ -42,6 +46,7 @@ __global__ __launch_bounds__(CM_ITER_THREADS) void k_iter_mid(IterArgs a) {
     }
     return;
   }
+  if (!(a.roles & 2)) return;
   const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE;
   const int n = ((int)blockIdx.x - 1) * CM_ITER_WAVES + wave;
   if (n >= a.N) return;
@@ -103,8 +108,17 @@ int cm_launch_iter_mid(cm_ctx* ctx, cm_problem* p, int it, int iters, int S, int
   a.mcE = p->mcE;
   size_t lds = (size_t)CM_ITER_WAVES * 2 * S * sizeof(double);
   if (p->small_cap > 0) lds = std::max(lds, small_lds_bytes(p->small_cap, p->small_cap * p->max_row_len));
+  a.stage_ok = 0;
+  if ((size_t)p->K * 9 + 16 <= 56 * 1024) { lds = std::max(lds, (size_t)p->K * 9 + 16); a.stage_ok = 1; }   // residual + flag per trial
   const int blocks = 1 + ((do_phi || a.do_mc) ? (N + CM_ITER_WAVES - 1) / CM_ITER_WAVES : 0);
   const int V = p->V;
+  static const bool split = getenv("CAVIAR_HIP_SPLIT_ITER") != nullptr;         // diagnostic: one launch per role (profiling only)
+  a.roles = 3;
+  if (split && it >= 0) {
+    a.roles = 2;
+    if (V <= 4) { CM_TRY(launch_iter<4>(ctx, a, lds, blocks)); } else { CM_TRY(launch_iter<64>(ctx, a, lds, blocks)); }
+    a.roles = 1;
+  }
   if (V <= 1) return launch_iter<1>(ctx, a, lds, blocks);
   if (V <= 2) return launch_iter<2>(ctx, a, lds, blocks);
   if (V <= 4) return launch_iter<4>(ctx, a, lds, blocks);

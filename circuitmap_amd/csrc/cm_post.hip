@@ -71,29 +71,36 @@ int cm_launch_post_single(cm_ctx* ctx, cm_problem* p, int it, const cm_options* 
                      p->act_idx, p->act_inv, p->n_act, ctx->use_mailbox ? ctx->d_mailbox : (int*)nullptr, p->z, p->scal);
   CM_HIP(hipGetLastError());
   if (!ctx->use_mailbox) {
-    CM_HIP(hipMemcpyAsync(ctx->h_pinned, p->n_act, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+    CM_HIP(hipMemcpyAsync(ctx->h_pinned + 8, p->n_act, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
     CM_HIP(hipEventRecord(ctx->ev[7], st));
   }
   return CM_OK;
 }
 
-// Host side of the mailbox: wait until the kernel launched by the last cm_launch_post_single() has posted the active-set size.
+// Host side of the mailbox: wait until the kernel launched by the last post has published the active-set size; the decoded
+// values land in ctx->mb_n / ctx->mb_flag.
 int cm_wait_active(cm_ctx* ctx, cm_problem* p) {
   (void)p;
-  if (!ctx->use_mailbox) { CM_HIP(hipEventSynchronize(ctx->ev[7])); return CM_OK; }
-  volatile int32_t* mb = ctx->h_pinned;
-  const int seq = ctx->mail_seq;
-  unsigned long long spins = 0;
-  while (__atomic_load_n(&mb[2], __ATOMIC_ACQUIRE) != seq) {
+  if (!ctx->use_mailbox) {
+    CM_HIP(hipEventSynchronize(ctx->ev[7]));
+    ctx->mb_n = ctx->h_pinned[8]; ctx->mb_flag = ctx->h_pinned[9];
+    return CM_OK;
+  }
+  volatile unsigned long long* mb = (volatile unsigned long long*)ctx->h_pinned;
+  const unsigned seq = (unsigned)ctx->mail_seq;
+  unsigned long long spins = 0, w;
+  while ((unsigned)((w = __atomic_load_n(mb, __ATOMIC_ACQUIRE)) >> 32) != seq) {
     if ((++spins & 0xFFFFull) == 0) {                      // every 64k polls make sure the stream is still alive
       hipError_t q = hipStreamQuery(ctx->stream);
       if (q != hipErrorNotReady && q != hipSuccess) { cm_set_error("stream failed while waiting for the active set: %s", hipGetErrorString(q)); return CM_ERR_HIP; }
-      if (q == hipSuccess && __atomic_load_n(&mb[2], __ATOMIC_ACQUIRE) != seq) {
-        cm_set_error("active-set mailbox was not posted (seq %d, have %d)", seq, (int)mb[2]);
+      if (q == hipSuccess && (unsigned)(__atomic_load_n(mb, __ATOMIC_ACQUIRE) >> 32) != seq) {
+        cm_set_error("active-set mailbox was not posted (seq %u)", seq);
         return CM_ERR_STATE;
       }
     }
   }
+  ctx->mb_n = (int)(w & 0x7FFFFFFFull);
+  ctx->mb_flag = (int)((w >> 31) & 1ull);
   return CM_OK;
 }
 

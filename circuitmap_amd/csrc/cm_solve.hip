@@ -329,7 +329,7 @@ __global__ __launch_bounds__(1024) void k_solve_small(const double* __restrict__
 // Expects cm_launch_row_stats() to have been enqueued after the last change of lam.
 int cm_solve_mu(cm_ctx* ctx, cm_problem* p, int* n_active_out) {
   CM_TRY(cm_wait_active(ctx, p));                   // the only host wait of an iteration: size of the active set
-  const int na = ctx->h_pinned[0];
+  const int na = ctx->mb_n;
   if (n_active_out) *n_active_out = na;
   return cm_solve_launch(ctx, p, na);
 }
