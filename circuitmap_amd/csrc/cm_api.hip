@@ -351,6 +351,7 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
   uint32_t chain[2] = {(uint32_t)(o->seed >> 32), (uint32_t)(o->seed & 0xFFFFFFFFull)};
   const size_t key_per = (size_t)(N + 3) * 2;
   bool rng_deferred = false;
+  int rng_done = 1;                              // iterations whose keys / orders / tables exist (iteration 0 is done up front)
   if (o->rng_mode == CM_RNG_THREEFRY && iters > 0) {
     keys.assign(key_per * iters, 0u);
     if (p->keys_iters < iters) {
@@ -400,15 +401,25 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
     CM_TRY(cm_launch_sweep(ctx, p, it, o, timed ? EV(it, 3) : nullptr));  // :81  update_lam
     if (timed) CM_HIP(hipEventRecord(EV(it, 4), st));
     CM_TRY(cm_launch_stats(ctx, p, o->spont_orthogonality));         // row + column statistics of the new lam
-    if (rng_deferred) {                                              // iteration 0 is enqueued: the GPU is busy, finish the key chain now
-      cm_host_key_schedule_range(chain, 1, iters - 1, N, keys.data());
-      CM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev[1], 0));          // (ev[1]: first part of the keys is uploaded)
-      CM_HIP(hipMemcpyAsync(p->keys + key_per, keys.data() + key_per, key_per * (iters - 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->side));
-      CM_TRY(cm_launch_rng(ctx, p, 1, iters - 1, ctx->side));        // orders of iterations 1.. (:196)
-      CM_TRY(cm_launch_ndtri_table(ctx, p, 1, iters - 1, S, o->rng_mode, ctx->side));
-      CM_HIP(hipEventRecord(ctx->ev[6], ctx->side));
-      CM_HIP(hipStreamWaitEvent(st, ctx->ev[6], 0));                 // the MC logit of iteration 1 (next kernel) needs them
-      rng_deferred = false;
+    if (rng_deferred) {
+      // The work of this iteration is enqueued and the GPU is busy with it: extend the (sequential, host-side) threefry key
+      // chain and turn it into sweep orders / ndtri tables on the side stream.  Two chunks so that nothing ever waits on the
+      // long part: iterations 1-2 right after iteration 0 (~35 us of host time), the rest in two halves behind iterations 1
+      // and 2 (each of those keeps the GPU busy for > 1 ms at the benchmark shape).
+      const int upto = (it == 0) ? std::min(iters, 3) : (it == 1) ? std::min(iters, 3 + (iters - 3 + 1) / 2) : iters;
+      if (upto > rng_done) {
+        const int n_new = upto - rng_done;
+        cm_host_key_schedule_range(chain, rng_done, n_new, N, keys.data());
+        CM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev[1], 0));        // (ev[1]: first part of the keys is uploaded)
+        CM_HIP(hipMemcpyAsync(p->keys + key_per * rng_done, keys.data() + key_per * rng_done, key_per * n_new * sizeof(uint32_t),
+                              hipMemcpyHostToDevice, ctx->side));
+        CM_TRY(cm_launch_rng(ctx, p, rng_done, n_new, ctx->side));   // orders of the new iterations (:196)
+        CM_TRY(cm_launch_ndtri_table(ctx, p, rng_done, n_new, S, o->rng_mode, ctx->side));
+        CM_HIP(hipEventRecord(ctx->ev[6], ctx->side));
+        CM_HIP(hipStreamWaitEvent(st, ctx->ev[6], 0));               // the MC logit of the next iteration (next kernel) needs them
+        rng_done = upto;
+      }
+      rng_deferred = rng_done < iters;
     }
     if (o->save_histories) CM_TRY(record_hist(ctx, p, it, 0));       // mu, beta, lam of this iteration (:90-92)
     // :84-88 update_sigma, update_phi, z, spont_rate; then block_update_mu (small sets) and the MC logit of iteration it + 1
