@@ -12,6 +12,7 @@
 #include "cm_bodies.h"
 
 #define TS CM_TILE
+#define CM_LINV_THREADS 1024  // threads that run the diagonal-tile elimination (256 was measured slower: 4 elements per thread)
 #define TP (CM_TILE + 1)   // padded LDS row (doubles)
 
 // ------------------------------------------------------------------------------------------------
@@ -94,9 +95,11 @@ __device__ __forceinline__ cm_d4 blk_mfma_nn(cm_d4 acc, const double (*A)[TP], c
 // ONE barrier per pivot: after the sweep the right half holds Ltilde^-1 (unit lower, C = Ltilde D Ltilde^T) and
 // L^-1 = D^-1/2 Ltilde^-1.  Only L^-1 is needed downstream (panel solve and inverse seed), so L itself is not formed.
 // C is destroyed; Rt is scratch; Li receives L^-1 (lower triangular).
-__device__ __forceinline__ void tile_linv(double (*C)[TP], double (*Rt)[TP], double (*Li)[TP], int* __restrict__ flag) {
+// Executed by the first `nt` threads of the workgroup; the caller retires all other waves first (a retired wave no longer
+// counts at s_barrier), so each of the 33 barriers only has to collect nt / 64 waves.
+__device__ __forceinline__ void tile_linv(double (*C)[TP], double (*Rt)[TP], double (*Li)[TP], int* __restrict__ flag, int nt) {
   __shared__ double dk[TS];
-  const int tid = threadIdx.x, nt = blockDim.x;       // 256 or 1024 threads
+  const int tid = threadIdx.x;
   for (int i = tid; i < TS * TS; i += nt) Rt[i / TS][i % TS] = (i / TS == i % TS) ? 1.0 : 0.0;
   bool bad = false;
   for (int k = 0; k < TS; ++k) {
@@ -130,8 +133,10 @@ __device__ __forceinline__ void tile_linv(double (*C)[TP], double (*Rt)[TP], dou
 __global__ __launch_bounds__(1024) void k_chol_first(double* __restrict__ A, int ld, double* __restrict__ Dinv, int* __restrict__ flag) {
   __shared__ double C[TS][TP], Rt[TS][TP], Li[TS][TP];
   tile_load(C, A, ld);
-  tile_linv(C, Rt, Li, flag);
-  tile_store(Dinv, TS, Li);
+  __syncthreads();
+  if (threadIdx.x >= CM_LINV_THREADS) return;
+  tile_linv(C, Rt, Li, flag, CM_LINV_THREADS);
+  for (int i = threadIdx.x; i < TS * TS; i += CM_LINV_THREADS) Dinv[(size_t)(i / TS) * TS + (i % TS)] = Li[i / TS][i % TS];
 }
 
 // panel solve for large matrices: Lf[i][j] = A[i][j] * L_jj^-T for i > j   (one 256-thread workgroup per tile row)
@@ -178,6 +183,12 @@ __global__ __launch_bounds__(1024) void k_chol_panel(double* __restrict__ A, dou
     if (l != i) tile_load(Pl, A + (size_t)l * TS * ld + (size_t)j * TS, ld);
     tile_load(Li, Dinv + (size_t)j * TS * TS, TS);
   }
+  double* out = A + (size_t)i * TS * ld + (size_t)l * TS;
+  double oprev[4] = {0.0, 0.0, 0.0, 0.0};
+  if (mm) {                                          // the tile to be updated: requested now, consumed after the products
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) oprev[reg] = out[(size_t)BLK_ROW(rb, lane, reg) * ld + BLK_COL(cb, lane)];
+  }
   __syncthreads();
   if (mm && !SOLVED) {
     cm_d4 c = {0.0, 0.0, 0.0, 0.0};
@@ -193,7 +204,6 @@ __global__ __launch_bounds__(1024) void k_chol_panel(double* __restrict__ A, dou
   }
   __syncthreads();
   if (!SOLVED && l == j + 1) tile_store(Lf + (size_t)i * TS * ld + (size_t)j * TS, ld, Xi);
-  double* out = A + (size_t)i * TS * ld + (size_t)l * TS;
   const bool diag = (i == j + 1 && l == j + 1);
   if (mm) {
     cm_d4 c = {0.0, 0.0, 0.0, 0.0};
@@ -201,13 +211,16 @@ __global__ __launch_bounds__(1024) void k_chol_panel(double* __restrict__ A, dou
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int rr = BLK_ROW(rb, lane, reg), cc = BLK_COL(cb, lane);
-      const double o = out[(size_t)rr * ld + cc] - c[reg];
+      const double o = oprev[reg] - c[reg];
       if (diag) Pi[rr][cc] = o; else out[(size_t)rr * ld + cc] = o;
     }
   }
   if (diag) {
-    tile_linv(Pi, Pl, Li, flag);                     // Pi holds the updated SPD tile (written before the barrier inside)
-    tile_store(Dinv + (size_t)(j + 1) * TS * TS, TS, Li);
+    __syncthreads();                                 // Pi holds the updated SPD tile; Lf store of this workgroup is issued
+    if (threadIdx.x >= CM_LINV_THREADS) return;
+    tile_linv(Pi, Pl, Li, flag, CM_LINV_THREADS);
+    double* dst = Dinv + (size_t)(j + 1) * TS * TS;
+    for (int q = threadIdx.x; q < TS * TS; q += CM_LINV_THREADS) dst[(size_t)(q / TS) * TS + (q % TS)] = Li[q / TS][q % TS];
   }
 }
 
