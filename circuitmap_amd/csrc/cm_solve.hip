@@ -224,6 +224,17 @@ __global__ __launch_bounds__(1024) void k_chol_panel(double* __restrict__ A, dou
   }
 }
 
+// 256-thread register staging of a 32x32 tile (4 elements per thread): lets the global loads of the NEXT tile pair fly while
+// the matrix cores work on the current one
+__device__ __forceinline__ void tile_fetch(double r[4], const double* __restrict__ src, int ld) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { const int i = threadIdx.x + 256 * q; r[q] = src[(size_t)(i / TS) * ld + (i % TS)]; }
+}
+__device__ __forceinline__ void tile_put(double (*dst)[TP], const double r[4]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { const int i = threadIdx.x + 256 * q; dst[i / TS][i % TS] = r[q]; }
+}
+
 // ------------------------------------------------------------------------------------------------
 // X = L^-1 by recursive doubling.  Level with half-size b tiles, pair q = rows/cols [2qb, 2qb+2b):
 //    T   = L21 * X11        (stored in the unused strictly-upper tile (c, j2) of A)
@@ -246,11 +257,19 @@ __global__ __launch_bounds__(256) void k_inv_T(double* __restrict__ A, const dou
   if (j2 >= nblk) return;
   const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE, rb = wave >> 1, cb = wave & 1;
   cm_d4 acc = {0.0, 0.0, 0.0, 0.0};
-  for (int j1 = c; j1 < (2 * q + 1) * b; ++j1) {    // X11[j1][c] is non-zero only for j1 >= c
+  const int jend = (2 * q + 1) * b;                  // X11[j1][c] is non-zero only for j1 >= c
+  double ra[4], rx[4];
+  tile_fetch(ra, Lf + (size_t)j2 * TS * ld + (size_t)c * TS, ld);
+  tile_fetch(rx, X + (size_t)c * TS * ld + (size_t)c * TS, ld);
+  for (int j1 = c; j1 < jend; ++j1) {
     __syncthreads();
-    tile_load(Lt, Lf + (size_t)j2 * TS * ld + (size_t)j1 * TS, ld);
-    tile_load(Xt, X + (size_t)j1 * TS * ld + (size_t)c * TS, ld);
+    tile_put(Lt, ra);
+    tile_put(Xt, rx);
     __syncthreads();
+    if (j1 + 1 < jend) {
+      tile_fetch(ra, Lf + (size_t)j2 * TS * ld + (size_t)(j1 + 1) * TS, ld);
+      tile_fetch(rx, X + (size_t)(j1 + 1) * TS * ld + (size_t)c * TS, ld);
+    }
     acc = blk_mfma_nn(acc, Lt, Xt, rb, cb, lane);
   }
   double* out = A + (size_t)c * TS * ld + (size_t)j2 * TS;    // scratch: strictly-upper tile (c, j2)
@@ -267,11 +286,19 @@ __global__ __launch_bounds__(256) void k_inv_X21(const double* __restrict__ A, d
   if (i >= nblk) return;
   const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE, rb = wave >> 1, cb = wave & 1;
   cm_d4 acc = {0.0, 0.0, 0.0, 0.0};
-  for (int j2 = (2 * q + 1) * b; j2 <= i; ++j2) {   // X22[i][j2] is non-zero only for j2 <= i
+  const int jbeg = (2 * q + 1) * b;                  // X22[i][j2] is non-zero only for j2 <= i
+  double ra[4], rx[4];
+  tile_fetch(ra, X + (size_t)i * TS * ld + (size_t)jbeg * TS, ld);
+  tile_fetch(rx, A + (size_t)c * TS * ld + (size_t)jbeg * TS, ld);
+  for (int j2 = jbeg; j2 <= i; ++j2) {
     __syncthreads();
-    tile_load(Xa, X + (size_t)i * TS * ld + (size_t)j2 * TS, ld);
-    tile_load(Tt, A + (size_t)c * TS * ld + (size_t)j2 * TS, ld);
+    tile_put(Xa, ra);
+    tile_put(Tt, rx);
     __syncthreads();
+    if (j2 + 1 <= i) {
+      tile_fetch(ra, X + (size_t)i * TS * ld + (size_t)(j2 + 1) * TS, ld);
+      tile_fetch(rx, A + (size_t)c * TS * ld + (size_t)(j2 + 1) * TS, ld);
+    }
     acc = blk_mfma_nn(acc, Xa, Tt, rb, cb, lane);
   }
   double* out = X + (size_t)i * TS * ld + (size_t)c * TS;
