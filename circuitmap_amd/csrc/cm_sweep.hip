@@ -13,6 +13,8 @@
 //      those rows are swept in parallel and only the mu_n != 0 rows form the sequential chain (one workgroup).
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "cm_bodies.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -445,7 +447,8 @@ __global__ __launch_bounds__(256) void k_seq_pack(SweepArgs a, const int* __rest
 }
 
 template <bool R_IN_LDS>
-__global__ __launch_bounds__(1024) void k_sweep_seq(SweepArgs a, const SeqRec* __restrict__ packed, const int* __restrict__ seq_off,
+__global__ __launch_bounds__(1024) void k_sweep_seq(SweepArgs a, const SeqRec* __restrict__ packed, int packed_cap, int nchunks_cap,
+                                                     const int* __restrict__ seq_off,
                                                      const int* __restrict__ chunk_first, const int* __restrict__ meta, int K,
                                                      const int* __restrict__ col_ptr, const int* __restrict__ csc_row,
                                                      const int* __restrict__ csc_pos, double* __restrict__ Rg) {
@@ -454,28 +457,27 @@ __global__ __launch_bounds__(1024) void k_sweep_seq(SweepArgs a, const SeqRec* _
   __shared__ double scr[3 * CM_MAX_VALS];
   extern __shared__ double Rl[];
 #define R_AT(k) (R_IN_LDS ? Rl[k] : Rg[k])
-  const int nseq = meta[0], nchunks = meta[2];
-  if (nseq == 0) return;
-  for (int i = threadIdx.x; i <= nchunks && i < CM_SEQ_LDS_CHUNKS; i += blockDim.x) {
-    const int f = chunk_first[i];
-    cfo[i][0] = f; cfo[i][1] = seq_off[f];
+  // Start-up in as few dependent global round trips as possible: chunk 0 always starts at record 0, so its records are
+  // requested speculatively (up to a full buffer, clamped to the allocation) together with meta, the statically addressed
+  // chunk-table entries and R; only the record offsets of later chunks need a second round trip.
+  {
+    const int i = threadIdx.x;                                   // blockDim.x == CM_SEQ_CAP == 1024
+    if (i < packed_cap) buf[0][i] = packed[i];
   }
+  const int nseq = meta[0], nchunks = meta[2];
+  for (int i = threadIdx.x; i < CM_SEQ_LDS_CHUNKS; i += blockDim.x) cfo[i][0] = (i <= nchunks_cap) ? chunk_first[i] : 0;
+  if (R_IN_LDS)
+    for (int k = threadIdx.x; k < K; k += blockDim.x) Rl[k] = Rg[k];
+  if (nseq == 0) return;
+  __syncthreads();
+  for (int i = threadIdx.x; i <= nchunks && i < CM_SEQ_LDS_CHUNKS; i += blockDim.x) cfo[i][1] = (i == 0) ? 0 : seq_off[cfo[i][0]];
   __syncthreads();
   auto first_row = [&](int c) { return c < CM_SEQ_LDS_CHUNKS ? cfo[c][0] : chunk_first[c]; };
   auto first_off = [&](int c) { return c < CM_SEQ_LDS_CHUNKS ? cfo[c][1] : seq_off[chunk_first[c]]; };
-  // R_k = sum_n mu_n lam_nk was formed by the column kernel (cm_launch_col_stats) just before this launch
-  if (R_IN_LDS)
-    for (int k = threadIdx.x; k < K; k += blockDim.x) Rl[k] = Rg[k];
   const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE;
   const double sig = a.scal[CM_S_SHAPE] / a.scal[CM_S_RATE];
   const double thresh = a.msrmp + a.scal[CM_S_SPONT_RATE];
   const int P = a.V - 1;
-  // chunk 0 is loaded by everybody
-  {
-    const int o0 = first_off(0), o1 = first_off(1);
-    for (int i = threadIdx.x; i < o1 - o0; i += blockDim.x) buf[0][i] = packed[o0 + i];
-  }
-  __syncthreads();
   int cur = 0;
   for (int c = 0; c < nchunks; ++c) {
     if (wave > 0) {
@@ -587,16 +589,19 @@ int cm_launch_sweep(cm_ctx* ctx, cm_problem* p, int it, const cm_options* o, hip
   hipLaunchKernelGGL(k_seq_pack, dim3((N + 3) / 4), dim3(256), 0, st, a, p->seq_n, p->seq_off, p->seq_meta, (SeqRec*)p->packed);
   if (mid) CM_HIP(hipEventRecord(mid, st));
   const size_t lds = (size_t)p->K * sizeof(double);
+  const long long nrec = (long long)p->N + p->nnz;             // allocation of `packed` (records) and of the chunk table
+  const int packed_cap = (int)std::min<long long>(CM_SEQ_CAP, nrec);
+  const int nchunks_cap = (int)std::min<long long>(CM_SEQ_LDS_CHUNKS - 1, nrec / 512 + 7);
   if (lds <= 88 * 1024) {     // 64 KiB of record buffers + R must fit the CU's 160 KiB
     static thread_local size_t attr_set = 0;      // raise the dynamic-LDS cap only when it has to grow
     if (lds > attr_set) {
       CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_seq<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       attr_set = lds;
     }
-    hipLaunchKernelGGL(k_sweep_seq<true>, dim3(1), dim3(1024), lds, st, a, (const SeqRec*)p->packed, p->seq_off, p->chunk_first,
+    hipLaunchKernelGGL(k_sweep_seq<true>, dim3(1), dim3(1024), lds, st, a, (const SeqRec*)p->packed, packed_cap, nchunks_cap, p->seq_off, p->chunk_first,
                        p->seq_meta, p->K, p->col_ptr, p->csc_row, p->csc_pos, p->R);
   } else {
-    hipLaunchKernelGGL(k_sweep_seq<false>, dim3(1), dim3(1024), 0, st, a, (const SeqRec*)p->packed, p->seq_off, p->chunk_first,
+    hipLaunchKernelGGL(k_sweep_seq<false>, dim3(1), dim3(1024), 0, st, a, (const SeqRec*)p->packed, packed_cap, nchunks_cap, p->seq_off, p->chunk_first,
                        p->seq_meta, p->K, p->col_ptr, p->csc_row, p->csc_pos, p->R);
   }
   CM_HIP(hipGetLastError());
