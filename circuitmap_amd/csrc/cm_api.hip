@@ -103,7 +103,7 @@ extern "C" int cm_problem_destroy(cm_problem* p) {
   void* ptrs[] = {p->y, p->ss, p->sum_y, p->vals, p->row_ptr, p->col, p->grp, p->rowcnt, p->col_ptr, p->csc_row, p->csc_pos,
                   p->mask, p->lam, p->mu, p->beta, p->mu_prior, p->beta_prior, p->phi, p->phi_cov, p->phi_prior, p->phi_cov_prior,
                   p->scal, p->R, p->colany, p->z, p->mcE, p->rs, p->act_idx, p->act_inv, p->n_act, p->orders_all, p->orders_tmp, p->inv_all, p->wtab,
-                  p->keys, p->uexp, p->A, p->X, p->Lf, p->Dinv, p->rhs, p->seq_n, p->seq_off, p->chunk_first,
+                  p->keys, p->uexp, p->A, p->X, p->Lf, p->Dinv, p->rhs, p->seq_n, p->seq_off, p->seq_pos, p->chunk_first,
                   p->seq_meta, p->packed};
   for (void* q : ptrs) if (q) hipFree(q);
   free_hist(p);
@@ -148,7 +148,7 @@ extern "C" int cm_problem_create(cm_ctx* ctx, int32_t N, int32_t K, int32_t T, c
       (rc = dmalloc(&p->rs, 4 * (size_t)N)) || (rc = dmalloc(&p->act_idx, N)) || (rc = dmalloc(&p->act_inv, N)) ||
       (rc = dmalloc(&p->n_act, 4)) || (rc = dmalloc(&p->A, ld * ld)) || (rc = dmalloc(&p->X, ld * ld)) || (rc = dmalloc(&p->Lf, ld * ld)) ||
       (rc = dmalloc(&p->Dinv, ld * CM_TILE)) || (rc = dmalloc(&p->rhs, 2 * ld)) || (rc = dmalloc(&p->seq_n, N)) ||
-      (rc = dmalloc(&p->seq_off, (size_t)N + 1)) || (rc = dmalloc(&p->chunk_first, ((size_t)N + p->nnz) / 512 + 8)) ||
+      (rc = dmalloc(&p->seq_off, (size_t)N + 1)) || (rc = dmalloc(&p->seq_pos, N)) || (rc = dmalloc(&p->chunk_first, ((size_t)N + p->nnz) / 512 + 8)) ||
       (rc = dmalloc(&p->seq_meta, 8)) || (rc = dmalloc((char**)&p->packed, ((size_t)N + p->nnz) * 32)))
     return fail(rc);
   if (hipMemsetAsync(p->mcE, 0, (size_t)N * CM_MAX_VALS * sizeof(double), st) != hipSuccess) return fail(CM_ERR_HIP);
@@ -455,6 +455,7 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
   if (iters > 0) {
     CM_HIP(hipMemcpy(ctx->h_pinned + 8, p->n_act, 4 * sizeof(int), hipMemcpyDeviceToHost));   // [8..11]: outside the mailbox words
     if (ctx->h_pinned[9]) { cm_set_error("weight precision matrix not positive definite"); return CM_ERR_NOT_SPD; }
+    if (ctx->h_pinned[10]) { cm_set_error("sweep ticket wait timed out (internal error)"); return CM_ERR_STATE; }
   }
   if (tm) {
     float a = 0, b = 0, c = 0;

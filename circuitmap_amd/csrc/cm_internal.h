@@ -51,6 +51,7 @@ struct cm_problem {
   int32_t V = 0;         // number of distinct stimulus values (sorted ascending; powers = vals[1:])
   int32_t ld = 0;        // leading dimension of the solve matrices (multiple of CM_TILE), sized for N
   int32_t max_row_len = 0; // longest CSR row (targeted trials of one neuron)
+  int32_t max_col_len = 0; // most neurons targeted in one trial
   int32_t small_cap = 0;   // largest active set solved inside the fused mid-iteration kernel
   // --- static encoding (built once by cm_problem_create) ---
   double* y = nullptr;        // [K]  trapz(psc)
@@ -97,6 +98,7 @@ struct cm_problem {
   int32_t orders_cap = 0;     // iterations the two buffers are sized for
   int32_t* seq_n = nullptr;   // [N]   neurons with mu != 0 in sweep order
   int32_t* seq_off = nullptr; // [N+1] record offset of each such row in `packed`
+  int32_t* seq_pos = nullptr; // [N]   position of neuron n in the chain, -1 if mu_n == 0
   int32_t* chunk_first = nullptr; // [n_chunk_cap] first row of each LDS chunk
   int32_t* seq_meta = nullptr;// [4]   nseq, total records, nchunks
   void* packed = nullptr;     // [(N + nnz) * 32 B] packed row records of the sequential chain

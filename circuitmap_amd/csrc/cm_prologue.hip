@@ -280,6 +280,8 @@ int cm_encode_stim(cm_ctx* ctx, cm_problem* p, const double* d_stim) {
   CM_HIP(hipMemcpyAsync(p->h_col_ptr.data(), p->col_ptr, (size_t)(K + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
   CM_HIP(hipMemcpyAsync(p->h_csc_row.data(), p->csc_row, (size_t)p->nnz * sizeof(int), hipMemcpyDeviceToHost, st));
   CM_HIP(hipStreamSynchronize(st));
+  p->max_col_len = 0;
+  for (int k = 0; k < K; ++k) p->max_col_len = std::max(p->max_col_len, p->h_col_ptr[k + 1] - p->h_col_ptr[k]);
   hipFree(d_table); hipFree(d_flags); hipFree(d_row_nnz); hipFree(d_col_cnt);
   return CM_OK;
 }

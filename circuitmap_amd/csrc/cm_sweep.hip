@@ -344,7 +344,7 @@ struct __align__(16) SeqRec {
 __device__ __forceinline__ void seq_scan_body(const int* __restrict__ order, const double* __restrict__ mu,
                                               const int* __restrict__ row_ptr, int N, int* __restrict__ seq_n,
                                               int* __restrict__ seq_off, int* __restrict__ chunk_first, int* __restrict__ meta,
-                                              int (*wsum)[16], int* carry) {
+                                              int* __restrict__ seq_pos, int (*wsum)[16], int* carry) {
   if (threadIdx.x < 2) carry[threadIdx.x] = 0;
   __syncthreads();
   const int lane = threadIdx.x % CM_WAVE, w = threadIdx.x / CM_WAVE;
@@ -375,6 +375,7 @@ __device__ __forceinline__ void seq_scan_body(const int* __restrict__ order, con
       const int cprev = off == 0 ? -1 : (off - 1) / CM_SEQ_B;   // previous row ends at `off`
       if (c != cprev) chunk_first[c] = j;
     }
+    if (m < N) seq_pos[n] = f ? (bf + sf - 1) : -1;         // position in the chain, for the per-trial tickets
     __syncthreads();
     if (threadIdx.x == 0) {
       int tf = 0, tr = 0;
@@ -401,7 +402,8 @@ __device__ __forceinline__ void seq_scan_body(const int* __restrict__ order, con
 __global__ __launch_bounds__(1024) void k_presweep(SweepArgs a, int N, int K, int nbI, int nbC, int roles, const int* __restrict__ order,
                                                     const int* __restrict__ col_ptr, const int* __restrict__ csc_row,
                                                     const int* __restrict__ csc_pos, double* __restrict__ R, int* __restrict__ seq_n,
-                                                    int* __restrict__ seq_off, int* __restrict__ chunk_first, int* __restrict__ meta) {
+                                                    int* __restrict__ seq_off, int* __restrict__ chunk_first, int* __restrict__ meta,
+                                                    int* __restrict__ seq_pos) {
   __shared__ double scr_all[16][3 * CM_MAX_VALS];
   __shared__ int wsum[2][16];
   __shared__ int carry[2];
@@ -415,12 +417,16 @@ __global__ __launch_bounds__(1024) void k_presweep(SweepArgs a, int N, int K, in
     cm_col_dot16((b - nbI) * 1024 + threadIdx.x, K, a.mu, a.lam, col_ptr, csc_row, csc_pos, 0.0, R, nullptr);
   } else {
     if (!(roles & 4)) return;
-    seq_scan_body(order, a.mu, a.row_ptr, N, seq_n, seq_off, chunk_first, meta, wsum, carry);
+    seq_scan_body(order, a.mu, a.row_ptr, N, seq_n, seq_off, chunk_first, meta, seq_pos, wsum, carry);
   }
 }
 
+// `turns` != 0: also store in bits 24..31 of the slot word how many EARLIER chain rows touch the entry's trial (its ticket
+// in the multi-wave chain kernel); requires nnz < 2^24 and at most 255 targeted neurons per trial.
 __global__ __launch_bounds__(256) void k_seq_pack(SweepArgs a, const int* __restrict__ seq_n, const int* __restrict__ seq_off,
-                                                   const int* __restrict__ meta, SeqRec* __restrict__ packed) {
+                                                   const int* __restrict__ meta, SeqRec* __restrict__ packed, int turns,
+                                                   const int* __restrict__ seq_pos, const int* __restrict__ col_ptr,
+                                                   const int* __restrict__ csc_row) {
   const int j = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE;
   const int lane = threadIdx.x % CM_WAVE;
   if (j >= meta[0]) return;
@@ -438,7 +444,10 @@ __global__ __launch_bounds__(256) void k_seq_pack(SweepArgs a, const int* __rest
     const int k = a.col[e], g = a.grp[e];
     SeqRec r;
     r.a = (uint32_t)k | ((uint32_t)g << 24) | ((uint32_t)(a.mask[k] != 0) << 31);
-    r.b = e;
+    int turn = 0;
+    if (turns)
+      for (int ce = col_ptr[k]; ce < col_ptr[k + 1]; ++ce) { const int q = seq_pos[csc_row[ce]]; turn += (q >= 0 && q < j); }
+    r.b = e | (turn << 24);
     r.x = a.lam[e];
     r.y = a.mcE[(size_t)n * CM_MAX_VALS + g];
     r.z = -2.0 * sig * a.y[k] * mu;                                                       // caviar.py:205, first term
@@ -532,6 +541,111 @@ __global__ __launch_bounds__(1024) void k_sweep_seq(SweepArgs a, const SeqRec* _
 #undef R_AT
 }
 
+// ------------------------------------------------------------------------------------------------
+// Multi-wave chain.  Two chain rows conflict only if they share a trial (through R_k), and with H targets per trial the
+// dependency graph of a sweep is sparse: at the benchmark shape its critical path is ~130 of 1000 rows.  CM_PAR_W consumer
+// waves take the rows of a chunk round-robin, each in increasing order; a record carries its trial's "turn" (number of earlier
+// chain rows touching that trial, from k_seq_pack) and a per-trial LDS counter is the ticket: a row starts when every one of
+// its trials shows its turn, and publishes turn + 1 after updating R.  Static in-order assignment makes this deadlock free
+// (the smallest unfinished row never waits); results are bit-identical to the one-wave walk because every R_k still sees
+// its updates in sweep order.  Requires rows <= 64 trials, <= 255 neurons per trial, nnz < 2^24 (host checks).
+// ------------------------------------------------------------------------------------------------
+#define CM_PAR_W 8
+__global__ __launch_bounds__(1024) void k_sweep_par(SweepArgs a, const SeqRec* __restrict__ packed, int packed_cap, int nchunks_cap,
+                                                     const int* __restrict__ seq_off, const int* __restrict__ chunk_first,
+                                                     const int* __restrict__ meta, int K, const double* __restrict__ Rg,
+                                                     int* __restrict__ err_flag) {
+  __shared__ SeqRec buf[2][CM_SEQ_CAP];
+  __shared__ int cfo[CM_SEQ_LDS_CHUNKS][2];
+  __shared__ int roff[2][CM_SEQ_CAP + 1];            // record offset of every row of the chunk, relative to the chunk start
+  __shared__ double scr[CM_PAR_W][3 * CM_MAX_VALS];
+  extern __shared__ double dyn[];
+  double* Rl = dyn;                                  // [K]
+  int* cnt = (int*)(dyn + K);                        // [K] tickets
+  {
+    const int i = threadIdx.x;
+    if (i < packed_cap) buf[0][i] = packed[i];
+  }
+  const int nseq = meta[0], nchunks = meta[2];
+  for (int i = threadIdx.x; i < CM_SEQ_LDS_CHUNKS; i += blockDim.x) cfo[i][0] = (i <= nchunks_cap) ? chunk_first[i] : 0;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) { Rl[k] = Rg[k]; cnt[k] = 0; }
+  if (nseq == 0) return;
+  __syncthreads();
+  for (int i = threadIdx.x; i <= nchunks && i < CM_SEQ_LDS_CHUNKS; i += blockDim.x) cfo[i][1] = (i == 0) ? 0 : seq_off[cfo[i][0]];
+  __syncthreads();
+  auto first_row = [&](int c) { return c < CM_SEQ_LDS_CHUNKS ? cfo[c][0] : chunk_first[c]; };
+  auto first_off = [&](int c) { return c < CM_SEQ_LDS_CHUNKS ? cfo[c][1] : seq_off[chunk_first[c]]; };
+  {                                                  // row offsets of chunk 0
+    const int r0 = first_row(0), rows0 = first_row(1) - r0;
+    for (int j = threadIdx.x; j <= rows0; j += blockDim.x) roff[0][j] = seq_off[r0 + j];
+  }
+  __syncthreads();
+  const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE;
+  const double sig = a.scal[CM_S_SHAPE] / a.scal[CM_S_RATE];
+  const double thresh = a.msrmp + a.scal[CM_S_SPONT_RATE];
+  const int P = a.V - 1;
+  int cur = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    const int rows = first_row(c + 1) - first_row(c);
+    if (wave >= CM_PAR_W) {
+      if (c + 1 < nchunks) {                         // producers: records and row offsets of chunk c + 1
+        const int o0 = first_off(c + 1), o1 = first_off(c + 2);
+        const int nth = blockDim.x - CM_PAR_W * CM_WAVE, t = threadIdx.x - CM_PAR_W * CM_WAVE;
+        for (int i = t; i < o1 - o0; i += nth) buf[cur ^ 1][i] = packed[o0 + i];
+        const int r1 = first_row(c + 1), rows1 = first_row(c + 2) - r1;
+        for (int j = t; j <= rows1; j += nth) roff[cur ^ 1][j] = seq_off[r1 + j] - o0;
+      }
+    } else {
+      int j = wave;
+      SeqRec h, r;
+      if (j < rows) { const int pos = roff[cur][j]; h = buf[cur][pos]; r = buf[cur][min(pos + 1 + lane, CM_SEQ_CAP - 1)]; }
+      for (; j < rows; j += CM_PAR_W) {
+        SeqRec hn = h, rn = r;
+        if (j + CM_PAR_W < rows) {                   // this wave's next row: requested before waiting on the tickets
+          const int pn = roff[cur][j + CM_PAR_W];
+          hn = buf[cur][pn]; rn = buf[cur][min(pn + 1 + lane, CM_SEQ_CAP - 1)];
+        }
+        const int len = h.b;
+        const bool valid = lane < len;
+        const double mu = h.x, t3 = h.y;
+        const int k = valid ? (int)(r.a & 0xFFFFFFu) : 0, g = (int)((r.a >> 24) & 0x7Fu);
+        const bool msk = (r.a >> 31) != 0u;
+        const int slot = r.b & 0xFFFFFF, turn = (int)((unsigned)r.b >> 24);
+        // ---- wait until every trial of this row shows its turn (bounded: a logic error must not hang the GPU)
+        unsigned spins = 0;
+        while (true) {
+          const bool ok = !valid || (__hip_atomic_load(&cnt[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == turn);
+          if (__all(ok)) break;
+          if (++spins > (1u << 18)) { if (lane == 0) *err_flag = 1; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        double est = 0.0, rk = 0.0;
+        if (valid) {
+          rk = Rl[k];
+          if (msk) {
+            const double loo = sig * (rk - mu * r.x);
+            const double arg = r.z + 2.0 * mu * loo + t3;                              // caviar.py:205-206
+            est = cm_sigmoid(r.y - 0.5 * arg);                                         // caviar.py:216
+          }
+        }
+        double pava = 1.0;
+        if (a.gated) pava = row_gate(valid, g, est, P, thresh, a.min_count, scr[wave]);  // caviar.py:219-221
+        if (valid) {
+          const double nl = est * pava;                                                // caviar.py:224
+          a.lam[slot] = nl;
+          Rl[k] = rk + mu * (nl - r.x);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (valid) __hip_atomic_store(&cnt[k], turn + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        h = hn; r = rn;
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
 // Sweep orders of iterations [it0, it0 + n_it) into p->orders_all (caviar.py:196); threefry mode only.
 int cm_launch_rng(cm_ctx* ctx, cm_problem* p, int it0, int n_it, hipStream_t st) {
   (void)ctx;
@@ -585,14 +699,28 @@ int cm_launch_sweep(cm_ctx* ctx, cm_problem* p, int it, const cm_options* o, hip
   static const bool split = getenv("CAVIAR_HIP_SPLIT_PRESWEEP") != nullptr;     // diagnostic: one launch per role (profiling only)
   for (int pass = 0; pass < (split ? 3 : 1); ++pass)
     hipLaunchKernelGGL(k_presweep, dim3(nbI + nbC + 1), dim3(1024), 0, st, a, N, p->K, nbI, nbC, split ? (1 << pass) : 7, p->order,
-                       p->col_ptr, p->csc_row, p->csc_pos, p->R, p->seq_n, p->seq_off, p->chunk_first, p->seq_meta);
-  hipLaunchKernelGGL(k_seq_pack, dim3((N + 3) / 4), dim3(256), 0, st, a, p->seq_n, p->seq_off, p->seq_meta, (SeqRec*)p->packed);
+                       p->col_ptr, p->csc_row, p->csc_pos, p->R, p->seq_n, p->seq_off, p->chunk_first, p->seq_meta, p->seq_pos);
+  // multi-wave chain for long chains when the ticket encoding fits (see k_sweep_par)
+  static const bool no_par = getenv("CAVIAR_HIP_NO_PAR_SWEEP") != nullptr;
+  const size_t lds_par = (size_t)p->K * (sizeof(double) + sizeof(int));
+  const bool par = !no_par && ctx->mb_n > 48 && p->max_row_len <= CM_WAVE && p->max_col_len <= 255 && p->nnz < (1 << 24) &&
+                   lds_par <= 68 * 1024;
+  hipLaunchKernelGGL(k_seq_pack, dim3((N + 3) / 4), dim3(256), 0, st, a, p->seq_n, p->seq_off, p->seq_meta, (SeqRec*)p->packed,
+                     par ? 1 : 0, p->seq_pos, p->col_ptr, p->csc_row);
   if (mid) CM_HIP(hipEventRecord(mid, st));
   const size_t lds = (size_t)p->K * sizeof(double);
   const long long nrec = (long long)p->N + p->nnz;             // allocation of `packed` (records) and of the chunk table
   const int packed_cap = (int)std::min<long long>(CM_SEQ_CAP, nrec);
   const int nchunks_cap = (int)std::min<long long>(CM_SEQ_LDS_CHUNKS - 1, nrec / 512 + 7);
-  if (lds <= 88 * 1024) {     // 64 KiB of record buffers + R must fit the CU's 160 KiB
+  if (par) {
+    static thread_local size_t attr_par = 0;
+    if (lds_par > attr_par) {
+      CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_par), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_par));
+      attr_par = lds_par;
+    }
+    hipLaunchKernelGGL(k_sweep_par, dim3(1), dim3(1024), lds_par, st, a, (const SeqRec*)p->packed, packed_cap, nchunks_cap, p->seq_off,
+                       p->chunk_first, p->seq_meta, p->K, p->R, p->n_act + 2);
+  } else if (lds <= 88 * 1024) {     // 64 KiB of record buffers + R must fit the CU's 160 KiB
     static thread_local size_t attr_set = 0;      // raise the dynamic-LDS cap only when it has to grow
     if (lds > attr_set) {
       CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_seq<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
