@@ -550,7 +550,12 @@ __global__ __launch_bounds__(1024) void k_sweep_seq(SweepArgs a, const SeqRec* _
 // (the smallest unfinished row never waits); results are bit-identical to the one-wave walk because every R_k still sees
 // its updates in sweep order.  Requires rows <= 64 trials, <= 255 neurons per trial, nnz < 2^24 (host checks).
 // ------------------------------------------------------------------------------------------------
-#define CM_PAR_W 8
+#ifndef CM_PAR_W
+#define CM_PAR_W 12   // consumer waves (the other 4 stream records); 8 and 4 measured 1.5 % and 4 % slower
+#endif
+#ifndef CM_PAR_MIN_ROWS
+#define CM_PAR_MIN_ROWS 0    // measured: the multi-wave kernel also wins for the ~30-row steady-state chains
+#endif
 __global__ __launch_bounds__(1024) void k_sweep_par(SweepArgs a, const SeqRec* __restrict__ packed, int packed_cap, int nchunks_cap,
                                                      const int* __restrict__ seq_off, const int* __restrict__ chunk_first,
                                                      const int* __restrict__ meta, int K, const double* __restrict__ Rg,
@@ -703,7 +708,7 @@ int cm_launch_sweep(cm_ctx* ctx, cm_problem* p, int it, const cm_options* o, hip
   // multi-wave chain for long chains when the ticket encoding fits (see k_sweep_par)
   static const bool no_par = getenv("CAVIAR_HIP_NO_PAR_SWEEP") != nullptr;
   const size_t lds_par = (size_t)p->K * (sizeof(double) + sizeof(int));
-  const bool par = !no_par && ctx->mb_n > 48 && p->max_row_len <= CM_WAVE && p->max_col_len <= 255 && p->nnz < (1 << 24) &&
+  const bool par = !no_par && ctx->mb_n > CM_PAR_MIN_ROWS && p->max_row_len <= CM_WAVE && p->max_col_len <= 255 && p->nnz < (1 << 24) &&
                    lds_par <= 68 * 1024;
   hipLaunchKernelGGL(k_seq_pack, dim3((N + 3) / 4), dim3(256), 0, st, a, p->seq_n, p->seq_off, p->seq_meta, (SeqRec*)p->packed,
                      par ? 1 : 0, p->seq_pos, p->col_ptr, p->csc_row);
