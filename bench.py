@@ -143,21 +143,24 @@ def main():
     if rank == 0:
         its = a.iters
         value = world * a.steps * its / dt
-        # --- dominant kernel: k_sweep_seq, one launch per iteration (timed by HIP events on the library's stream).
-        # Algorithmic bytes of a launch = the packed 32-B records of the rows in the chain (header + one per targeted
-        # trial: trial, power, mask, slot, lam_old, MC logit, -2*sigma*y*mu) + 8 B lam write per trial + the K-vector R.
-        # The library reports how many rows / records the chain actually held in each fit (it shrinks as cells are pruned).
-        seq_ms = float(np.mean([t["sweep_seq_ms"] for t in tms])) / its          # average launch duration, ms
-        recs = float(np.mean([t["sum_seq_records"] for t in tms])) / its         # records per launch (average over the fit)
+        # --- dominant kernel (rocprof, profiles/): k_iter_mid, one launch per iteration, timed live by HIP events that the
+        # library records on its stream around every launch (cm_timings.mid_ms).  Algorithmic bytes of one launch:
+        #   block 0   y, R (8 B each), colany, mask (1 B each) per trial; mu, beta (8 B), row stats (32 B) per neuron; z written
+        #   waves     per neuron: its lam row (8 + 1 B per targeted trial), counts of V stimulus values (4 B each), phi priors
+        #             (48 B), phi / phi_cov written (48 B); next MC logit: inverse order (4 B), key (8 B), ndtri table row
+        #             (2 S x 8 B), P logits written (8 B each)
+        S = 100
+        mid_ms = float(np.mean([t["mid_ms"] for t in tms])) / its                # average launch duration, ms
+        mid_bytes = K * (8 + 8 + 1 + 1 + 8) + N * (8 + 8 + 32) + nnz * 9 + N * (8 + 4 * nvals + 48 + 48 + 4 + 8 + 2 * S * 8 + 8 * (nvals - 1))
+        achieved = mid_bytes / (mid_ms * 1e-3) / 1e9
+        # --- the Gauss-Seidel chain kernel (k_sweep_par), second opinion: its launch time and the records it actually streamed
+        seq_ms = float(np.mean([t["sweep_seq_ms"] for t in tms])) / its
+        recs = float(np.mean([t["sum_seq_records"] for t in tms])) / its         # 32-B records per launch (average over the fit)
         rows = float(np.mean([t["sum_seq_rows"] for t in tms])) / its
-        sparse_bytes = recs * 32 + (recs - rows) * 8 + K * 8
+        chain_bytes = recs * 32 + (recs - rows) * 8 + K * 12                      # records + lam writes + R and ticket vectors
         dense_equiv_bytes = 12 * N * K                                             # I + lam read + lam write, fp32 dense
-        achieved = sparse_bytes / (seq_ms * 1e-3) / 1e9
-        # HBM traffic of the same kernel from rocprofv3 PMC passes (profiles/r01_pmc_*; FETCH_SIZE doubled as the gfx950 guide
-        # prescribes): measured for cfg3 only
-        traffic = {"cfg3": int((2 * 45.21 + 13.32) * 1024)}.get(a.workload)
         phase = {k: float(np.mean([t[k] for t in tms])) for k in
-                 ("total_ms", "iters_ms", "fn_scan_ms", "solve_ms", "mc_ms", "mc_wait_ms", "sweep_indep_ms", "sweep_seq_ms", "post_ms")}
+                 ("total_ms", "iters_ms", "fn_scan_ms", "solve_ms", "sweep_indep_ms", "sweep_seq_ms", "mid_ms", "post_ms")}
         out = {
             "metric": "CAVIaR iterations/sec (N=%d, K=%d, T=%d)" % (N, K, T),
             "value": value, "unit": "iterations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -167,12 +170,15 @@ def main():
                                    "1 circuit per GPU" % (a.workload, N, K, T, H, its),
                        "nnz_targeted": int(nnz), "distinct_powers": int(nvals) - 1,
                        "mean_active_set": float(np.mean([t["sum_active"] for t in tms])) / max(its, 1)},
-            "roofline": {"bound": "hbm", "kernel": "k_sweep_seq", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "avg_launch_ms": seq_ms, "algorithmic_bytes_per_launch": int(sparse_bytes), "chain_rows_per_launch": rows,
-                         "dense_equiv_bytes_per_launch": int(dense_equiv_bytes),
-                         "dense_equiv_achieved": dense_equiv_bytes / (seq_ms * 1e-3) / 1e9,
-                         "note": "latency-bound sequential Gauss-Seidel chain (one workgroup); see DESIGN.md"},
+            "roofline": {"bound": "hbm", "kernel": "k_iter_mid", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": mid_ms, "algorithmic_bytes_per_launch": int(mid_bytes),
+                         "note": "latency-bound: 10 dependent Newton steps of fp64 exp/log per neuron; every kernel of this "
+                                 "workload is latency- or dependency-bound, none is bandwidth-bound (DESIGN.md section 5)",
+                         "chain_kernel": {"kernel": "k_sweep_par", "avg_launch_ms": seq_ms, "algorithmic_bytes_per_launch": int(chain_bytes),
+                                          "achieved": chain_bytes / (seq_ms * 1e-3) / 1e9, "chain_rows_per_launch": rows,
+                                          "dense_equiv_bytes_per_launch": int(dense_equiv_bytes),
+                                          "dense_equiv_achieved": dense_equiv_bytes / (seq_ms * 1e-3) / 1e9}},
             "phase_ms_per_step": phase,
         }
         if world == 1 and not a.no_cpu_baseline:

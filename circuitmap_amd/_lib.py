@@ -41,7 +41,7 @@ class CmResult(C.Structure):
 
 class CmTimings(C.Structure):
     _fields_ = [("total_ms", C.c_double), ("iters_ms", C.c_double), ("fn_scan_ms", C.c_double), ("solve_ms", C.c_double),
-                ("mc_ms", C.c_double), ("mc_wait_ms", C.c_double), ("sweep_indep_ms", C.c_double), ("sweep_seq_ms", C.c_double), ("post_ms", C.c_double),
+                ("mc_ms", C.c_double), ("mc_wait_ms", C.c_double), ("sweep_indep_ms", C.c_double), ("sweep_seq_ms", C.c_double), ("mid_ms", C.c_double), ("post_ms", C.c_double),
                 ("iters", C.c_int32), ("last_active", C.c_int32), ("sum_active", C.c_int64), ("sum_seq_rows", C.c_int64), ("sum_seq_records", C.c_int64)]
 
     def as_dict(self):

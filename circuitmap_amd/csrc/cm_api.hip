@@ -423,7 +423,9 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
     }
     if (o->save_histories) CM_TRY(record_hist(ctx, p, it, 0));       // mu, beta, lam of this iteration (:90-92)
     // :84-88 update_sigma, update_phi, z, spont_rate; then block_update_mu (small sets) and the MC logit of iteration it + 1
+    if (timed) CM_HIP(hipEventRecord(EV(it, 8), st));
     CM_TRY(cm_launch_iter_mid(ctx, p, it, iters, S, o->rng_mode, o, 1, 1));
+    if (timed) CM_HIP(hipEventRecord(EV(it, 9), st));
     CM_TRY(post_wait_fallback());
     if (o->save_histories) CM_TRY(record_hist(ctx, p, it, 1));       // shape, rate, phi, phi_cov, z
     if (phases) CM_HIP(hipEventRecord(EV(it, 5), st));
@@ -471,6 +473,8 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
       float d = 0;
       hipEventElapsedTime(&d, EV(it, 3), EV(it, 4));
       tm->sweep_seq_ms += d;
+      hipEventElapsedTime(&d, EV(it, 8), EV(it, 9));
+      tm->mid_ms += d;
       if (!phases) continue;
       hipEventElapsedTime(&d, EV(it, 0), EV(it, 1)); tm->solve_ms += d;        // host wait + large-set solve (small sets are fused)
       hipEventElapsedTime(&d, EV(it, 1), EV(it, 3)); tm->sweep_indep_ms += d;  // pre-sweep + pack

@@ -110,7 +110,8 @@ typedef struct cm_timings {
   double mc_ms;          /* sum: update_phi(it) + Monte-Carlo logit(it+1) on the side stream (overlapped) */
   double mc_wait_ms;     /* sum: main stream waiting for the side stream before the sweep     */
   double sweep_indep_ms; /* sum: k_sweep_indep launches                                       */
-  double sweep_seq_ms;   /* sum: k_sweep_seq launches (the sequential Gauss-Seidel chain)     */
+  double sweep_seq_ms;   /* sum: chain-kernel launches (k_sweep_par / k_sweep_seq: the Gauss-Seidel chain) */
+  double mid_ms;         /* sum: k_iter_mid launches (sigma, z, small solve || phi + next MC logit) */
   double post_ms;        /* sum: row/col stats, update_sigma, soft-threshold (main stream)    */
   int32_t iters;
   int32_t last_active;   /* size of the active (lam row != 0) set in the last iteration       */
