@@ -153,6 +153,9 @@ def main():
         mid_ms = float(np.mean([t["mid_ms"] for t in tms])) / its                # average launch duration, ms
         mid_bytes = K * (8 + 8 + 1 + 1 + 8) + N * (8 + 8 + 32) + nnz * 9 + N * (8 + 4 * nvals + 48 + 48 + 4 + 8 + 2 * S * 8 + 8 * (nvals - 1))
         achieved = mid_bytes / (mid_ms * 1e-3) / 1e9
+        # HBM traffic of the same kernel from rocprofv3 PMC passes (profiles/r01_d_pmc_*: FETCH_SIZE 1235.0 KB, doubled as the
+        # MI355X guide prescribes for gfx950, + WRITE_SIZE 102.1 KB per launch); measured for cfg3 only
+        traffic = {"cfg3": int((2 * 1235.0 + 102.1) * 1024)}.get(a.workload)
         # --- the Gauss-Seidel chain kernel (k_sweep_par), second opinion: its launch time and the records it actually streamed
         seq_ms = float(np.mean([t["sweep_seq_ms"] for t in tms])) / its
         recs = float(np.mean([t["sum_seq_records"] for t in tms])) / its         # 32-B records per launch (average over the fit)
@@ -171,7 +174,7 @@ def main():
                        "nnz_targeted": int(nnz), "distinct_powers": int(nvals) - 1,
                        "mean_active_set": float(np.mean([t["sum_active"] for t in tms])) / max(its, 1)},
             "roofline": {"bound": "hbm", "kernel": "k_iter_mid", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": mid_ms, "algorithmic_bytes_per_launch": int(mid_bytes),
                          "note": "latency-bound: 10 dependent Newton steps of fp64 exp/log per neuron; every kernel of this "
                                  "workload is latency- or dependency-bound, none is bandwidth-bound (DESIGN.md section 5)",
