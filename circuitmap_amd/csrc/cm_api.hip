@@ -148,7 +148,7 @@ extern "C" int cm_problem_create(cm_ctx* ctx, int32_t N, int32_t K, int32_t T, c
       (rc = dmalloc(&p->rs, 4 * (size_t)N)) || (rc = dmalloc(&p->act_idx, N)) || (rc = dmalloc(&p->act_inv, N)) ||
       (rc = dmalloc(&p->n_act, 4)) || (rc = dmalloc(&p->A, ld * ld)) || (rc = dmalloc(&p->X, ld * ld)) || (rc = dmalloc(&p->Lf, ld * ld)) ||
       (rc = dmalloc(&p->Dinv, ld * CM_TILE)) || (rc = dmalloc(&p->rhs, 2 * ld)) || (rc = dmalloc(&p->seq_n, N)) ||
-      (rc = dmalloc(&p->seq_off, (size_t)N + 1)) || (rc = dmalloc(&p->seq_pos, N)) || (rc = dmalloc(&p->chunk_first, ((size_t)N + p->nnz) / 512 + 8)) ||
+      (rc = dmalloc(&p->seq_off, (size_t)N + 1)) || (rc = dmalloc(&p->seq_pos, N)) || (rc = dmalloc(&p->chunk_first, ((size_t)N + p->nnz) / 256 + 8)) ||
       (rc = dmalloc(&p->seq_meta, 8)) || (rc = dmalloc((char**)&p->packed, ((size_t)N + p->nnz) * 32)))
     return fail(rc);
   if (hipMemsetAsync(p->mcE, 0, (size_t)N * CM_MAX_VALS * sizeof(double), st) != hipSuccess) return fail(CM_ERR_HIP);

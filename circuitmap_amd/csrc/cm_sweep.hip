@@ -344,7 +344,7 @@ struct __align__(16) SeqRec {
 __device__ __forceinline__ void seq_scan_body(const int* __restrict__ order, const double* __restrict__ mu,
                                               const int* __restrict__ row_ptr, int N, int* __restrict__ seq_n,
                                               int* __restrict__ seq_off, int* __restrict__ chunk_first, int* __restrict__ meta,
-                                              int* __restrict__ seq_pos, int (*wsum)[16], int* carry) {
+                                              int* __restrict__ seq_pos, int gran, int (*wsum)[16], int* carry) {
   if (threadIdx.x < 2) carry[threadIdx.x] = 0;
   __syncthreads();
   const int lane = threadIdx.x % CM_WAVE, w = threadIdx.x / CM_WAVE;
@@ -371,8 +371,8 @@ __device__ __forceinline__ void seq_scan_body(const int* __restrict__ order, con
       seq_n[j] = n;
       seq_off[j] = off;
       // chunk of this row = floor((end offset - 1) / B); first row of each chunk registers itself
-      const int c = (off + recs - 1) / CM_SEQ_B;
-      const int cprev = off == 0 ? -1 : (off - 1) / CM_SEQ_B;   // previous row ends at `off`
+      const int c = (off + recs - 1) / gran;
+      const int cprev = off == 0 ? -1 : (off - 1) / gran;       // previous row ends at `off`
       if (c != cprev) chunk_first[c] = j;
     }
     if (m < N) seq_pos[n] = f ? (bf + sf - 1) : -1;         // position in the chain, for the per-trial tickets
@@ -386,7 +386,7 @@ __device__ __forceinline__ void seq_scan_body(const int* __restrict__ order, con
   }
   if (threadIdx.x == 0) {
     const int nseq = carry[0], total = carry[1];
-    const int nchunks = total > 0 ? (total - 1) / CM_SEQ_B + 1 : 0;
+    const int nchunks = total > 0 ? (total - 1) / gran + 1 : 0;
     seq_off[nseq] = total;
     chunk_first[nchunks] = nseq;
     meta[0] = nseq; meta[1] = total; meta[2] = nchunks;
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(1024) void k_presweep(SweepArgs a, int N, int K, in
                                                     const int* __restrict__ col_ptr, const int* __restrict__ csc_row,
                                                     const int* __restrict__ csc_pos, double* __restrict__ R, int* __restrict__ seq_n,
                                                     int* __restrict__ seq_off, int* __restrict__ chunk_first, int* __restrict__ meta,
-                                                    int* __restrict__ seq_pos) {
+                                                    int* __restrict__ seq_pos, int gran) {
   __shared__ double scr_all[16][3 * CM_MAX_VALS];
   __shared__ int wsum[2][16];
   __shared__ int carry[2];
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(1024) void k_presweep(SweepArgs a, int N, int K, in
     cm_col_dot16((b - nbI) * 1024 + threadIdx.x, K, a.mu, a.lam, col_ptr, csc_row, csc_pos, 0.0, R, nullptr);
   } else {
     if (!(roles & 4)) return;
-    seq_scan_body(order, a.mu, a.row_ptr, N, seq_n, seq_off, chunk_first, meta, seq_pos, wsum, carry);
+    seq_scan_body(order, a.mu, a.row_ptr, N, seq_n, seq_off, chunk_first, meta, seq_pos, gran, wsum, carry);
   }
 }
 
@@ -556,20 +556,22 @@ __global__ __launch_bounds__(1024) void k_sweep_seq(SweepArgs a, const SeqRec* _
 #ifndef CM_PAR_MIN_ROWS
 #define CM_PAR_MIN_ROWS 0    // measured: the multi-wave kernel also wins for the ~30-row steady-state chains
 #endif
+// CAP = records per LDS buffer, TK = ticket type: (1024, int) for K up to ~5600 trials, (512, uint8_t) up to ~10900.
+template <int CAP, typename TK>
 __global__ __launch_bounds__(1024) void k_sweep_par(SweepArgs a, const SeqRec* __restrict__ packed, int packed_cap, int nchunks_cap,
                                                      const int* __restrict__ seq_off, const int* __restrict__ chunk_first,
                                                      const int* __restrict__ meta, int K, const double* __restrict__ Rg,
                                                      int* __restrict__ err_flag) {
-  __shared__ SeqRec buf[2][CM_SEQ_CAP];
+  __shared__ SeqRec buf[2][CAP];
   __shared__ int cfo[CM_SEQ_LDS_CHUNKS][2];
-  __shared__ int roff[2][CM_SEQ_CAP + 1];            // record offset of every row of the chunk, relative to the chunk start
+  __shared__ int roff[2][CAP + 1];            // record offset of every row of the chunk, relative to the chunk start
   __shared__ double scr[CM_PAR_W][3 * CM_MAX_VALS];
   extern __shared__ double dyn[];
   double* Rl = dyn;                                  // [K]
-  int* cnt = (int*)(dyn + K);                        // [K] tickets
+  volatile TK* cnt = (volatile TK*)(dyn + K);        // [K] tickets
   {
     const int i = threadIdx.x;
-    if (i < packed_cap) buf[0][i] = packed[i];
+    if (i < packed_cap && i < CAP) buf[0][i] = packed[i];
   }
   const int nseq = meta[0], nchunks = meta[2];
   for (int i = threadIdx.x; i < CM_SEQ_LDS_CHUNKS; i += blockDim.x) cfo[i][0] = (i <= nchunks_cap) ? chunk_first[i] : 0;
@@ -603,12 +605,12 @@ __global__ __launch_bounds__(1024) void k_sweep_par(SweepArgs a, const SeqRec* _
     } else {
       int j = wave;
       SeqRec h, r;
-      if (j < rows) { const int pos = roff[cur][j]; h = buf[cur][pos]; r = buf[cur][min(pos + 1 + lane, CM_SEQ_CAP - 1)]; }
+      if (j < rows) { const int pos = roff[cur][j]; h = buf[cur][pos]; r = buf[cur][min(pos + 1 + lane, CAP - 1)]; }
       for (; j < rows; j += CM_PAR_W) {
         SeqRec hn = h, rn = r;
         if (j + CM_PAR_W < rows) {                   // this wave's next row: requested before waiting on the tickets
           const int pn = roff[cur][j + CM_PAR_W];
-          hn = buf[cur][pn]; rn = buf[cur][min(pn + 1 + lane, CM_SEQ_CAP - 1)];
+          hn = buf[cur][pn]; rn = buf[cur][min(pn + 1 + lane, CAP - 1)];
         }
         const int len = h.b;
         const bool valid = lane < len;
@@ -619,7 +621,7 @@ __global__ __launch_bounds__(1024) void k_sweep_par(SweepArgs a, const SeqRec* _
         // ---- wait until every trial of this row shows its turn (bounded: a logic error must not hang the GPU)
         unsigned spins = 0;
         while (true) {
-          const bool ok = !valid || (__hip_atomic_load(&cnt[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == turn);
+          const bool ok = !valid || ((int)cnt[k] == turn);
           if (__all(ok)) break;
           if (++spins > (1u << 18)) { if (lane == 0) *err_flag = 1; break; }
           __builtin_amdgcn_s_sleep(1);
@@ -642,7 +644,7 @@ __global__ __launch_bounds__(1024) void k_sweep_par(SweepArgs a, const SeqRec* _
           Rl[k] = rk + mu * (nl - r.x);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (valid) __hip_atomic_store(&cnt[k], turn + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (valid) cnt[k] = (TK)(turn + 1);
         h = hn; r = rn;
       }
     }
@@ -701,30 +703,44 @@ int cm_launch_sweep(cm_ctx* ctx, cm_problem* p, int it, const cm_options* o, hip
   hipStream_t st = ctx->stream;
   const int N = p->N;
   const int nbI = (N + 15) / 16, nbC = (p->K * 16 + 1023) / 1024;    // 16 rows per block; 16 lanes per trial column
+  // multi-wave chain when the ticket encoding fits (see k_sweep_par): variant 1 = 1024-record buffers + 32-bit tickets,
+  // variant 2 = 512-record buffers + 8-bit tickets (larger K); 0 = single-consumer kernel
+  static const bool no_par = getenv("CAVIAR_HIP_NO_PAR_SWEEP") != nullptr;
+  int par = 0;
+  if (!no_par && ctx->mb_n > CM_PAR_MIN_ROWS && p->max_row_len <= CM_WAVE && p->max_col_len <= 255 && p->nnz < (1 << 24)) {
+    if ((size_t)p->K * 12 <= 68 * 1024) par = 1;
+    else if ((size_t)p->K * 9 + 16 <= 96 * 1024) par = 2;
+  }
+  const int cap = (par == 2) ? 512 : CM_SEQ_CAP;
+  const int gran = cap - CM_WAVE - 1;                              // chunking granule: a chunk spans < gran + 65 <= cap records
+  const size_t lds_par = (par == 2) ? (size_t)p->K * 9 + 16 : (size_t)p->K * 12;
   static const bool split = getenv("CAVIAR_HIP_SPLIT_PRESWEEP") != nullptr;     // diagnostic: one launch per role (profiling only)
   for (int pass = 0; pass < (split ? 3 : 1); ++pass)
     hipLaunchKernelGGL(k_presweep, dim3(nbI + nbC + 1), dim3(1024), 0, st, a, N, p->K, nbI, nbC, split ? (1 << pass) : 7, p->order,
-                       p->col_ptr, p->csc_row, p->csc_pos, p->R, p->seq_n, p->seq_off, p->chunk_first, p->seq_meta, p->seq_pos);
-  // multi-wave chain for long chains when the ticket encoding fits (see k_sweep_par)
-  static const bool no_par = getenv("CAVIAR_HIP_NO_PAR_SWEEP") != nullptr;
-  const size_t lds_par = (size_t)p->K * (sizeof(double) + sizeof(int));
-  const bool par = !no_par && ctx->mb_n > CM_PAR_MIN_ROWS && p->max_row_len <= CM_WAVE && p->max_col_len <= 255 && p->nnz < (1 << 24) &&
-                   lds_par <= 68 * 1024;
+                       p->col_ptr, p->csc_row, p->csc_pos, p->R, p->seq_n, p->seq_off, p->chunk_first, p->seq_meta, p->seq_pos, gran);
   hipLaunchKernelGGL(k_seq_pack, dim3((N + 3) / 4), dim3(256), 0, st, a, p->seq_n, p->seq_off, p->seq_meta, (SeqRec*)p->packed,
                      par ? 1 : 0, p->seq_pos, p->col_ptr, p->csc_row);
   if (mid) CM_HIP(hipEventRecord(mid, st));
   const size_t lds = (size_t)p->K * sizeof(double);
   const long long nrec = (long long)p->N + p->nnz;             // allocation of `packed` (records) and of the chunk table
-  const int packed_cap = (int)std::min<long long>(CM_SEQ_CAP, nrec);
-  const int nchunks_cap = (int)std::min<long long>(CM_SEQ_LDS_CHUNKS - 1, nrec / 512 + 7);
-  if (par) {
+  const int packed_cap = (int)std::min<long long>(cap, nrec);
+  const int nchunks_cap = (int)std::min<long long>(CM_SEQ_LDS_CHUNKS - 1, nrec / 256 + 7);
+  if (par == 1) {
     static thread_local size_t attr_par = 0;
     if (lds_par > attr_par) {
-      CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_par), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_par));
+      CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_par<CM_SEQ_CAP, int>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_par));
       attr_par = lds_par;
     }
-    hipLaunchKernelGGL(k_sweep_par, dim3(1), dim3(1024), lds_par, st, a, (const SeqRec*)p->packed, packed_cap, nchunks_cap, p->seq_off,
-                       p->chunk_first, p->seq_meta, p->K, p->R, p->n_act + 2);
+    hipLaunchKernelGGL((k_sweep_par<CM_SEQ_CAP, int>), dim3(1), dim3(1024), lds_par, st, a, (const SeqRec*)p->packed, packed_cap, nchunks_cap,
+                       p->seq_off, p->chunk_first, p->seq_meta, p->K, p->R, p->n_act + 2);
+  } else if (par == 2) {
+    static thread_local size_t attr_par2 = 0;
+    if (lds_par > attr_par2) {
+      CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_par<512, uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_par));
+      attr_par2 = lds_par;
+    }
+    hipLaunchKernelGGL((k_sweep_par<512, uint8_t>), dim3(1), dim3(1024), lds_par, st, a, (const SeqRec*)p->packed, packed_cap, nchunks_cap,
+                       p->seq_off, p->chunk_first, p->seq_meta, p->K, p->R, p->n_act + 2);
   } else if (lds <= 88 * 1024) {     // 64 KiB of record buffers + R must fit the CU's 160 KiB
     static thread_local size_t attr_set = 0;      // raise the dynamic-LDS cap only when it has to grow
     if (lds > attr_set) {

@@ -97,11 +97,12 @@ def _sim_case(N, K, seed, **kw):
     return sim, default_priors(N)
 
 
-@pytest.mark.parametrize("N,K,iters", [(300, 1000, 50), (1000, 2000, 12), (2000, 4000, 3)])
+@pytest.mark.parametrize("N,K,iters", [(300, 1000, 50), (1000, 2000, 12), (2000, 4000, 3), (1000, 6000, 3)])
 def test_caviar_vs_oracle_bench_sizes(N, K, iters):
     """BASELINE configs[1] (full) and configs[2] (first 12 iterations: covers the ungated full-size solves, the gating
     transition and the shrinking active set) against the running-residual oracle on identical inputs; N = 2000 exercises
-    the two-round shuffle (N > 1625), the large-matrix Cholesky path (63 tiles) and K > 2048."""
+    the two-round shuffle (N > 1625), the large-matrix Cholesky path (63 tiles) and K > 2048; K = 6000 takes the multi-wave
+    chain with 8-bit tickets and 512-record buffers."""
     from circuitmap_amd.optimise import caviar
     from oracle import caviar_oracle as co
     sim, pri = _sim_case(N, K, 1000 + N)
