@@ -169,33 +169,40 @@ __device__ __forceinline__ int post_single_body(const double* __restrict__ y, co
 // (quirk 11) so elements are classed by y == 0, y == 1, 0 < y < 1.
 // ------------------------------------------------------------------------------------------------
 
+// full-precision reciprocal from the hardware estimate + two Newton steps (normal-range operands)
+__device__ __forceinline__ double cm_rcp(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
+}
+
 __device__ __forceinline__ void inv2x2(double h11, double h12, double h21, double h22, double o[4]) {
-  // LU with partial pivoting on the 2x2 (what LAPACK getrf/getri do for jnp.linalg.inv)
+  // LU with partial pivoting on the 2x2 (the structure of LAPACK getrf/getri behind jnp.linalg.inv); the two pivots are
+  // inverted once each (reciprocal + Newton) instead of dividing by them repeatedly -- this sits on the Newton chain
   double a = h11, b = h12, c = h21, d = h22;
-  bool sw = fabs(c) > fabs(a);
+  const bool sw = fabs(c) > fabs(a);
   if (sw) { double t = a; a = c; c = t; t = b; b = d; d = t; }
-  const double l = c / a;
-  const double u22 = d - l * b;
-  // solve for unit vectors (with row swap applied to the right-hand side)
-  // column 0 of inverse: rhs = P e0
+  const double ra = cm_rcp(a);
+  const double l = c * ra;
+  const double ru = cm_rcp(d - l * b);
+  // columns of the inverse: solve for P e0 and P e1
   double r0 = sw ? 0.0 : 1.0, r1 = sw ? 1.0 : 0.0;
-  double y1 = r1 - l * r0;
-  double x1 = y1 / u22;
-  double x0 = (r0 - b * x1) / a;
-  o[0] = x0; o[2] = x1;
+  double x1 = (r1 - l * r0) * ru;
+  o[0] = (r0 - b * x1) * ra; o[2] = x1;
   r0 = sw ? 1.0 : 0.0; r1 = sw ? 0.0 : 1.0;
-  y1 = r1 - l * r0;
-  x1 = y1 / u22;
-  x0 = (r0 - b * x1) / a;
-  o[1] = x0; o[3] = x1;
+  x1 = (r1 - l * r0) * ru;
+  o[1] = (r0 - b * x1) * ra; o[3] = x1;
 }
 
 template <int SEG>
 __device__ __forceinline__ double phi_nll(double p0, double p1, double val, double n0, double n1, double smid, double nmid,
-                                          bool lane_on, double pr0, double pr1, const double prec[4], double t) {
+                                          bool lane_on, double pr0, double pr1, const double prec[4], double t, double* sig_out) {
   double tot = 0.0;
+  *sig_out = 0.0;
   if (lane_on) {
     const double s = cm_sigmoid(p0 * val - p1);
+    *sig_out = s;
     const double ls = log(s), l1s = log(1.0 - s);
     if (n0 > 0.0) tot += n0 * cm_nan_to_num(0.0 * ls + 1.0 * l1s);
     if (n1 > 0.0) tot += n1 * cm_nan_to_num(1.0 * ls + 0.0 * l1s);
@@ -250,10 +257,13 @@ __device__ __forceinline__ void phi_body(int n, int lane, const double* __restri
   const double t = 1e1, alpha = 0.25;
   double p0 = pr0, p1 = pr1;                     // caviar.py:305: restart from the prior every call (quirk 3)
   double cov[4] = {0, 0, 0, 0};
+  double fcur = 0.0;                              // sigmoid(p0 * val - p1) of this lane's value at the current phi
+  bool have_f = false;
   for (int stepi = 0; stepi < 10; ++stepi) {     // caviar.py:308
     double j1 = 0.0, j2 = 0.0, h11 = 0.0, h12 = 0.0, h22 = 0.0;
     if (on) {
-      const double f = cm_sigmoid(p0 * val - p1);
+      // the accepted candidate of the previous step evaluated exactly this sigmoid (same expression, same operands)
+      const double f = have_f ? fcur : cm_sigmoid(p0 * val - p1);
       const double r = sy - cnt * f;
       j1 = -val * r; j2 = r;
       const double ff = cnt * f * (1.0 - f);
@@ -277,15 +287,21 @@ __device__ __forceinline__ void phi_body(int n, int lane, const double* __restri
       const bool is_f0 = first && ev == 0;
       const double st = is_f0 ? 0.0 : ldexp(1.0, -b);
       const double q0 = is_f0 ? p0 : p0 + st * v0, q1 = is_f0 ? p1 : p1 + st * v1;
-      const double fv = phi_nll<SEG>(q0, q1, val, n0, n1, smid, nmid, on, pr0, pr1, prec, t);
+      double sg;
+      const double fv = phi_nll<SEG>(q0, q1, val, n0, n1, smid, nmid, on, pr0, pr1, prec, t, &sg);
       if (first) f0 = cm_readlane_f64(fv, 0);
       const double rhs = f0 + alpha * st * Jv;
       const bool ok = !is_f0 && b <= 39 && !(isnan(fv) || fv > rhs);
       const unsigned long long m = __ballot(ok);
-      if (m) accepted = (first ? base - 1 : base) + (int)(__ffsll((long long)m) - 1) / SEG;
+      if (m) {
+        const int seg = (int)(__ffsll((long long)m) - 1) / SEG;          // first accepting segment of this round
+        accepted = (first ? base - 1 : base) + seg;
+        fcur = __shfl(sg, seg * SEG + g, CM_WAVE);                        // its sigmoid for this lane's value
+      }
       base += first ? E - 1 : E;
       first = false;
     }
+    have_f = accepted >= 0;                        // b = 40 is taken without an evaluation: recompute next step
     if (accepted < 0) accepted = 40;
     const double step = ldexp(1.0, -accepted);
     p0 += step * v0; p1 += step * v1;                                             // caviar.py:301
