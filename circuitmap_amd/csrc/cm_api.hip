@@ -73,6 +73,7 @@ extern "C" int cm_ctx_destroy(cm_ctx* c) {
   for (auto& e : c->ev) if (e) hipEventDestroy(e);
   for (auto& e : c->pool) hipEventDestroy(e);
   if (c->h_pinned) hipHostFree(c->h_pinned);
+  if (c->h_stage) hipHostFree(c->h_stage);
   if (c->own_stream) hipStreamDestroy(c->stream);
   delete c;
   return CM_OK;
@@ -101,8 +102,8 @@ extern "C" int cm_problem_destroy(cm_problem* p) {
   hipSetDevice(p->ctx->device);
   hipStreamSynchronize(p->ctx->stream);
   void* ptrs[] = {p->y, p->ss, p->sum_y, p->vals, p->row_ptr, p->col, p->grp, p->rowcnt, p->col_ptr, p->csc_row, p->csc_pos,
-                  p->mask, p->lam, p->mu, p->beta, p->mu_prior, p->beta_prior, p->phi, p->phi_cov, p->phi_prior, p->phi_cov_prior,
-                  p->scal, p->R, p->colany, p->z, p->mcE, p->rs, p->act_idx, p->act_inv, p->n_act, p->orders_all, p->orders_tmp, p->inv_all, p->wtab,
+                  p->mask, p->slab, p->pslab, p->phi, p->phi_cov,
+                  p->R, p->colany, p->mcE, p->rs, p->act_idx, p->act_inv, p->n_act, p->orders_all, p->orders_tmp, p->inv_all, p->wtab,
                   p->keys, p->uexp, p->A, p->X, p->Lf, p->Dinv, p->rhs, p->seq_n, p->seq_off, p->seq_pos, p->chunk_first,
                   p->seq_meta, p->packed};
   for (void* q : ptrs) if (q) hipFree(q);
@@ -140,17 +141,19 @@ extern "C" int cm_problem_create(cm_ctx* ctx, int32_t N, int32_t K, int32_t T, c
 
   p->ld = ((N + CM_TILE - 1) / CM_TILE) * CM_TILE;
   const size_t ld = p->ld;
-  if ((rc = dmalloc(&p->mask, K)) || (rc = dmalloc(&p->lam, (size_t)p->nnz)) || (rc = dmalloc(&p->mu, N)) || (rc = dmalloc(&p->beta, N)) ||
-      (rc = dmalloc(&p->mu_prior, N)) || (rc = dmalloc(&p->beta_prior, N)) || (rc = dmalloc(&p->phi, 2 * (size_t)N)) ||
-      (rc = dmalloc(&p->phi_cov, 4 * (size_t)N)) || (rc = dmalloc(&p->phi_prior, 2 * (size_t)N)) ||
-      (rc = dmalloc(&p->phi_cov_prior, 4 * (size_t)N)) || (rc = dmalloc(&p->scal, CM_S_COUNT)) || (rc = dmalloc(&p->R, K)) ||
-      (rc = dmalloc(&p->colany, K)) || (rc = dmalloc(&p->z, K)) || (rc = dmalloc(&p->mcE, (size_t)N * CM_MAX_VALS)) ||
+  if ((rc = dmalloc(&p->mask, K)) || (rc = dmalloc(&p->slab, 2 * (size_t)N + K + (size_t)p->nnz)) ||
+      (rc = dmalloc(&p->pslab, 8 * (size_t)N + CM_S_COUNT)) || (rc = dmalloc(&p->phi, 2 * (size_t)N)) ||
+      (rc = dmalloc(&p->phi_cov, 4 * (size_t)N)) || (rc = dmalloc(&p->R, K)) ||
+      (rc = dmalloc(&p->colany, K)) || (rc = dmalloc(&p->mcE, (size_t)N * CM_MAX_VALS)) ||
       (rc = dmalloc(&p->rs, 4 * (size_t)N)) || (rc = dmalloc(&p->act_idx, N)) || (rc = dmalloc(&p->act_inv, N)) ||
       (rc = dmalloc(&p->n_act, 4)) || (rc = dmalloc(&p->A, ld * ld)) || (rc = dmalloc(&p->X, ld * ld)) || (rc = dmalloc(&p->Lf, ld * ld)) ||
       (rc = dmalloc(&p->Dinv, ld * CM_TILE)) || (rc = dmalloc(&p->rhs, 2 * ld)) || (rc = dmalloc(&p->seq_n, N)) ||
       (rc = dmalloc(&p->seq_off, (size_t)N + 1)) || (rc = dmalloc(&p->seq_pos, N)) || (rc = dmalloc(&p->chunk_first, ((size_t)N + p->nnz) / 256 + 8)) ||
       (rc = dmalloc(&p->seq_meta, 8)) || (rc = dmalloc((char**)&p->packed, ((size_t)N + p->nnz) * 32)))
     return fail(rc);
+  p->mu = p->slab; p->beta = p->slab + N; p->z = p->slab + 2 * (size_t)N; p->lam = p->slab + 2 * (size_t)N + K;
+  p->mu_prior = p->pslab; p->beta_prior = p->pslab + N; p->phi_prior = p->pslab + 2 * (size_t)N;
+  p->phi_cov_prior = p->pslab + 4 * (size_t)N; p->scal = p->pslab + 8 * (size_t)N;
   if (hipMemsetAsync(p->mcE, 0, (size_t)N * CM_MAX_VALS * sizeof(double), st) != hipSuccess) return fail(CM_ERR_HIP);
   if (hipStreamSynchronize(st) != hipSuccess) { cm_set_error("prologue failed: %s", hipGetErrorString(hipGetLastError())); return fail(CM_ERR_HIP); }
   *out = p;
@@ -190,28 +193,44 @@ extern "C" int cm_pava_last(const double* y, int32_t n, double* out) {
   return CM_OK;
 }
 
+static int stage_reserve(cm_ctx* ctx, size_t bytes) {
+  if (ctx->h_stage_bytes >= bytes) return CM_OK;
+  if (ctx->h_stage) hipHostFree(ctx->h_stage);
+  ctx->h_stage = nullptr; ctx->h_stage_bytes = 0;
+  CM_HIP(hipHostMalloc(&ctx->h_stage, bytes, hipHostMallocDefault));
+  ctx->h_stage_bytes = bytes;
+  return CM_OK;
+}
+
+// priors -> device in ONE pinned transfer (mu_prior | beta_prior | phi_prior | phi_cov_prior | scalars), then the state is
+// initialised from them on the device (caviar.py:44-49)
+__global__ __launch_bounds__(256) void k_state_from_priors(const double* __restrict__ pslab, int N, double* __restrict__ mu,
+                                                            double* __restrict__ beta, double* __restrict__ phi, double* __restrict__ phi_cov) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) { mu[i] = pslab[i]; beta[i] = pslab[N + i]; }
+  if (i < 2 * N) phi[i] = pslab[2 * (size_t)N + i];
+  if (i < 4 * N) phi_cov[i] = pslab[4 * (size_t)N + i];
+}
+
 static int upload_priors(cm_ctx* ctx, cm_problem* p, const cm_priors* pr) {
   hipStream_t st = ctx->stream;
-  const size_t N = p->N;
-  CM_HIP(hipMemcpyAsync(p->mu_prior, pr->mu, N * sizeof(double), hipMemcpyHostToDevice, st));
-  CM_HIP(hipMemcpyAsync(p->beta_prior, pr->beta, N * sizeof(double), hipMemcpyHostToDevice, st));
-  CM_HIP(hipMemcpyAsync(p->phi_prior, pr->phi, 2 * N * sizeof(double), hipMemcpyHostToDevice, st));
-  CM_HIP(hipMemcpyAsync(p->phi_cov_prior, pr->phi_cov, 4 * N * sizeof(double), hipMemcpyHostToDevice, st));
-  CM_HIP(hipMemcpyAsync(p->phi, pr->phi, 2 * N * sizeof(double), hipMemcpyHostToDevice, st));          // caviar.py:48-49
-  CM_HIP(hipMemcpyAsync(p->phi_cov, pr->phi_cov, 4 * N * sizeof(double), hipMemcpyHostToDevice, st));
-  CM_HIP(hipMemcpyAsync(p->mu, pr->mu, N * sizeof(double), hipMemcpyHostToDevice, st));                // caviar.py:44-45
-  CM_HIP(hipMemcpyAsync(p->beta, pr->beta, N * sizeof(double), hipMemcpyHostToDevice, st));
-  double h[CM_S_COUNT] = {0};
-  h[CM_S_SHAPE] = pr->shape; h[CM_S_RATE] = pr->rate; h[CM_S_SPONT_RATE] = 0.0;
-  h[CM_S_SHAPE_PRIOR] = pr->shape; h[CM_S_RATE_PRIOR] = pr->rate;
-  CM_HIP(hipMemcpyAsync(p->scal, h, sizeof(h), hipMemcpyHostToDevice, st));
-  CM_HIP(hipStreamSynchronize(st));   // h is a stack buffer
+  const size_t N = p->N, n = 8 * N + CM_S_COUNT;
+  CM_HIP(hipStreamSynchronize(st));                 // the staging buffer may still feed an earlier transfer of this context
+  CM_TRY(stage_reserve(ctx, std::max(n, 2 * N + (size_t)p->K + (size_t)p->nnz) * sizeof(double)));
+  double* h = (double*)ctx->h_stage;
+  memcpy(h, pr->mu, N * 8); memcpy(h + N, pr->beta, N * 8); memcpy(h + 2 * N, pr->phi, 2 * N * 8); memcpy(h + 4 * N, pr->phi_cov, 4 * N * 8);
+  double* sc = h + 8 * N;
+  for (int i = 0; i < CM_S_COUNT; ++i) sc[i] = 0.0;
+  sc[CM_S_SHAPE] = pr->shape; sc[CM_S_RATE] = pr->rate; sc[CM_S_SHAPE_PRIOR] = pr->shape; sc[CM_S_RATE_PRIOR] = pr->rate;
+  CM_HIP(hipMemcpyAsync(p->pslab, h, n * sizeof(double), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_state_from_priors, dim3((unsigned)((4 * N + 255) / 256)), dim3(256), 0, st, p->pslab, (int)N, p->mu, p->beta, p->phi, p->phi_cov);
+  CM_HIP(hipGetLastError());
   return CM_OK;
 }
 
 // reconnect_spont_cells, caviar.py:102-144.  Host C++ on the compressed rows (one-off, after the last iteration).
-static void host_reconnect(const cm_problem* p, std::vector<double>& mu, std::vector<double>& beta, std::vector<double>& lam,
-                           std::vector<double>& z, double minimax_spk_prob, double minimum_spike_count, int verbose) {
+static void host_reconnect(const cm_problem* p, double* mu, double* beta, double* lam, double* z, double minimax_spk_prob,
+                           double minimum_spike_count, int verbose) {
   const int N = p->N, K = p->K, V = p->V;
   const int P = V - 1;
   std::vector<int> disc;
@@ -437,20 +456,15 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
   CM_HIP(hipEventRecord(ctx->ev[2], st));
 
   if (o->fn_scan) {                                                  // caviar.py:94-98
-    const size_t nnz = p->nnz;
-    std::vector<double> mu(N), beta(N), lam(nnz ? nnz : 1), z(K);
-    CM_HIP(hipMemcpyAsync(mu.data(), p->mu, (size_t)N * 8, hipMemcpyDeviceToHost, st));
-    CM_HIP(hipMemcpyAsync(beta.data(), p->beta, (size_t)N * 8, hipMemcpyDeviceToHost, st));
-    if (nnz) CM_HIP(hipMemcpyAsync(lam.data(), p->lam, nnz * 8, hipMemcpyDeviceToHost, st));
-    CM_HIP(hipMemcpyAsync(z.data(), p->z, (size_t)K * 8, hipMemcpyDeviceToHost, st));
+    // mu | beta | z | lam are one device slab: one pinned copy down, the host scan, one copy back, final update_phi
+    const size_t nslab = 2 * (size_t)N + K + (size_t)p->nnz;
+    CM_TRY(stage_reserve(ctx, nslab * sizeof(double)));
+    double* h = (double*)ctx->h_stage;
+    CM_HIP(hipMemcpyAsync(h, p->slab, nslab * sizeof(double), hipMemcpyDeviceToHost, st));
     CM_HIP(hipStreamSynchronize(st));
-    host_reconnect(p, mu, beta, lam, z, o->msrmp, o->minimum_spike_count, o->verbose);
-    CM_HIP(hipMemcpyAsync(p->mu, mu.data(), (size_t)N * 8, hipMemcpyHostToDevice, st));
-    CM_HIP(hipMemcpyAsync(p->beta, beta.data(), (size_t)N * 8, hipMemcpyHostToDevice, st));
-    if (nnz) CM_HIP(hipMemcpyAsync(p->lam, lam.data(), nnz * 8, hipMemcpyHostToDevice, st));
-    CM_HIP(hipMemcpyAsync(p->z, z.data(), (size_t)K * 8, hipMemcpyHostToDevice, st));
+    host_reconnect(p, h, h + N, h + 2 * (size_t)N + K, h + 2 * (size_t)N, o->msrmp, o->minimum_spike_count, o->verbose);
+    CM_HIP(hipMemcpyAsync(p->slab, h, nslab * sizeof(double), hipMemcpyHostToDevice, st));
     CM_TRY(cm_launch_update_phi(ctx, p, st));
-    CM_HIP(hipStreamSynchronize(st));   // host vectors go out of scope
   }
   CM_HIP(hipEventRecord(ctx->ev[3], st));
   CM_HIP(hipStreamSynchronize(st));
@@ -635,7 +649,7 @@ extern "C" int cm_k_reconnect(cm_ctx* ctx, int32_t N, int32_t K, const double* s
   std::vector<double> vm(mu, mu + N), vb(beta, beta + N), vz(z, z + K), vl(nnz ? nnz : 1);
   for (int n = 0; n < N; ++n)
     for (int e = p->h_row_ptr[n]; e < p->h_row_ptr[n + 1]; ++e) vl[e] = lam[(size_t)n * K + p->h_col[e]];
-  host_reconnect(p, vm, vb, vl, vz, minimax_spk_prob, minimum_spike_count, 0);
+  host_reconnect(p, vm.data(), vb.data(), vl.data(), vz.data(), minimax_spk_prob, minimum_spike_count, 0);
   for (int n = 0; n < N; ++n)
     for (int e = p->h_row_ptr[n]; e < p->h_row_ptr[n + 1]; ++e) lam[(size_t)n * K + p->h_col[e]] = vl[e];
   std::copy(vm.begin(), vm.end(), mu); std::copy(vb.begin(), vb.end(), beta); std::copy(vz.begin(), vz.end(), z);

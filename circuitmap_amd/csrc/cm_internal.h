@@ -40,6 +40,8 @@ struct cm_ctx {
   int mb_n = 0, mb_flag = 0;     // last values read from the mailbox (active-set size, not-SPD flag)
   bool use_mailbox = true;
   int num_cus = 256;
+  void* h_stage = nullptr;        // pinned staging buffer (priors upload, fn_scan round trip), grown on demand
+  size_t h_stage_bytes = 0;
   std::vector<hipEvent_t> pool;   // per-iteration events (CM_EV_PER_IT per iteration): phase stamps + cross-stream edges
 };
 
@@ -71,6 +73,8 @@ struct cm_problem {
   std::vector<double> h_vals;
   // --- CAVIaR state ---
   uint8_t* mask = nullptr;    // [K] lam_mask
+  double* slab = nullptr;     // one allocation: mu | beta | z | lam (so the false-negative scan moves them in one copy each way)
+  double* pslab = nullptr;    // one allocation: mu_prior | beta_prior | phi_prior | phi_cov_prior | scal
   double* lam = nullptr;      // [nnz] CSR order
   double* mu = nullptr;       // [N]
   double* beta = nullptr;     // [N] posterior variance (reference's "beta")
