@@ -155,6 +155,45 @@ __global__ __launch_bounds__(256) void k_chol_trsm(const double* __restrict__ A,
   for (int reg = 0; reg < 4; ++reg) out[(size_t)BLK_ROW(rb, lane, reg) * ld + BLK_COL(cb, lane)] = c[reg];
 }
 
+// Large matrices (more than 48 tiles): the trailing update is bandwidth-bound -- every panel re-reads and re-writes the
+// whole trailing matrix -- so it gets its own lean kernel: 256-thread workgroups, two LDS tiles (the solved panel tiles X_i,
+// X_l from Lf), one 16x16 output block per wave on the matrix cores, output tile prefetched into registers.  Many workgroups
+// per CU keep enough bytes in flight; block 0 owns the diagonal tile (j+1, j+1) and factors it in place.
+__global__ __launch_bounds__(256) void k_chol_bulk(double* __restrict__ A, const double* __restrict__ Lf, int ld, int j,
+                                                   double* __restrict__ Dinv, int* __restrict__ flag) {
+  __shared__ double Sm[3][TS][TP];
+  double (*Xi)[TP] = Sm[0], (*Xl)[TP] = Sm[1];
+  // linear block id -> (i, l), 0 <= l' <= i' in the trailing tile rows; id 0 is the diagonal tile (j+1, j+1)
+  const int t = blockIdx.x;
+  int ip = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while ((ip + 1) * (ip + 2) / 2 <= t) ++ip;
+  while (ip * (ip + 1) / 2 > t) --ip;
+  const int lp = t - ip * (ip + 1) / 2;
+  const int i = j + 1 + ip, l = j + 1 + lp;
+  const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE, rb = wave >> 1, cb = wave & 1;
+  double* out = A + (size_t)i * TS * ld + (size_t)l * TS;
+  double oprev[4];
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) oprev[reg] = out[(size_t)BLK_ROW(rb, lane, reg) * ld + BLK_COL(cb, lane)];
+  tile_load(Xi, Lf + (size_t)i * TS * ld + (size_t)j * TS, ld);
+  if (l != i) tile_load(Xl, Lf + (size_t)l * TS * ld + (size_t)j * TS, ld);
+  __syncthreads();
+  cm_d4 c = {0.0, 0.0, 0.0, 0.0};
+  c = (l != i) ? blk_mfma_nt(c, Xi, Xl, rb, cb, lane) : blk_mfma_nt(c, Xi, Xi, rb, cb, lane);
+  if (t != 0) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) out[(size_t)BLK_ROW(rb, lane, reg) * ld + BLK_COL(cb, lane)] = oprev[reg] - c[reg];
+    return;
+  }
+  // block 0: the updated diagonal tile never goes back to HBM -- factor it here, next to the bulk of the update, and
+  // publish L^-1 for the next panel's solve (the tile's own copy in A is dead after this)
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) Sm[2][BLK_ROW(rb, lane, reg)][BLK_COL(cb, lane)] = oprev[reg] - c[reg];
+  __syncthreads();                                 // all reads of Xi are done: reuse tiles 0 and 1 as scratch
+  tile_linv(Sm[2], Sm[0], Sm[1], flag, 256);
+  tile_store(Dinv + (size_t)(j + 1) * TS * TS, TS, Sm[1]);
+}
+
 // Panel j in ONE launch (1024-thread workgroups, one per trailing tile (i, l), j < l <= i):
 //   X_i = A[i][j] L_jj^-T, X_l = A[l][j] L_jj^-T     (panel solve, recomputed per workgroup from the read-only panel tiles)
 //   A[i][l] -= X_i X_l^T                             (trailing update, in place: the tile is owned by this workgroup)
@@ -411,9 +450,9 @@ int cm_solve_launch(cm_ctx* ctx, cm_problem* p, int na) {
   hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(1024), 0, st, A, ld, p->Dinv, p->n_act + 1);
   for (int j = 0; j + 1 < nblk; ++j) {
     const int t = nblk - j - 1;
-    if (nblk > 48) {                                 // large: solve the panel once, then a pure trailing update
+    if (nblk > 48) {                                 // large: solve the panel once, then the bandwidth-lean trailing update (block 0 factors the next diagonal tile)
       hipLaunchKernelGGL(k_chol_trsm, dim3(t), dim3(256), 0, st, A, p->Lf, ld, p->Dinv, j);
-      hipLaunchKernelGGL(k_chol_panel<true>, dim3(t * (t + 1) / 2), dim3(1024), 0, st, A, p->Lf, ld, p->Dinv, j, nblk, p->n_act + 1);
+      hipLaunchKernelGGL(k_chol_bulk, dim3(t * (t + 1) / 2), dim3(256), 0, st, A, p->Lf, ld, j, p->Dinv, p->n_act + 1);
     } else {                                         // small / medium: one launch per panel
       hipLaunchKernelGGL(k_chol_panel<false>, dim3(t * (t + 1) / 2), dim3(1024), 0, st, A, p->Lf, ld, p->Dinv, j, nblk, p->n_act + 1);
     }
