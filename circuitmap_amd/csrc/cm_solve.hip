@@ -129,14 +129,57 @@ __device__ __forceinline__ void tile_linv(double (*C)[TP], double (*Rt)[TP], dou
   __syncthreads();
 }
 
+// Same elimination with the tile in REGISTERS: thread (r = tid & 31, g = tid >> 5) of the first 256 threads owns columns
+// 4 g .. 4 g + 3 of row r.  It runs in place: once column c of C is eliminated its slot holds column c of the right-hand
+// block (slot k of row i becomes -m_i at pivot k), so a row is always 32 live values.  Per pivot the pivot row and the pivot
+// column are broadcast through a double-buffered 64 doubles of LDS -- ONE 4-wave barrier, 4 LDS operations and 4 FMAs per
+// thread per pivot instead of an LDS read-modify-write per element.  C is read, Li written.  All of the first 256 threads of
+// the workgroup must call it and every other wave must have retired (a retired wave no longer counts at s_barrier).
+__device__ __forceinline__ void tile_linv_reg(const double (*C)[TP], double (*Li)[TP], int* __restrict__ flag) {
+  __shared__ __attribute__((aligned(16))) double rowv[2][TS];
+  __shared__ double colv[2][TS], dk[TS];
+  const int r = threadIdx.x & 31, g = threadIdx.x >> 5;
+  double v[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) v[c] = C[r][4 * g + c];
+#pragma unroll
+  for (int k = 0; k < TS; ++k) {
+    const int b = k & 1;
+    if (r == k) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) rowv[b][4 * g + c] = v[c];
+    }
+    if (g == (k >> 2)) colv[b][r] = v[k & 3];
+    __syncthreads();
+    const double d = rowv[b][k];
+    // 1/d sits on the 32-pivot dependency chain: hardware reciprocal estimate + two Newton steps (full double precision for
+    // the normal-range pivots of an SPD tile) instead of the ~3x longer IEEE division sequence
+    double rd = __builtin_amdgcn_rcp(d);
+    rd = fma(fma(-d, rd, 1.0), rd, rd);
+    rd = fma(fma(-d, rd, 1.0), rd, rd);
+    if (threadIdx.x == 0) { dk[k] = d; if (!(d > 0.0)) *flag = 1; }   // not SPD (also catches NaN)
+    const double m = (r > k) ? colv[b][r] * rd : 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = fma(-m, rowv[b][4 * g + c], v[c]);
+    if (g == (k >> 2) && r > k) v[k & 3] = -m;
+  }
+  __syncthreads();
+  const double rs = 1.0 / sqrt(dk[r]);               // L^-1 = D^-1/2 Ltilde^-1
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int col = 4 * g + c;
+    Li[r][col] = (col < r) ? v[c] * rs : ((col == r) ? rs : 0.0);
+  }
+  __syncthreads();
+}
+
 // factor the first diagonal tile
-__global__ __launch_bounds__(1024) void k_chol_first(double* __restrict__ A, int ld, double* __restrict__ Dinv, int* __restrict__ flag) {
-  __shared__ double C[TS][TP], Rt[TS][TP], Li[TS][TP];
+__global__ __launch_bounds__(256) void k_chol_first(double* __restrict__ A, int ld, double* __restrict__ Dinv, int* __restrict__ flag) {
+  __shared__ double C[TS][TP], Li[TS][TP];
   tile_load(C, A, ld);
   __syncthreads();
-  if (threadIdx.x >= CM_LINV_THREADS) return;
-  tile_linv(C, Rt, Li, flag, CM_LINV_THREADS);
-  for (int i = threadIdx.x; i < TS * TS; i += CM_LINV_THREADS) Dinv[(size_t)(i / TS) * TS + (i % TS)] = Li[i / TS][i % TS];
+  tile_linv_reg(C, Li, flag);
+  for (int i = threadIdx.x; i < TS * TS; i += 256) Dinv[(size_t)(i / TS) * TS + (i % TS)] = Li[i / TS][i % TS];
 }
 
 // panel solve for large matrices: Lf[i][j] = A[i][j] * L_jj^-T for i > j   (one 256-thread workgroup per tile row)
@@ -189,8 +232,8 @@ __global__ __launch_bounds__(256) void k_chol_bulk(double* __restrict__ A, const
   // publish L^-1 for the next panel's solve (the tile's own copy in A is dead after this)
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) Sm[2][BLK_ROW(rb, lane, reg)][BLK_COL(cb, lane)] = oprev[reg] - c[reg];
-  __syncthreads();                                 // all reads of Xi are done: reuse tiles 0 and 1 as scratch
-  tile_linv(Sm[2], Sm[0], Sm[1], flag, 256);
+  __syncthreads();                                 // all reads of Xi are done: tile 1 receives L^-1
+  tile_linv_reg(Sm[2], Sm[1], flag);
   tile_store(Dinv + (size_t)(j + 1) * TS * TS, TS, Sm[1]);
 }
 
@@ -256,10 +299,10 @@ __global__ __launch_bounds__(1024) void k_chol_panel(double* __restrict__ A, dou
   }
   if (diag) {
     __syncthreads();                                 // Pi holds the updated SPD tile; Lf store of this workgroup is issued
-    if (threadIdx.x >= CM_LINV_THREADS) return;
-    tile_linv(Pi, Pl, Li, flag, CM_LINV_THREADS);
+    if (threadIdx.x >= 256) return;
+    tile_linv_reg(Pi, Li, flag);
     double* dst = Dinv + (size_t)(j + 1) * TS * TS;
-    for (int q = threadIdx.x; q < TS * TS; q += CM_LINV_THREADS) dst[(size_t)(q / TS) * TS + (q % TS)] = Li[q / TS][q % TS];
+    for (int q = threadIdx.x; q < TS * TS; q += 256) dst[(size_t)(q / TS) * TS + (q % TS)] = Li[q / TS][q % TS];
   }
 }
 
@@ -447,7 +490,7 @@ int cm_solve_launch(cm_ctx* ctx, cm_problem* p, int na) {
   hipLaunchKernelGGL(k_build_precision, dim3(ld), dim3(64), (size_t)ld * sizeof(double), st, p->lam, p->row_ptr, p->col, p->col_ptr,
                      p->csc_row, p->csc_pos, p->act_idx, p->act_inv, p->rs, p->scal, p->mu_prior, p->beta_prior, na, ld, A, p->rhs);
   // Cholesky
-  hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(1024), 0, st, A, ld, p->Dinv, p->n_act + 1);
+  hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(256), 0, st, A, ld, p->Dinv, p->n_act + 1);
   for (int j = 0; j + 1 < nblk; ++j) {
     const int t = nblk - j - 1;
     if (nblk > 48) {                                 // large: solve the panel once, then the bandwidth-lean trailing update (block 0 factors the next diagonal tile)
