@@ -151,16 +151,21 @@ __device__ __forceinline__ void tile_linv_reg(const double (*C)[TP], double (*Li
     }
     if (g == (k >> 2)) colv[b][r] = v[k & 3];
     __syncthreads();
+    // all LDS reads of the pivot are issued together, before the reciprocal chain (no branch on r > k: a select)
     const double d = rowv[b][k];
+    const double cv = colv[b][r];
+    double rw[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) rw[c] = rowv[b][4 * g + c];
     // 1/d sits on the 32-pivot dependency chain: hardware reciprocal estimate + two Newton steps (full double precision for
     // the normal-range pivots of an SPD tile) instead of the ~3x longer IEEE division sequence
     double rd = __builtin_amdgcn_rcp(d);
     rd = fma(fma(-d, rd, 1.0), rd, rd);
     rd = fma(fma(-d, rd, 1.0), rd, rd);
     if (threadIdx.x == 0) { dk[k] = d; if (!(d > 0.0)) *flag = 1; }   // not SPD (also catches NaN)
-    const double m = (r > k) ? colv[b][r] * rd : 0.0;
+    const double m = (r > k) ? cv * rd : 0.0;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) v[c] = fma(-m, rowv[b][4 * g + c], v[c]);
+    for (int c = 0; c < 4; ++c) v[c] = fma(-m, rw[c], v[c]);
     if (g == (k >> 2) && r > k) v[k & 3] = -m;
   }
   __syncthreads();
