@@ -1,4 +1,4 @@
-"""ctypes binding of libcaviar_hip.so (include/caviar_hip.h).
+"""ctypes binding of libcaviar_hip.so (include/caviar_hip.h, include/nwd_hip.h).
 
 The product path has NO CPU fallback: if the HIP library is missing or no gfx950 device is
 visible, loading / context creation raises.
@@ -48,7 +48,18 @@ class CmTimings(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
-# every symbol include/caviar_hip.h declares: (restype, argtypes)
+_fp = C.POINTER(C.c_float)
+
+
+class CmNwdBlock(C.Structure):
+    _fields_ = [("weight", _fp), ("bias", _fp), ("bn_weight", _fp), ("bn_bias", _fp), ("bn_mean", _fp), ("bn_var", _fp)]
+
+
+class CmNwdParams(C.Structure):
+    _fields_ = [("dblock", CmNwdBlock * 4), ("ublock", CmNwdBlock * 4), ("conv", CmNwdBlock), ("bn_eps", C.c_float)]
+
+
+# every symbol include/caviar_hip.h and include/nwd_hip.h declare: (restype, argtypes)
 SYMBOLS = {
     "cm_last_error": (C.c_char_p, []),
     "cm_version": (C.c_char_p, []),
@@ -57,6 +68,9 @@ SYMBOLS = {
     "cm_ctx_create": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "cm_ctx_destroy": (C.c_int, [C.c_void_p]),
     "cm_ctx_synchronize": (C.c_int, [C.c_void_p]),
+    "cm_mem_alloc": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "cm_mem_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cm_mem_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),
     "cm_problem_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "cm_problem_destroy": (C.c_int, [C.c_void_p]),
     "cm_problem_nnz": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
@@ -70,6 +84,13 @@ SYMBOLS = {
     "cm_k_update_phi": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, _dp, _dp, _dp, _dp]),
     "cm_k_reconnect": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_double]),
     "cm_k_rng_streams": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, _ip, _dp]),
+    # include/nwd_hip.h
+    "cm_nwd_create": (C.c_int, [C.c_void_p, C.POINTER(CmNwdParams), C.POINTER(C.c_void_p)]),
+    "cm_nwd_destroy": (None, [C.c_void_p]),
+    "cm_nwd_max_trace_len": (C.c_int, []),
+    "cm_nwd_min_trace_len": (C.c_int, []),
+    "cm_nwd_demix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                               C.c_int, C.POINTER(C.c_float)]),
 }
 
 _lib = None
@@ -121,6 +142,24 @@ class Context:
 
     def synchronize(self):
         check(self.lib.cm_ctx_synchronize(self.handle))
+
+    # device buffers without torch (cm_mem_*): addresses are plain ints
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        check(self.lib.cm_mem_alloc(self.handle, int(nbytes), C.byref(p)))
+        return p.value or 0
+
+    def free(self, ptr):
+        check(self.lib.cm_mem_free(self.handle, C.c_void_p(ptr)))
+
+    def upload(self, ptr, array):
+        a = np.ascontiguousarray(array)
+        check(self.lib.cm_mem_copy(self.handle, C.c_void_p(ptr), a.ctypes.data_as(C.c_void_p), a.nbytes, 1))
+
+    def download(self, ptr, array):
+        assert array.flags["C_CONTIGUOUS"]
+        check(self.lib.cm_mem_copy(self.handle, array.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), array.nbytes, 2))
+        return array
 
     def close(self):
         if self.handle:

@@ -85,6 +85,33 @@ extern "C" int cm_ctx_synchronize(cm_ctx* c) {
   return CM_OK;
 }
 
+extern "C" int cm_mem_alloc(cm_ctx* c, uint64_t bytes, void** out) {
+  if (!c || !out) { cm_set_error("cm_mem_alloc: NULL argument"); return CM_ERR_INVALID; }
+  CM_HIP(hipSetDevice(c->device));
+  *out = nullptr;
+  if (bytes == 0) return CM_OK;
+  CM_HIP(hipMalloc(out, (size_t)bytes));
+  return CM_OK;
+}
+extern "C" int cm_mem_free(cm_ctx* c, void* ptr) {
+  if (!c) { cm_set_error("cm_mem_free: NULL context"); return CM_ERR_INVALID; }
+  if (!ptr) return CM_OK;
+  CM_HIP(hipSetDevice(c->device));
+  CM_HIP(hipStreamSynchronize(c->stream));
+  CM_HIP(hipFree(ptr));
+  return CM_OK;
+}
+extern "C" int cm_mem_copy(cm_ctx* c, void* dst, const void* src, uint64_t bytes, int kind) {
+  if (!c || (bytes && (!dst || !src))) { cm_set_error("cm_mem_copy: NULL argument"); return CM_ERR_INVALID; }
+  if (kind < 1 || kind > 3) { cm_set_error("cm_mem_copy: kind must be 1 (H2D), 2 (D2H) or 3 (D2D)"); return CM_ERR_INVALID; }
+  if (bytes == 0) return CM_OK;
+  CM_HIP(hipSetDevice(c->device));
+  const hipMemcpyKind k = kind == 1 ? hipMemcpyHostToDevice : (kind == 2 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice);
+  CM_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, k, c->stream));
+  CM_HIP(hipStreamSynchronize(c->stream));
+  return CM_OK;
+}
+
 template <typename T>
 static int dmalloc(T** p, size_t n) {
   CM_HIP(hipMalloc((void**)p, (n ? n : 1) * sizeof(T)));

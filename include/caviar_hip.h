@@ -131,6 +131,14 @@ int cm_ctx_create(int device_id, void* hip_stream, cm_ctx** out);
 int cm_ctx_destroy(cm_ctx* ctx);
 int cm_ctx_synchronize(cm_ctx* ctx);
 
+/* Device buffers for hosts that have no other way to hold HBM (a ctypes caller without torch): lets the output of one
+ * entry point (e.g. cm_nwd_demix, nwd_hip.h) feed the next (cm_problem_create with CM_MEM_DEVICE) without a host round
+ * trip.  cm_mem_copy: kind 1 = host->device, 2 = device->host, 3 = device->device; ordered on the ctx stream and complete
+ * on return. */
+int cm_mem_alloc(cm_ctx* ctx, uint64_t bytes, void** out);
+int cm_mem_free(cm_ctx* ctx, void* ptr);
+int cm_mem_copy(cm_ctx* ctx, void* dst, const void* src, uint64_t bytes, int kind);
+
 /* Uploads (CM_MEM_HOST) or adopts by copy (CM_MEM_DEVICE) psc[K*T] and stim[N*K], then runs the one-off prologue
  * on the GPU: y = trapz(psc), sum(psc^2) (caviar.py:28-30) and the compressed encoding of the stimulus matrix
  * (distinct powers, per-row and per-column index of targeted trials; caviar.py:32-35,42). */

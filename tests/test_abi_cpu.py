@@ -1,5 +1,5 @@
-"""CPU-only checks of the drop-in boundary: the C-ABI library loads, exports every symbol that include/caviar_hip.h
-declares, reports the reference's defaults, and refuses loudly to run without a GPU (no CPU fallback)."""
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads, exports every symbol that include/*.h
+declare, reports the reference's defaults, and refuses loudly to run without a GPU (no CPU fallback)."""
 import ctypes as C
 import os
 import re
@@ -18,10 +18,16 @@ def lib():
     return _lib.load()
 
 
+HEADERS = ("caviar_hip.h", "nwd_hip.h")
+
+
+def header_text():
+    text = "".join(open(os.path.join(ROOT, "include", h)).read() for h in HEADERS)
+    return re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+
+
 def declared_functions():
-    text = open(os.path.join(ROOT, "include", "caviar_hip.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(cm_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(cm_[a-z0-9_]+)\s*\(", header_text())))
 
 
 def test_header_symbols_exported(lib):
@@ -37,10 +43,9 @@ def test_header_symbols_exported(lib):
 def test_struct_layouts_match_header():
     """Field order of the ctypes mirrors == field order of the C structs (a silent mismatch would corrupt arguments)."""
     from circuitmap_amd import _lib
-    text = open(os.path.join(ROOT, "include", "caviar_hip.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = header_text()
     for cname, cls in [("cm_priors", _lib.CmPriors), ("cm_options", _lib.CmOptions), ("cm_result", _lib.CmResult),
-                       ("cm_timings", _lib.CmTimings)]:
+                       ("cm_timings", _lib.CmTimings), ("cm_nwd_block", _lib.CmNwdBlock), ("cm_nwd_params", _lib.CmNwdParams)]:
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), text, flags=re.S).group(1)
         fields = []
         for decl in body.split(";"):
@@ -48,7 +53,7 @@ def test_struct_layouts_match_header():
             if not decl:
                 continue
             for part in decl.split(","):
-                fields.append(re.findall(r"[A-Za-z_][A-Za-z0-9_]*", part)[-1])
+                fields.append(re.findall(r"[A-Za-z_][A-Za-z0-9_]*", re.sub(r"\[[^\]]*\]", "", part))[-1])
         assert fields == [f for f, _ in cls._fields_], cname
 
 
