@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """CAVIaR iterations/s on MI355X (BASELINE.json metric), one process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg5] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg5|nwd] [--no-cpu-baseline]
+
+`--workload nwd` benchmarks the upstream NWD demixer forward pass instead (its own metric, traces/s; see bench_nwd).
 
 A "step" is one complete `caviar()` run of one circuit per GPU: `iters` (50) CAVIaR iterations plus the
 false-negative scan and final phi update (reference circuitmap/optimise/caviar.py:79-98), on synthetic data of the
@@ -67,16 +69,113 @@ def cpu_baseline(sim, pri, wl):
     return out
 
 
+def nwd_flops_per_trace(T):
+    """multiply-adds x 2 of the reference network for one trace of T samples (neural_waveform_demixing.py:258-268), as dense
+    PyTorch would count them: Conv1d = out_len * cout * cin * k; ConvTranspose1d = in_len * cin * cout * k."""
+    pool = lambda L: (L - 3) // 2 + 1
+    P0 = pool(T); E1 = P0 - 62; P1 = pool(E1); E2 = P1 - 31; P2 = pool(E2); E3 = P2 - 15; P3 = pool(E3); E4 = P3 - 15
+    mac = (E1 * 16 * 1 * 32 + E2 * 16 * 16 * 32 + E3 * 32 * 16 * 16 + E4 * 32 * 32 * 16
+           + E4 * 32 * 16 * 16 + E3 * 48 * 16 * 16 + E2 * 32 * 16 * 32 + E1 * 32 * 4 * 32 + T * 1 * 4 * 256)
+    return 2 * mac
+
+
+def bench_nwd(a):
+    """One step = NeuralDemixer.__call__ on K = 2000 traces of T = 900 samples (the trace batch of cfg3), traces and result
+    resident in HBM (float64 in, float64 out), seeded random parameters of the reference architecture.  The kernel is
+    compute-bound on the fp32 matrix cores (157.3 TFLOP/s dense, MI355X_MICROARCH.md); its launch is timed live with HIP
+    events on the library's stream."""
+    import numpy as np
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: no GPU visible (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if dist is not None:
+        dist.barrier()
+    from circuitmap_amd.neural_waveform_demixing import NeuralDemixer
+    from oracle import nwd_oracle as no          # parameter generator + the CPU baseline (checker / baseline only)
+    K, T = 2000, 900
+    state = no.random_state(seed=0)
+    rng = np.random.default_rng(3000 + rank)
+    traces = rng.normal(0, 0.05, (K, T)) + np.exp(-np.abs(np.arange(T)[None, :] - rng.uniform(100, 500, (K, 1))) / 60.0) * rng.uniform(0.5, 4, (K, 1))
+    dm = NeuralDemixer(state=state, device=local_rank)
+    ctx = dm.ctx
+    d_in, d_out = ctx.alloc(traces.nbytes), ctx.alloc(traces.nbytes)
+    ctx.upload(d_in, traces)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.synchronize()
+
+    for _ in range(a.warmup):
+        dm.demix_device(d_in, K, T, d_out)
+    barrier()
+    t0 = time.perf_counter()
+    kms = []
+    for _ in range(a.steps):
+        kms.append(dm.demix_device(d_in, K, T, d_out))
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        flops = nwd_flops_per_trace(T) * K
+        k_ms = float(np.mean(kms))
+        achieved = flops / (k_ms * 1e-3) / 1e12
+        out = {"metric": "NWD demixer traces/sec (K=%d, T=%d)" % (K, T), "value": world * a.steps * K / dt, "unit": "traces/s",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "nwd: NeuralDemixer forward (U-Net + rescale + monotone filter) on %d traces x %d samples per GPU, "
+                                      "seeded random parameters" % (K, T)},
+               "roofline": {"bound": "mfma", "kernel": "k_nwd_forward", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s",
+                            "frac": achieved / 157.3, "traffic": None, "avg_launch_ms": k_ms,
+                            "algorithmic_flops_per_launch": int(flops),
+                            "hbm_bytes_per_launch": int(K * T * 16)}}
+        if world == 1 and not a.no_cpu_baseline:
+            nb = 256
+            nthreads = torch.get_num_threads()
+            t = time.time()
+            ref = no.demix(traces[:nb], state)
+            dtc = time.time() - t
+            got = ctx.download(d_out, np.empty_like(traces))[:nb]
+            out["cpu_baseline"] = {"value": nb / dtc, "unit": "traces/s", "cores": int(nthreads), "kind": "port",
+                                   "sample": "float32 PyTorch-CPU oracle on the first %d traces, %.2f s" % (nb, dtc),
+                                   "max_abs_diff_vs_gpu_over_scale": float(np.max(np.abs(got - ref)) / max(np.max(np.abs(ref)), 1e-30))}
+        print(json.dumps(out), flush=True)
+    ctx.free(d_in); ctx.free(d_out)
+    dm.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS) + ["nwd"])
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--phases", action="store_true", help="stamp every phase of every iteration (more host API calls)")
     a = ap.parse_args()
+    if a.workload == "nwd":
+        return bench_nwd(a)
 
     import numpy as np
     import torch

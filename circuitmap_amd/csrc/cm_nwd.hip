@@ -1,25 +1,32 @@
 // cm_nwd.hip -- NWD demixer forward pass (include/nwd_hip.h): the reference's NeuralDemixer.__call__
-// (circuitmap/neural_waveform_demixing.py:36-54) as ONE fused kernel, one 512-thread workgroup per trace.
+// (circuitmap/neural_waveform_demixing.py:36-54) as ONE fused kernel, one 1024-thread workgroup per trace.
 //
 // Every activation of the 1-D U-Net lives in LDS (119 KB at T = 900); HBM sees the trace once (float64 in) and the
 // result once (float64 out).  The eight inner layers (4 strided-pool convolutions, 4 transposed convolutions) are
 // implicit GEMMs on v_mfma_f32_16x16x4_f32: M = output channels (16 per block), N = 16 output positions, K = input
 // channel x tap, the B operand read straight out of the LDS activation rows (im2col never materialised), the A operand
-// streamed from the BatchNorm-folded, lane-packed weights in L2.  Transposed convolutions run as ordinary correlations
-// over zero-padded rows with flipped taps; the stride-2 one (ublock4) as two 16-tap polyphase branches.  Skip
-// connections are written by the encoder directly into their slot of the decoder's concatenated, padded input rows.
+// from BatchNorm-folded, lane-packed weights that the workgroup stages through a 32 KB LDS window once per layer (each
+// wavefront keeps a weight fragment in a register across its <= 4 output tiles).  Transposed convolutions run as
+// ordinary correlations over zero-padded rows with flipped taps; the stride-2 one (ublock4) as two 16-tap polyphase
+// branches; the last layer (1 output channel, 256 dilated taps) as a Toeplitz product so that it too fills the 16 rows of
+// the matrix instruction.  Skip connections are written by the encoder directly into their slot of the decoder's
+// concatenated, padded input rows.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 #include "../../include/nwd_hip.h"
 #include "cm_internal.h"
 
-#define NWD_THREADS 512
+#define NWD_THREADS 1024
 #define NWD_WAVES (NWD_THREADS / CM_WAVE)
 #define NWD_LDS_LIMIT (160 * 1024)
+#define NWD_WBUF 8192                   // floats of LDS the packed weights are staged through (32 KB)
+#define NWD_WBUF_MIN 4096
+#define NWD_MAXT 4                      // output tiles one wavefront carries through a layer
 
 typedef float cm_f4 __attribute__((ext_vector_type(4)));
 
@@ -30,10 +37,11 @@ struct NwdPlan {
   int oC1, sC1;      // [interp(ublock1) | enc3], padded 15: 48 rows
   int oC2, sC2;      // [interp(ublock2) | enc2], padded 31: 32 rows
   int oC3, sC3;      // [interp(ublock3) | enc1], padded 15: 32 rows
-  int oC4, sC4;      // interp(ublock4), padded 255:          4 rows   (overlays C2, dead by then)
+  int oC4, sC4;      // interp(ublock4), padded 255, split by sample parity, 16 samples per 17-float row: 8 rows (overlays C2)
+  int oW, nW;        // weight staging window: nW floats (NWD_WBUF, less for long traces, never under NWD_WBUF_MIN)
   int oS;            // scratch: normalised trace + pooled rows / deconv outputs before interpolation
   int oOut;          // raw network output [T]                        (overlays C1)
-  int oScan;         // float64 scan buffer [2][512], as a float offset (overlays B1/C1 tail, 8-byte aligned)
+  int oScan;         // float64 scan buffer [2][NWD_THREADS], as a float offset (overlays B1/C1 tail, 8-byte aligned)
   int lds_floats;
 };
 
@@ -65,8 +73,8 @@ static bool nwd_make_plan(int T, NwdPlan* pl) {
   int o = 0;
   p.sC3 = al(p.E1 + 30); p.oC3 = o; o += 32 * p.sC3;
   p.sC2 = al(p.E2 + 62); p.oC2 = o; o += 32 * p.sC2;
-  p.sC4 = al(T + 510);   p.oC4 = p.oC2;
-  const int c4_end = p.oC4 + 4 * p.sC4;
+  p.sC4 = al((((T + 1) / 2 + 15) / 16 + 17) * 17);     p.oC4 = p.oC2;     // rows of 16 samples: one per 16-column group + 17 of look-ahead (K = 272)
+  const int c4_end = p.oC4 + 8 * p.sC4;
   p.sC1 = al(p.E3 + 30); p.oC1 = o; o += 48 * p.sC1;
   p.sB1 = al(p.E4 + 30); p.oB1 = o; o += 32 * p.sB1;
   if (c4_end > o) o = c4_end;                      // very short C2: let C4 run over C1/B1 (dead too) -- keep the total honest
@@ -79,16 +87,21 @@ static bool nwd_make_plan(int T, NwdPlan* pl) {
   s = std::max(s, 4 * al(p.U4));
   p.oS = o; o += s;
   // raw output + scan buffer reuse the C1/B1 region only if it is large enough; otherwise append
-  const int need_tail = al(T) + 2 * 2 * NWD_THREADS;          // T floats + 2 x 512 doubles
+  const int need_tail = al(T) + 2 * 2 * NWD_THREADS;          // T floats + 2 x NWD_THREADS doubles
   if (48 * p.sC1 + 32 * p.sB1 >= need_tail && c4_end <= p.oC1) {
     p.oOut = p.oC1; p.oScan = p.oC1 + al(T);
   } else {
     p.oOut = o; p.oScan = o + al(T); o += need_tail;
   }
   p.oScan = (p.oScan + 1) & ~1;
-  p.lds_floats = o + 2;
+  o = (o + 2 + 3) & ~3;
+  const int budget = (NWD_LDS_LIMIT - 256) / (int)sizeof(float);                       // 256 B left for static LDS
+  int nw = budget - o;
+  nw = nw > NWD_WBUF ? NWD_WBUF : (nw & ~1023);
+  p.oW = o; p.nW = nw; o += nw > 0 ? nw : 0;
+  p.lds_floats = o;
   *pl = p;
-  return (size_t)p.lds_floats * sizeof(float) <= NWD_LDS_LIMIT - 256;                 // 256 B left for static LDS
+  return nw >= NWD_WBUF_MIN;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -120,39 +133,70 @@ __device__ __forceinline__ void nwd_interp(const float* in, int in_stride, int C
 
 // Implicit-GEMM correlation on the fp32 matrix cores:
 //     out[row][p] = relu( bias[row] + sum_ic sum_t W[row][ic][t] * in[ic][p + t * dil] ),   0 <= p < out_len
-// One work item = (16-row block mb, 16-position tile), dealt round-robin to the 8 wavefronts.  Operand layout of
-// v_mfma_f32_16x16x4_f32: lane l feeds A[row = l & 15][k = l >> 4] and B[k = l >> 4][col = l & 15]; accumulator register i of
-// lane l holds D[row = 4 (l >> 4) + i][col = l & 15].  Packed weights: wp[((mb * n_ic + ic) * (TAPS / 4) + ks) * 64 + l].
+// Operand layout of v_mfma_f32_16x16x4_f32: lane l feeds A[row = l & 15][k = l >> 4] and B[k = l >> 4][col = l & 15];
+// accumulator register i of lane l holds D[row = 4 (l >> 4) + i][col = l & 15].
+// Packed weights wp[((ic * n_mblk + mb) * (TAPS / 4) + ks) * 64 + l]: a run of input channels is contiguous, so the workgroup
+// copies as many channels as fit into the LDS window `wbuf`, every wavefront multiplies them, and the next run follows.
+// Wavefront w owns row block mb = w % n_mblk and the tiles (w / n_mblk) + j * (8 / n_mblk), j < NWD_MAXT: a weight fragment
+// read from LDS is used for all of them (independent accumulators, which also hides the 40-cycle dependent-MFMA latency).
 // STORE(row, p, value) places one finished element.
 template <int TAPS, class Store>
 __device__ __forceinline__ void nwd_conv_mfma(const float* in, int in_stride, int n_ic, int dil, const float* __restrict__ wp,
-                                              const float* __restrict__ bias, int n_mblk, int m_valid, int out_len, Store store) {
+                                              const float* __restrict__ bias, int n_mblk, int m_valid, int out_len, float* wbuf,
+                                              int wfloats, Store store) {
+  constexpr int KS = TAPS / 4;
   const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE;
   const int col = lane & 15, kk = lane >> 4;
   const int ntiles = (out_len + 15) >> 4;
-  for (int item = wave; item < n_mblk * ntiles; item += NWD_WAVES) {
-    const int mb = item / ntiles, tile = item - mb * ntiles;
-    int p = 16 * tile + col;
-    const int pc = p < out_len ? p : out_len - 1;                       // clamp the read, drop the store
-    const float* bsrc = in + pc + kk * dil;
-    const float* asrc = wp + (size_t)mb * n_ic * (TAPS / 4) * 64 + lane;
-    cm_f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int ic = 0; ic < n_ic; ++ic) {
-      float a[TAPS / 4], b[TAPS / 4];
+  const int mb = wave % n_mblk, slot = wave / n_mblk, nslots = NWD_WAVES / n_mblk;
+  const int nt = slot < ntiles ? (ntiles - slot + nslots - 1) / nslots : 0;            // tiles of this wavefront (uniform)
+  const float* bsrc[NWD_MAXT];
+  cm_f4 acc[NWD_MAXT];
 #pragma unroll
-      for (int ks = 0; ks < TAPS / 4; ++ks) {
-        a[ks] = asrc[(ic * (TAPS / 4) + ks) * 64];
-        b[ks] = bsrc[ic * in_stride + 4 * ks * dil];
-      }
-#pragma unroll
-      for (int ks = 0; ks < TAPS / 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], b[ks], acc, 0, 0, 0);
+  for (int j = 0; j < NWD_MAXT; ++j) {
+    const int p = 16 * (slot + j * nslots) + col;
+    bsrc[j] = in + (p < out_len ? p : out_len - 1) + kk * dil;                          // clamp the read, drop the store
+    acc[j] = cm_f4{0.0f, 0.0f, 0.0f, 0.0f};
+  }
+  const int per_ic = n_mblk * KS * 64;
+  const int chunk = wfloats / per_ic < n_ic ? wfloats / per_ic : n_ic;
+  for (int c0 = 0; c0 < n_ic; c0 += chunk) {
+    const int nc = (n_ic - c0 < chunk) ? n_ic - c0 : chunk;
+    __syncthreads();                                                                    // the window is free again
+    {
+      const float4* src = reinterpret_cast<const float4*>(wp + (size_t)c0 * per_ic);
+      float4* dst = reinterpret_cast<float4*>(wbuf);
+      for (int i = threadIdx.x; i < nc * per_ic / 4; i += NWD_THREADS) dst[i] = src[i];
     }
-    if (p < out_len) {
+    __syncthreads();
+    if (nt > 0) {
+      const float* asrc = wbuf + mb * KS * 64 + lane;
+      for (int ic = 0; ic < nc; ++ic) {
+        float a[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) a[ks] = asrc[ic * per_ic + ks * 64];
+#pragma unroll
+        for (int j = 0; j < NWD_MAXT; ++j) {
+          if (j < nt) {
+            float b[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) b[ks] = bsrc[j][(c0 + ic) * in_stride + 4 * ks * dil];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], b[ks], acc[j], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NWD_MAXT; ++j) {
+    const int p = 16 * (slot + j * nslots) + col;
+    if (j < nt && p < out_len) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = 16 * mb + 4 * kk + i;
         if (row < m_valid) {
-          const float v = acc[i] + bias[row];
+          const float v = acc[j][i] + bias[row];
           store(row, p, v < 0.0f ? 0.0f : v);                       // ReLU that lets NaN through, like torch.relu
         }
       }
@@ -161,7 +205,7 @@ __device__ __forceinline__ void nwd_conv_mfma(const float* in, int in_stride, in
 }
 
 __global__ __launch_bounds__(NWD_THREADS) void k_nwd_forward(NwdPlan pl, NwdDev w, int K, const double* __restrict__ traces,
-                                                             int monotone_start, double* __restrict__ out, float* __restrict__ raw) {
+                                                             int monotone_start, double* __restrict__ out, float* __restrict__ raw, int stop) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ double red[NWD_WAVES];
   const int k = blockIdx.x;
@@ -191,73 +235,126 @@ __global__ __launch_bounds__(NWD_THREADS) void k_nwd_forward(NwdPlan pl, NwdDev 
 
   float* C3 = lds + pl.oC3; float* C2 = lds + pl.oC2; float* C1 = lds + pl.oC1; float* B1 = lds + pl.oB1; float* C4 = lds + pl.oC4;
   float* S = lds + pl.oS;
+  float* WB = lds + pl.oW;
   const int sC3 = pl.sC3, sC2 = pl.sC2, sC1 = pl.sC1, sB1 = pl.sB1, sC4 = pl.sC4;
 
   // ---- encoder: pool -> conv -> BN -> ReLU, each result written into its skip slot
   nwd_pool(X, 0, 1, pl.P0, Q, 0);
   __syncthreads();
-  nwd_conv_mfma<32>(Q, 0, 1, 2, w.wp[0], w.bias[0], 1, 16, pl.E1,
+  nwd_conv_mfma<32>(Q, 0, 1, 2, w.wp[0], w.bias[0], 1, 16, pl.E1, WB, pl.nW,
                     [&](int r, int p, float v) { C3[(16 + r) * sC3 + 15 + p] = v; });
   __syncthreads();
+  if (stop == 1) return;                             // diagnostic (CAVIAR_NWD_STOP): phase timing by early exit
   const int sQ1 = (pl.P1 + 3) & ~3;
   nwd_pool(C3 + 16 * sC3 + 15, sC3, 16, pl.P1, S, sQ1);
   __syncthreads();
-  nwd_conv_mfma<32>(S, sQ1, 16, 1, w.wp[1], w.bias[1], 1, 16, pl.E2,
+  nwd_conv_mfma<32>(S, sQ1, 16, 1, w.wp[1], w.bias[1], 1, 16, pl.E2, WB, pl.nW,
                     [&](int r, int p, float v) { C2[(16 + r) * sC2 + 31 + p] = v; });
   __syncthreads();
+  if (stop == 2) return;                             // diagnostic (CAVIAR_NWD_STOP): phase timing by early exit
   const int sQ2 = (pl.P2 + 3) & ~3;
   nwd_pool(C2 + 16 * sC2 + 31, sC2, 16, pl.P2, S, sQ2);
   __syncthreads();
-  nwd_conv_mfma<16>(S, sQ2, 16, 1, w.wp[2], w.bias[2], 2, 32, pl.E3,
+  nwd_conv_mfma<16>(S, sQ2, 16, 1, w.wp[2], w.bias[2], 2, 32, pl.E3, WB, pl.nW,
                     [&](int r, int p, float v) { C1[(16 + r) * sC1 + 15 + p] = v; });
   __syncthreads();
+  if (stop == 3) return;                             // diagnostic (CAVIAR_NWD_STOP): phase timing by early exit
   const int sQ3 = (pl.P3 + 3) & ~3;
   nwd_pool(C1 + 16 * sC1 + 15, sC1, 32, pl.P3, S, sQ3);
   __syncthreads();
-  nwd_conv_mfma<16>(S, sQ3, 32, 1, w.wp[3], w.bias[3], 2, 32, pl.E4,
+  nwd_conv_mfma<16>(S, sQ3, 32, 1, w.wp[3], w.bias[3], 2, 32, pl.E4, WB, pl.nW,
                     [&](int r, int p, float v) { B1[r * sB1 + 15 + p] = v; });
   __syncthreads();
+  if (stop == 4) return;                             // diagnostic (CAVIAR_NWD_STOP): phase timing by early exit
 
   // ---- decoder: deconv -> BN -> ReLU into scratch, linear interpolation into rows 0..15 of the next concatenated input
   const int sU1 = (pl.U1 + 3) & ~3, sU2 = (pl.U2 + 3) & ~3, sU3 = (pl.U3 + 3) & ~3, sU4 = (pl.U4 + 3) & ~3;
-  nwd_conv_mfma<16>(B1, sB1, 32, 1, w.wp[4], w.bias[4], 1, 16, pl.U1, [&](int r, int p, float v) { S[r * sU1 + p] = v; });
+  nwd_conv_mfma<16>(B1, sB1, 32, 1, w.wp[4], w.bias[4], 1, 16, pl.U1, WB, pl.nW, [&](int r, int p, float v) { S[r * sU1 + p] = v; });
   __syncthreads();
   nwd_interp(S, sU1, 16, pl.U1, C1 + 15, sC1, pl.E3);
   __syncthreads();
-  nwd_conv_mfma<16>(C1, sC1, 48, 1, w.wp[5], w.bias[5], 1, 16, pl.U2, [&](int r, int p, float v) { S[r * sU2 + p] = v; });
+  if (stop == 5) return;                             // diagnostic (CAVIAR_NWD_STOP): phase timing by early exit
+  nwd_conv_mfma<16>(C1, sC1, 48, 1, w.wp[5], w.bias[5], 1, 16, pl.U2, WB, pl.nW, [&](int r, int p, float v) { S[r * sU2 + p] = v; });
   __syncthreads();
   nwd_interp(S, sU2, 16, pl.U2, C2 + 31, sC2, pl.E2);
   __syncthreads();
-  nwd_conv_mfma<32>(C2, sC2, 32, 1, w.wp[6], w.bias[6], 1, 16, pl.U3, [&](int r, int p, float v) { S[r * sU3 + p] = v; });
+  if (stop == 6) return;                             // diagnostic (CAVIAR_NWD_STOP): phase timing by early exit
+  nwd_conv_mfma<32>(C2, sC2, 32, 1, w.wp[6], w.bias[6], 1, 16, pl.U3, WB, pl.nW, [&](int r, int p, float v) { S[r * sU3 + p] = v; });
   __syncthreads();
   nwd_interp(S, sU3, 16, pl.U3, C3 + 15, sC3, pl.E1);
   // C2 is dead from here on: its space becomes C4, whose padding must be zero again
-  for (int i = tid; i < 4 * sC4; i += NWD_THREADS) C4[i] = 0.0f;
+  for (int i = tid; i < 8 * sC4; i += NWD_THREADS) C4[i] = 0.0f;
   __syncthreads();
+  if (stop == 7) return;                             // diagnostic (CAVIAR_NWD_STOP): phase timing by early exit
   // stride-2 deconv as two polyphase branches: row r = 2 oc + phase, output sample 2 q + phase
-  nwd_conv_mfma<16>(C3, sC3, 32, 1, w.wp[7], w.bias[7], 1, 8, pl.E1 + 15,
+  nwd_conv_mfma<16>(C3, sC3, 32, 1, w.wp[7], w.bias[7], 1, 8, pl.E1 + 15, WB, pl.nW,
                     [&](int r, int q, float v) { S[(r >> 1) * sU4 + 2 * q + (r & 1)] = v; });
   __syncthreads();
-  nwd_interp(S, sU4, 4, pl.U4, C4 + 255, sC4, T);
+  // linear interpolation to T samples, written for the Toeplitz product below: padded sample i = 255 + x of channel c goes to
+  // row (c, parity i & 1), element q = i >> 1 at (q / 16) * 17 + q % 16   (16 samples per 17-float row: conflict-free B reads)
+  {
+    const float scale = (float)pl.U4 / (float)T;
+    for (int i = tid; i < 4 * T; i += NWD_THREADS) {
+      const int c = i / T, x = i - c * T;
+      float src = scale * ((float)x + 0.5f) - 0.5f;
+      src = src < 0.0f ? 0.0f : src;
+      const int i0 = (int)src;
+      const int i1 = i0 + ((i0 < pl.U4 - 1) ? 1 : 0);
+      const float l1 = src - (float)i0, l0 = 1.0f - l1;
+      const float* r = S + c * sU4;
+      const int ip = 255 + x, q = ip >> 1;
+      C4[(2 * c + (ip & 1)) * sC4 + (q >> 4) * 17 + (q & 15)] = l0 * r[i0] + l1 * r[i1];
+    }
+    // compact folded weights of the last layer, zero-padded by 16 on both sides: WB[ic * 288 + 16 + t]
+    for (int i = tid; i < 4 * 288; i += NWD_THREADS) {
+      const int ic = i / 288, t = i - ic * 288 - 16;
+      WB[i] = (t >= 0 && t < 256) ? w.wfin[ic * 256 + t] : 0.0f;
+    }
+  }
   __syncthreads();
+  if (stop == 8) return;                             // diagnostic (CAVIAR_NWD_STOP): phase timing by early exit
 
-  // ---- final ConvolutionBlock(4, 1, 256, padding 255, dilation 2): one output per thread, weights through scalar loads
+  // ---- final ConvolutionBlock(4, 1, 256, padding 255, dilation 2) as a Toeplitz product on the matrix cores.
+  // For output parity pi, s[q] = padded[2 q + pi] and out[2 m + pi] = sum_t s[m + t] w[t].  With m = 16 a + r:
+  //     D[r][a] = sum_{j < 272} Wtoe[r][j] * s[16 a + j],   Wtoe[r][j] = w[j - r]  (0 outside 0 <= j - r < 256)
+  // 8 work items = parity x 16-column tile (a) x channel pair, one per wavefront; the two channel-pair partial sums are
+  // combined in a fixed order afterwards (no atomics: bitwise reproducible).
   float* OUT = lds + pl.oOut;
-  for (int p = tid; p < T; p += NWD_THREADS) {
-    float acc0 = 0.0f, acc1 = 0.0f;
-    for (int ic = 0; ic < 4; ++ic) {
-      const float* r = C4 + ic * sC4 + p;
-      const float* wr = w.wfin + ic * 256;
-#pragma unroll 8
-      for (int t = 0; t < 256; t += 2) {
-        acc0 = fmaf(r[2 * t], wr[t], acc0);
-        acc1 = fmaf(r[2 * t + 2], wr[t + 1], acc1);
+  float* PART = S;                                   // [2][T] partial sums (the scratch rows are dead)
+  {
+    const int wave = tid / CM_WAVE, lane = tid % CM_WAVE, col = lane & 15, kk = lane >> 4;
+    const int pi = wave & 1, ntile = (wave >> 1) & 1, pair = wave >> 2;
+    const int na = ((T + 1) / 2 + 15) / 16;          // 16-sample groups per parity
+    for (int nt0 = ntile; wave < 8 && 16 * nt0 < na; nt0 += 2) {
+      const int a = 16 * nt0 + col;
+      const int ac = a < na ? a : na - 1;
+      cm_f4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+      const float* b0 = C4 + (2 * (2 * pair) + pi) * sC4 + ac * 17 + kk;
+      const float* b1 = b0 + 2 * sC4;
+      const float* a0 = WB + (2 * pair) * 288 + 16 + kk - col;
+      const float* a1 = a0 + 288;
+#pragma unroll 4
+      for (int ks = 0; ks < 68; ++ks) {
+        const int boff = (ks >> 2) * 17 + 4 * (ks & 3);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[4 * ks], b0[boff], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[4 * ks], b1[boff], acc1, 0, 0, 0);
+      }
+      if (a < na) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int p = 2 * (16 * a + 4 * kk + i) + pi;
+          if (p < T) PART[pair * T + p] = acc0[i] + acc1[i];
+        }
       }
     }
-    const float v = acc0 + acc1 + w.bfin;
+  }
+  __syncthreads();
+  for (int p = tid; p < T; p += NWD_THREADS) {
+    const float v = PART[p] + PART[T + p] + w.bfin;
     OUT[p] = v < 0.0f ? 0.0f : v;
   }
   __syncthreads();
+  if (stop == 9) return;                             // diagnostic (CAVIAR_NWD_STOP): phase timing by early exit
 
   // ---- rescale in float64 and enforce monotone decay from `monotone_start` on (running minimum seeded at start - 1)
   double* scan = reinterpret_cast<double*>(lds + pl.oScan);
@@ -312,7 +409,7 @@ Folded fold_bn(const cm_nwd_block& b, int cout, float eps) {
   }
   return f;
 }
-// pack W(row, ic, tap) -> [mb][ic][taps/4][64 lanes]
+// pack W(row, ic, tap) -> [ic][mb][taps/4][64 lanes]
 template <class W>
 void pack_mfma(std::vector<float>& dst, int m_valid, int n_ic, int taps, W wf) {
   const int n_mblk = (m_valid + 15) / 16;
@@ -322,7 +419,7 @@ void pack_mfma(std::vector<float>& dst, int m_valid, int n_ic, int taps, W wf) {
       for (int ks = 0; ks < taps / 4; ++ks)
         for (int l = 0; l < 64; ++l) {
           const int row = 16 * mb + (l & 15), tap = 4 * ks + (l >> 4);
-          if (row < m_valid) dst[(((size_t)mb * n_ic + ic) * (taps / 4) + ks) * 64 + l] = wf(row, ic, tap);
+          if (row < m_valid) dst[(((size_t)ic * n_mblk + mb) * (taps / 4) + ks) * 64 + l] = wf(row, ic, tap);
         }
 }
 }  // namespace
@@ -462,7 +559,8 @@ extern "C" int cm_nwd_demix(cm_ctx* ctx, const cm_nwd* nwd, int K, int T, const 
   }
   const size_t lds_bytes = (size_t)pl.lds_floats * sizeof(float);
   NWD_HIP(hipEventRecord(ctx->ev[0], st));
-  hipLaunchKernelGGL(k_nwd_forward, dim3(K), dim3(NWD_THREADS), lds_bytes, st, pl, nwd->dev, K, d_in, monotone_filter_start, d_out, d_raw);
+  static const int stop = getenv("CAVIAR_NWD_STOP") ? atoi(getenv("CAVIAR_NWD_STOP")) : 0;
+  hipLaunchKernelGGL(k_nwd_forward, dim3(K), dim3(NWD_THREADS), lds_bytes, st, pl, nwd->dev, K, d_in, monotone_filter_start, d_out, d_raw, stop);
   NWD_HIP(hipGetLastError());
   NWD_HIP(hipEventRecord(ctx->ev[1], st));
   if (out_mem == CM_MEM_HOST) {

@@ -107,4 +107,8 @@ def random_state(seed=0):
     name, cin, cout, k = FINAL[:4]
     conv_like(name + ".conv", (cout, cin, k), cin * k)
     bn(name, cout)
+    # keep the single output channel alive: a random BatchNorm shift below zero would make the last ReLU return all zeros,
+    # and a comparison of two all-zero outputs tests nothing
+    sd[name + ".bn.bias"] = np.abs(sd[name + ".bn.bias"]) + np.float32(0.25)
+    sd[name + ".bn.running_mean"] = np.zeros(cout, dtype=np.float32)
     return sd

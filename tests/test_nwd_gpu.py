@@ -47,6 +47,7 @@ def test_matches_oracle_random_weights(T):
     dm = NeuralDemixer(state=state)
     dem, raw = dm(traces, verbose=False, return_raw=True)
     odem, oraw = no.demix(traces, state, return_raw=True)
+    assert np.mean(oraw > 0) > 0.2                           # a non-trivial output (not killed by the last ReLU)
     assert scale_err(raw, oraw) < TOL
     assert scale_err(dem, odem) < TOL
     dm.close()
@@ -67,6 +68,7 @@ def test_full_size_properties():
     idx = rng.choice(K, 40, replace=False)
     np.testing.assert_array_equal(dm(traces[idx], verbose=False), dem[idx])            # rows are independent
     odem = no.demix(traces[idx], state)
+    assert np.mean(odem != 0) > 0.2
     assert scale_err(dem[idx], odem) < TOL
     scaled = dm(traces[idx] * 8.0, verbose=False)                                      # exact power-of-two rescaling
     np.testing.assert_array_equal(scaled, dem[idx] * 8.0)
