@@ -137,7 +137,7 @@ __device__ __forceinline__ void nwd_interp(const float* in, int in_stride, int C
 // accumulator register i of lane l holds D[row = 4 (l >> 4) + i][col = l & 15].
 // Packed weights wp[((ic * n_mblk + mb) * (TAPS / 4) + ks) * 64 + l]: a run of input channels is contiguous, so the workgroup
 // copies as many channels as fit into the LDS window `wbuf`, every wavefront multiplies them, and the next run follows.
-// Wavefront w owns row block mb = w % n_mblk and the tiles (w / n_mblk) + j * (8 / n_mblk), j < NWD_MAXT: a weight fragment
+// Wavefront w owns row block mb = w % n_mblk and the tiles (w / n_mblk) + j * (NWD_WAVES / n_mblk), j < NWD_MAXT: a weight fragment
 // read from LDS is used for all of them (independent accumulators, which also hides the 40-cycle dependent-MFMA latency).
 // STORE(row, p, value) places one finished element.
 template <int TAPS, class Store>
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(NWD_THREADS) void k_nwd_forward(NwdPlan pl, NwdDev 
   // ---- final ConvolutionBlock(4, 1, 256, padding 255, dilation 2) as a Toeplitz product on the matrix cores.
   // For output parity pi, s[q] = padded[2 q + pi] and out[2 m + pi] = sum_t s[m + t] w[t].  With m = 16 a + r:
   //     D[r][a] = sum_{j < 272} Wtoe[r][j] * s[16 a + j],   Wtoe[r][j] = w[j - r]  (0 outside 0 <= j - r < 256)
-  // 8 work items = parity x 16-column tile (a) x channel pair, one per wavefront; the two channel-pair partial sums are
+  // 8 work items = parity x 16-column tile (a) x channel pair, one per wavefront (the first 8); the two channel-pair partial sums are
   // combined in a fixed order afterwards (no atomics: bitwise reproducible).
   float* OUT = lds + pl.oOut;
   float* PART = S;                                   // [2][T] partial sums (the scratch rows are dead)
