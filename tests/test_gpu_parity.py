@@ -138,6 +138,37 @@ def test_invariants_full_size():
     assert dead.sum() > 0.5 * len(dead)                                  # most cells are disconnected and pruned
 
 
+def test_invariants_stress_size():
+    """The same size-independent properties at BASELINE configs[4] (N=5000, K=10000: 157-tile Cholesky, two-round shuffle,
+    8-bit chain tickets), plus: a row whose lam is identically 0 has exactly the prior mean and the prior VARIANCE
+    (quirk: `beta` returns diag(Sigma)), and a second run of the same problem object reproduces the first bit for bit."""
+    from circuitmap_amd import _lib
+    from circuitmap_amd.optimise.caviar import Problem
+    sim, pri = _sim_case(5000, 10000, 2005, lite=True)
+    stim = sim["stim_matrix"]
+    ctx = _lib.default_context(0)
+    prob = Problem(ctx, sim["psc"], stim)
+    args = prior_args(pri)
+    prob.run(*args, iters=50, seed=0)
+    res = prob.fetch()
+    mu, beta, lam, shape, rate, phi, phi_cov, z = res[:8]
+    assert np.all((lam >= 0) & (lam <= 1))
+    assert np.all(lam[stim == 0] == 0)
+    assert shape == pri["shape"] + 10000 / 2
+    assert np.all(phi > 0) and np.all(np.isfinite(phi_cov))
+    assert np.all(z[np.any(lam >= 0.1, axis=0)] == 0) and np.all(z >= 0)
+    dead = ~np.any(lam != 0, axis=1)
+    assert dead.sum() > 0.5 * len(dead)
+    assert np.all(mu[dead] == pri["mu"][dead]) and np.all(beta[dead] == pri["beta"][dead] ** 2)
+    r2 = np.corrcoef(sim["weights"], mu)[0, 1] ** 2
+    assert r2 > 0.6, r2
+    prob.run(*args, iters=50, seed=0)
+    res2 = prob.fetch()
+    for a, b in zip(res[:8], res2[:8]):
+        np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+    prob.close()
+
+
 def test_edge_cases(ctx):
     from circuitmap_amd import _lib
     from circuitmap_amd.optimise import caviar
