@@ -173,6 +173,8 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--phases", action="store_true", help="stamp every phase of every iteration (more host API calls)")
+    ap.add_argument("--device-sim", action="store_true", help="generate the synthetic experiment on the GPU (include/sim_hip.h): "
+                    "psc and stim_matrix never exist on the host")
     a = ap.parse_args()
     if a.workload == "nwd":
         return bench_nwd(a)
@@ -209,10 +211,18 @@ def main():
 
     wl = WORKLOADS[a.workload]
     N, K, T, H = wl["N"], wl["K"], wl["T"], wl["H"]
-    sim = simulate(N=N, T=T, H=H, trials=K, seed=2000 + rank, lite=(N > 2000))
     pri = default_priors(N)
-    ctx = _lib.Context(local_rank)
-    prob = Problem(ctx, sim["psc"], sim["stim_matrix"])        # H2D + one-off prologue: outside the timed region
+    gen_ms = None
+    if a.device_sim:
+        from circuitmap_amd.simulation import simulate_device
+        dsim = simulate_device(N=N, T=T, H=H, trials=K, seed=2000 + rank, device_id=local_rank, keep_on_device=True)
+        ctx, gen_ms = dsim["ctx"], dsim["device_ms"]
+        prob = Problem(ctx, None, None, device_ptrs=(N, K, T, dsim["psc_ptr"], dsim["stim_ptr"]))   # one-off prologue: outside the timed region
+        sim = None
+    else:
+        sim = simulate(N=N, T=T, H=H, trials=K, seed=2000 + rank, lite=(N > 2000))
+        ctx = _lib.Context(local_rank)
+        prob = Problem(ctx, sim["psc"], sim["stim_matrix"])        # H2D + one-off prologue: outside the timed region
     nnz, nvals = prob.nnz
     run_args = (pri["mu"], pri["beta"], pri["shape"], pri["rate"], pri["phi"], pri["phi_cov"])
     opts = dict(iters=a.iters, seed=0)
@@ -267,7 +277,7 @@ def main():
             "metric": "CAVIaR iterations/sec (N=%d, K=%d, T=%d)" % (N, K, T),
             "value": value, "unit": "iterations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic" if gen_ms is None else "synthetic (generated on the GPU in %.2f ms)" % gen_ms,
             "config": {"workload": "%s: N=%d neurons, K=%d trials, T=%d, H=%d targets/trial, %d iterations + fn_scan per step, "
                                    "1 circuit per GPU" % (a.workload, N, K, T, H, its),
                        "nnz_targeted": int(nnz), "distinct_powers": int(nvals) - 1,
@@ -284,9 +294,13 @@ def main():
             "phase_ms_per_step": phase,
         }
         if world == 1 and not a.no_cpu_baseline:
+            if sim is None:                                    # the oracle needs host copies of what the GPU generated
+                sim = {"psc": ctx.download(dsim["psc_ptr"], np.empty((K, T))), "stim_matrix": ctx.download(dsim["stim_ptr"], np.empty((N, K)))}
             out["cpu_baseline"] = cpu_baseline(sim, pri, wl)
         print(json.dumps(out), flush=True)
     prob.close()
+    if a.device_sim:
+        ctx.free(dsim["psc_ptr"]); ctx.free(dsim["stim_ptr"])
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

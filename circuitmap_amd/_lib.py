@@ -59,7 +59,28 @@ class CmNwdParams(C.Structure):
     _fields_ = [("dblock", CmNwdBlock * 4), ("ublock", CmNwdBlock * 4), ("conv", CmNwdBlock), ("bn_eps", C.c_float)]
 
 
-# every symbol include/caviar_hip.h and include/nwd_hip.h declare: (restype, argtypes)
+CM_SIM_MAX_POWERS = 16
+
+
+class CmSimOptions(C.Structure):
+    _fields_ = [("N", C.c_int32), ("T", C.c_int32), ("H", C.c_int32), ("trials", C.c_int32), ("nreps", C.c_int32),
+                ("n_powers", C.c_int32), ("powers", C.c_double * CM_SIM_MAX_POWERS),
+                ("connection_prob", C.c_double), ("min_latency", C.c_double), ("gamma_beta", C.c_double), ("sigma", C.c_double),
+                ("frac_strongly_connected", C.c_double),
+                ("strong_weight_lower", C.c_double), ("strong_weight_upper", C.c_double), ("weak_exp_mean", C.c_double), ("min_weight", C.c_double),
+                ("phi_0_lower", C.c_double), ("phi_0_upper", C.c_double), ("phi_1_lower", C.c_double), ("phi_1_upper", C.c_double),
+                ("mult_noise_log_var", C.c_double),
+                ("tau_r_min", C.c_double), ("tau_r_max", C.c_double), ("tau_delta_min", C.c_double), ("tau_delta_max", C.c_double),
+                ("gp_scale", C.c_double), ("gp_lengthscale", C.c_double), ("spont_prob", C.c_double), ("max_power_min_spike_rate", C.c_double),
+                ("seed", C.c_uint64)]
+
+
+class CmSimResult(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("psc", "stim_matrix", "weights", "phi_0", "phi_1", "spks", "spk_times", "I", "gp_noise",
+                                          "spont_pscs", "tau_r", "tau_d")]
+
+
+# every symbol include/*.h declare: (restype, argtypes)
 SYMBOLS = {
     "cm_last_error": (C.c_char_p, []),
     "cm_version": (C.c_char_p, []),
@@ -89,6 +110,9 @@ SYMBOLS = {
     "cm_nwd_destroy": (None, [C.c_void_p]),
     "cm_nwd_max_trace_len": (C.c_int, []),
     "cm_nwd_min_trace_len": (C.c_int, []),
+    # include/sim_hip.h
+    "cm_sim_options_default": (None, [C.POINTER(CmSimOptions)]),
+    "cm_simulate": (C.c_int, [C.c_void_p, C.POINTER(CmSimOptions), C.POINTER(CmSimResult), C.c_int, C.POINTER(C.c_float)]),
     "cm_nwd_demix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                C.c_int, C.POINTER(C.c_float)]),
 }

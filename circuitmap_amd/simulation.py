@@ -160,3 +160,71 @@ def simulate(N=300, T=900, H=10, trials=1000, nreps=1, connection_prob=0.05, pow
         "stim_matrix": stim_matrix, "psc": psc, "gp_noise": gp_noise, "kernel": None, "spks": spks,
         "spk_times": spk_times, "spont_pscs": spont_pscs, "I": I,
     }
+
+
+_SIM_KEYS = ("N", "T", "H", "trials", "nreps", "connection_prob", "min_latency", "gamma_beta", "sigma", "frac_strongly_connected",
+             "strong_weight_lower", "strong_weight_upper", "weak_exp_mean", "min_weight", "phi_0_lower", "phi_0_upper", "phi_1_lower",
+             "phi_1_upper", "mult_noise_log_var", "tau_r_min", "tau_r_max", "tau_delta_min", "tau_delta_max", "gp_scale",
+             "gp_lengthscale", "spont_prob", "max_power_min_spike_rate", "seed")
+
+
+def simulate_device(powers=(45, 55, 65), design="blockwise", device_id=0, keep_on_device=False, full=True, **kw):
+    """`simulate` generated ON the MI355X (include/sim_hip.h, circuitmap_amd/csrc/cm_sim.hip): same arguments, defaults and
+    returned keys as the reference's ``simulate`` (circuitmap/simulation.py:25-195, blockwise design), counter-based draws.
+
+    keep_on_device=False  -> dict of NumPy arrays (keys of the reference's `sim` dict; `full=False` skips the N x K and
+                             per-component K x T extras and returns psc, stim_matrix, weights, phi_0, phi_1, I only)
+    keep_on_device=True   -> `psc` and `stim_matrix` stay in HBM: dict with integer device addresses `psc_ptr`,
+                             `stim_ptr` (free with ctx.free) for cm_problem_create(..., CM_MEM_DEVICE), plus the small host vectors.
+    There is no CPU fallback; the NumPy restatement is `simulate` above."""
+    import ctypes as C
+    from . import _lib
+    if design != "blockwise":
+        raise NotImplementedError("simulate_device implements design='blockwise' (the reference's default)")
+    lib = _lib.load()
+    o = _lib.CmSimOptions()
+    lib.cm_sim_options_default(C.byref(o))
+    unknown = set(kw) - set(_SIM_KEYS)
+    if unknown:
+        raise TypeError("simulate_device() got an unexpected keyword argument '%s'" % sorted(unknown)[0])
+    for k, v in kw.items():
+        setattr(o, k, type(getattr(o, k))(v))
+    powers = [float(p) for p in powers]
+    if not 1 <= len(powers) <= _lib.CM_SIM_MAX_POWERS:
+        raise ValueError("1..%d powers" % _lib.CM_SIM_MAX_POWERS)
+    o.n_powers = len(powers)
+    for i, p in enumerate(powers):
+        o.powers[i] = p
+    ctx = _lib.default_context(device_id)
+    N, K, T = o.N, o.trials, o.T
+    res = _lib.CmSimResult()
+    ms = C.c_float(0.0)
+    small = {k: np.empty(n) for k, n in (("weights", N), ("phi_0", N), ("phi_1", N), ("tau_r", N), ("tau_d", N), ("I", K))}
+    if keep_on_device:
+        psc_ptr, stim_ptr = ctx.alloc(K * T * 8), ctx.alloc(N * K * 8)
+        dsmall = {k: ctx.alloc(v.nbytes) for k, v in small.items()}
+        res.psc, res.stim_matrix = psc_ptr, stim_ptr
+        for k, p in dsmall.items():
+            setattr(res, k, p)
+        try:
+            _lib.check(lib.cm_simulate(ctx.handle, C.byref(o), C.byref(res), _lib.CM_MEM_DEVICE, C.byref(ms)))
+            for k, v in small.items():
+                ctx.download(dsmall[k], v)
+        except Exception:
+            ctx.free(psc_ptr); ctx.free(stim_ptr)
+            raise
+        finally:
+            for p in dsmall.values():
+                ctx.free(p)
+        out = dict(small, psc_ptr=psc_ptr, stim_ptr=stim_ptr, N=N, K=K, T=T, sigma=o.sigma, device_ms=float(ms.value), ctx=ctx)
+        return out
+    big = {"psc": np.empty((K, T)), "stim_matrix": np.empty((N, K))}
+    if full:
+        big.update(spks=np.empty((N, K)), spk_times=np.empty((N, K)), gp_noise=np.empty((K, T)), spont_pscs=np.empty((K, T)))
+    for k, v in list(small.items()) + list(big.items()):
+        setattr(res, k, v.ctypes.data)
+    _lib.check(lib.cm_simulate(ctx.handle, C.byref(o), C.byref(res), _lib.CM_MEM_HOST, C.byref(ms)))
+    out = dict(small)
+    out.update(big)
+    out.update(sigma=o.sigma, kernel=None, mult_noise=None, device_ms=float(ms.value))
+    return out

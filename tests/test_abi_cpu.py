@@ -18,7 +18,7 @@ def lib():
     return _lib.load()
 
 
-HEADERS = ("caviar_hip.h", "nwd_hip.h")
+HEADERS = ("caviar_hip.h", "nwd_hip.h", "sim_hip.h")
 
 
 def header_text():
@@ -45,7 +45,8 @@ def test_struct_layouts_match_header():
     from circuitmap_amd import _lib
     text = header_text()
     for cname, cls in [("cm_priors", _lib.CmPriors), ("cm_options", _lib.CmOptions), ("cm_result", _lib.CmResult),
-                       ("cm_timings", _lib.CmTimings), ("cm_nwd_block", _lib.CmNwdBlock), ("cm_nwd_params", _lib.CmNwdParams)]:
+                       ("cm_timings", _lib.CmTimings), ("cm_nwd_block", _lib.CmNwdBlock), ("cm_nwd_params", _lib.CmNwdParams),
+                       ("cm_sim_options", _lib.CmSimOptions), ("cm_sim_result", _lib.CmSimResult)]:
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), text, flags=re.S).group(1)
         fields = []
         for decl in body.split(";"):
