@@ -112,7 +112,7 @@ SYMBOLS = {
     "cm_nwd_min_trace_len": (C.c_int, []),
     # include/sim_hip.h
     "cm_sim_options_default": (None, [C.POINTER(CmSimOptions)]),
-    "cm_simulate": (C.c_int, [C.c_void_p, C.POINTER(CmSimOptions), C.POINTER(CmSimResult), C.c_int, C.POINTER(C.c_float)]),
+    "cm_simulate": (C.c_int, [C.c_void_p, C.POINTER(CmSimOptions), C.c_int, C.POINTER(CmSimResult), C.c_int, C.POINTER(C.c_float)]),
     "cm_nwd_demix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                C.c_int, C.POINTER(C.c_float)]),
 }

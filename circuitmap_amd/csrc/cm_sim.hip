@@ -13,7 +13,7 @@
 
 namespace {
 enum : uint32_t { S_ORDER, S_SHUFFLE, S_CONN, S_TAU_R, S_TAU_D, S_PHI0, S_PHI1, S_WEIGHT, S_SPIKE, S_PAD, S_GAMMA_N, S_GAMMA_U, S_MULT,
-                  S_SPONT, S_SP_TR, S_SP_TD, S_SP_T0, S_SP_W, S_GP, S_IID, S_GAMMA_B };
+                  S_SPONT, S_SP_TR, S_SP_TD, S_SP_T0, S_SP_W, S_GP, S_IID, S_GAMMA_B, S_TARGET };
 constexpr int GAMMA_TRIES = 16;
 constexpr int GP_HALF_WIDTHS = 4;
 constexpr int SIM_MAX_H = 64;              // cells per hologram the trace kernel stages
@@ -51,6 +51,7 @@ __device__ __forceinline__ double sim_geom(double tau, double m) { return (1.0 -
 struct SimDev {
   cm_sim_options o;
   double powers_desc[CM_SIM_MAX_POWERS];
+  int random_design;     // 0 = blockwise, 1 = random
   int K, nholo, tpr, R, n_conn, n_strong, J, W;
   int32_t* orders;       // [R][N]
   int32_t* reorder;      // [K]
@@ -137,14 +138,29 @@ __global__ __launch_bounds__(256) void k_sim_design(SimDev s) {
   if (k >= s.K) return;
   const int N = s.o.N, H = s.o.H;
   const int t = s.reorder[k];
-  const int r = t / s.tpr, rem = t - r * s.tpr;
-  const int pi = rem / (s.nholo * s.o.nreps), h = (rem / s.o.nreps) % s.nholo;
-  const double power = s.powers_desc[pi];
-  for (int i = lane; i < H; i += CM_WAVE) {
-    const int idx = h * H + i;
-    int n = -1;
-    if (idx < N) { n = s.orders[(size_t)r * N + idx]; s.stim[(size_t)n * s.K + k] = power; }
-    s.cells[(size_t)k * H + i] = n;
+  double power;
+  if (s.random_design) {
+    // 'random' (:65-77): entry t of the equal split of the powers (caller's order: np.array_split sizes), H targets with replacement
+    const int P = s.o.n_powers, q = s.K / P, rmd = s.K % P;                // the first `rmd` groups have q + 1 entries
+    const int pi = (t < rmd * (q + 1)) ? t / (q + 1) : rmd + (t - rmd * (q + 1)) / (q > 0 ? q : 1);
+    power = s.o.powers[pi];
+    for (int i = lane; i < H; i += CM_WAVE) {
+      const int n = (int)floor(sim_uniform(s.o.seed, S_TARGET, (uint64_t)k * H + i) * N);
+      bool dup = false;
+      for (int j = 0; j < i; ++j) dup |= ((int)floor(sim_uniform(s.o.seed, S_TARGET, (uint64_t)k * H + j) * N) == n);
+      s.stim[(size_t)n * s.K + k] = power;
+      s.cells[(size_t)k * H + i] = dup ? -1 : n;
+    }
+  } else {
+    const int r = t / s.tpr, rem = t - r * s.tpr;
+    const int pi = rem / (s.nholo * s.o.nreps), h = (rem / s.o.nreps) % s.nholo;
+    power = s.powers_desc[pi];
+    for (int i = lane; i < H; i += CM_WAVE) {
+      const int idx = h * H + i;
+      int n = -1;
+      if (idx < N) { n = s.orders[(size_t)r * N + idx]; s.stim[(size_t)n * s.K + k] = power; }
+      s.cells[(size_t)k * H + i] = n;
+    }
   }
   if (lane == 0 && s.I) s.I[k] = power;
 }
@@ -294,9 +310,10 @@ extern "C" void cm_sim_options_default(cm_sim_options* o) {
   o->seed = 0;
 }
 
-extern "C" int cm_simulate(cm_ctx* ctx, const cm_sim_options* o, const cm_sim_result* out, int mem, float* device_ms) {
+extern "C" int cm_simulate(cm_ctx* ctx, const cm_sim_options* o, int design, const cm_sim_result* out, int mem, float* device_ms) {
   if (!ctx || !o || !out || !out->psc || !out->stim_matrix) { cm_set_error("cm_simulate: NULL argument (psc and stim_matrix are required)"); return CM_ERR_INVALID; }
   const int N = o->N, T = o->T, H = o->H, K = o->trials;
+  if (design != CM_SIM_BLOCKWISE && design != CM_SIM_RANDOM) { cm_set_error("cm_simulate: design must be CM_SIM_BLOCKWISE or CM_SIM_RANDOM"); return CM_ERR_INVALID; }
   if (N < 2 || K < 1 || T < 2 || H < 1 || H > SIM_MAX_H || o->nreps < 1 || o->n_powers < 1 || o->n_powers > CM_SIM_MAX_POWERS ||
       N > CM_SIM_MAX_DIM || K > CM_SIM_MAX_DIM || !(o->gp_lengthscale > 0.0) || o->gp_lengthscale > 200.0) {
     cm_set_error("cm_simulate: need 2 <= N <= %d, 1 <= trials <= %d, T >= 2, 1 <= H <= %d, 1 <= n_powers <= %d, 0 < gp_lengthscale <= 200",
@@ -316,6 +333,8 @@ extern "C" int cm_simulate(cm_ctx* ctx, const cm_sim_options* o, const cm_sim_re
   s.nholo = (N + H - 1) / H;
   s.tpr = o->n_powers * s.nholo * o->nreps;
   s.R = (K + s.tpr - 1) / s.tpr;
+  s.random_design = design;
+  if (design) s.R = 0;
   s.n_conn = (int)(o->connection_prob * N);
   s.n_strong = (int)std::ceil(o->frac_strongly_connected * s.n_conn);
   s.J = (int)(GP_HALF_WIDTHS * o->gp_lengthscale);

@@ -170,7 +170,7 @@ _SIM_KEYS = ("N", "T", "H", "trials", "nreps", "connection_prob", "min_latency",
 
 def simulate_device(powers=(45, 55, 65), design="blockwise", device_id=0, keep_on_device=False, full=True, **kw):
     """`simulate` generated ON the MI355X (include/sim_hip.h, circuitmap_amd/csrc/cm_sim.hip): same arguments, defaults and
-    returned keys as the reference's ``simulate`` (circuitmap/simulation.py:25-195, blockwise design), counter-based draws.
+    returned keys as the reference's ``simulate`` (circuitmap/simulation.py:25-195, both designs), counter-based draws.
 
     keep_on_device=False  -> dict of NumPy arrays (keys of the reference's `sim` dict; `full=False` skips the N x K and
                              per-component K x T extras and returns psc, stim_matrix, weights, phi_0, phi_1, I only)
@@ -179,8 +179,8 @@ def simulate_device(powers=(45, 55, 65), design="blockwise", device_id=0, keep_o
     There is no CPU fallback; the NumPy restatement is `simulate` above."""
     import ctypes as C
     from . import _lib
-    if design != "blockwise":
-        raise NotImplementedError("simulate_device implements design='blockwise' (the reference's default)")
+    assert design in ["random", "blockwise"]
+    dcode = 0 if design == "blockwise" else 1
     lib = _lib.load()
     o = _lib.CmSimOptions()
     lib.cm_sim_options_default(C.byref(o))
@@ -207,7 +207,7 @@ def simulate_device(powers=(45, 55, 65), design="blockwise", device_id=0, keep_o
         for k, p in dsmall.items():
             setattr(res, k, p)
         try:
-            _lib.check(lib.cm_simulate(ctx.handle, C.byref(o), C.byref(res), _lib.CM_MEM_DEVICE, C.byref(ms)))
+            _lib.check(lib.cm_simulate(ctx.handle, C.byref(o), dcode, C.byref(res), _lib.CM_MEM_DEVICE, C.byref(ms)))
             for k, v in small.items():
                 ctx.download(dsmall[k], v)
         except Exception:
@@ -223,7 +223,7 @@ def simulate_device(powers=(45, 55, 65), design="blockwise", device_id=0, keep_o
         big.update(spks=np.empty((N, K)), spk_times=np.empty((N, K)), gp_noise=np.empty((K, T)), spont_pscs=np.empty((K, T)))
     for k, v in list(small.items()) + list(big.items()):
         setattr(res, k, v.ctypes.data)
-    _lib.check(lib.cm_simulate(ctx.handle, C.byref(o), C.byref(res), _lib.CM_MEM_HOST, C.byref(ms)))
+    _lib.check(lib.cm_simulate(ctx.handle, C.byref(o), dcode, C.byref(res), _lib.CM_MEM_HOST, C.byref(ms)))
     out = dict(small)
     out.update(big)
     out.update(sigma=o.sigma, kernel=None, mult_noise=None, device_ms=float(ms.value))

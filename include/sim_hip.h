@@ -1,8 +1,8 @@
 /*
  * sim_hip.h -- C ABI of the device-side synthetic experiment generator in libcaviar_hip.so (MI355X, gfx950).
  *
- * Generative model of the reference's `circuitmap.simulation.simulate(design='blockwise')`
- * (reference circuitmap/simulation.py:25-195): blockwise H-spot hologram design (:44-63), per-neuron PSC kernels and
+ * Generative model of the reference's `circuitmap.simulation.simulate`
+ * (reference circuitmap/simulation.py:25-195): blockwise H-spot hologram design (:44-63) or random design (:65-77), per-neuron PSC kernels and
  * power curves (:81-92), Bernoulli spikes padded to a minimum rate at maximal power (:93-108), gamma latencies
  * (:110-114,197-198), sparse strong/weak connectivity (:116-127), evoked PSCs (:17-23,141-155), spontaneous PSCs
  * (:157-170), correlated + iid noise (:172-176).  Same argument names and defaults (cm_sim_options_default).
@@ -55,8 +55,10 @@ typedef struct cm_sim_result {
   double* tau_d;        /* [N] */
 } cm_sim_result;
 
+typedef enum cm_sim_design { CM_SIM_BLOCKWISE = 0, CM_SIM_RANDOM = 1 } cm_sim_design;   /* `design` keyword (simulation.py:32,44,65) */
+
 void cm_sim_options_default(cm_sim_options* o);      /* N=300, T=900, H=10, trials=1000, powers {45,55,65}, ... seed=0 */
-int cm_simulate(cm_ctx* ctx, const cm_sim_options* o, const cm_sim_result* out, int mem, float* device_ms);
+int cm_simulate(cm_ctx* ctx, const cm_sim_options* o, int design, const cm_sim_result* out, int mem, float* device_ms);
 
 #ifdef __cplusplus
 }

@@ -26,7 +26,7 @@ from .threefry import threefry2x32
 
 # stream ids
 S_ORDER, S_SHUFFLE, S_CONN, S_TAU_R, S_TAU_D, S_PHI0, S_PHI1, S_WEIGHT, S_SPIKE, S_PAD, S_GAMMA_N, S_GAMMA_U, S_MULT, \
-    S_SPONT, S_SP_TR, S_SP_TD, S_SP_T0, S_SP_W, S_GP, S_IID, S_GAMMA_B = range(21)
+    S_SPONT, S_SP_TR, S_SP_TD, S_SP_T0, S_SP_W, S_GP, S_IID, S_GAMMA_B, S_TARGET = range(22)
 
 GAMMA_TRIES = 16
 GP_HALF_WIDTHS = 4          # filter support = +- 4 lengthscales
@@ -35,7 +35,7 @@ DEFAULTS = dict(N=300, T=900, H=10, trials=1000, nreps=1, connection_prob=0.05, 
                 gamma_beta=15.0, sigma=6e-4, frac_strongly_connected=0.2, strong_weight_lower=20.0, strong_weight_upper=40.0,
                 weak_exp_mean=4.0, min_weight=9.0, phi_0_lower=0.2, phi_0_upper=0.25, phi_1_lower=10.0, phi_1_upper=15.0,
                 mult_noise_log_var=0.01, tau_r_min=25.0, tau_r_max=60.0, tau_delta_min=75.0, tau_delta_max=250.0, gp_scale=4e-3,
-                gp_lengthscale=50.0, spont_prob=0.05, max_power_min_spike_rate=0.4, seed=0)
+                gp_lengthscale=50.0, spont_prob=0.05, max_power_min_spike_rate=0.4, seed=0, design="blockwise")
 
 
 def bits64(seed, stream, idx):
@@ -116,20 +116,32 @@ def simulate(**kw):
     R = -(-K // tpr)
 
     # ---- design
-    orders = np.stack([random_order(seed, S_ORDER, np.uint64(r) * np.uint64(N), N) for r in range(R)])
-    reorder = random_order(seed, S_SHUFFLE, np.uint64(0), K)
     stim = np.zeros((N, K))
     trial_power = np.zeros(K)
     trial_cells = -np.ones((K, H), dtype=np.int32)
-    for k in range(K):
-        t = int(reorder[k])
-        r, rem = divmod(t, tpr)
-        pi, h = rem // (nholo * nreps), (rem // nreps) % nholo
-        cells = orders[r, h * H:(h + 1) * H]
-        stim[cells, k] = powers[pi]
-        trial_power[k] = powers[pi]
-        trial_cells[k, :len(cells)] = cells
-
+    if o["design"] == "blockwise":
+        orders = np.stack([random_order(seed, S_ORDER, np.uint64(r) * np.uint64(N), N) for r in range(R)])
+        reorder = random_order(seed, S_SHUFFLE, np.uint64(0), K)
+        for k in range(K):
+            t = int(reorder[k])
+            r, rem = divmod(t, tpr)
+            pi, h = rem // (nholo * nreps), (rem // nreps) % nholo
+            cells = orders[r, h * H:(h + 1) * H]
+            stim[cells, k] = powers[pi]
+            trial_power[k] = powers[pi]
+            trial_cells[k, :len(cells)] = cells
+    else:
+        # 'random' (:65-77): a shuffled equal split of the powers (in the caller's order) over the trials, H targets per trial
+        # drawn WITH replacement (a repeated cell collapses, so a trial can have fewer than H distinct targets)
+        plist = np.asarray(o["powers"], dtype=np.float64)
+        split = np.concatenate([np.full(len(a), p) for p, a in zip(plist, np.array_split(np.ones(K), len(plist)))])
+        reorder = random_order(seed, S_SHUFFLE, np.uint64(0), K)
+        for k in range(K):
+            tars = np.floor(uniform(seed, S_TARGET, np.uint64(k) * np.uint64(H) + np.arange(H, dtype=np.uint64)) * N).astype(np.int32)
+            trial_power[k] = split[reorder[k]]
+            stim[tars, k] = trial_power[k]
+            for i, n in enumerate(tars):
+                trial_cells[k, i] = n if n not in tars[:i] else -1
     # ---- per-neuron parameters
     n_idx = np.arange(N, dtype=np.uint64)
     tau_r = o["tau_r_min"] + (o["tau_r_max"] - o["tau_r_min"]) * uniform(seed, S_TAU_R, n_idx)

@@ -12,7 +12,8 @@ def _close(a, b, tol):
 
 
 @pytest.mark.parametrize("kw", [dict(N=60, trials=240, seed=3), dict(N=97, trials=500, H=7, seed=8, powers=(30.0, 50.0, 70.0, 120.0)),
-                                dict(N=300, trials=1000, seed=1), dict(N=64, trials=200, nreps=2, T=700, seed=5, gp_lengthscale=25.0)])
+                                dict(N=300, trials=1000, seed=1), dict(N=64, trials=200, nreps=2, T=700, seed=5, gp_lengthscale=25.0),
+                                dict(N=80, trials=301, design="random", seed=9), dict(N=12, trials=90, H=10, design="random", seed=2)])
 def test_matches_oracle(kw):
     from oracle import sim_oracle as so
     from circuitmap_amd.simulation import simulate_device
@@ -66,8 +67,8 @@ def test_argument_checks():
     from circuitmap_amd.simulation import simulate_device
     with pytest.raises(TypeError):
         simulate_device(N=50, trials=100, bogus=1)
-    with pytest.raises(NotImplementedError):
-        simulate_device(N=50, trials=100, design="random")
+    with pytest.raises(AssertionError):
+        simulate_device(N=50, trials=100, design="spiral")
     with pytest.raises(_lib.CaviarHipError):
         simulate_device(N=50, trials=100, H=100)
     with pytest.raises(_lib.CaviarHipError):

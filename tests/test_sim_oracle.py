@@ -82,3 +82,17 @@ def test_same_distribution_as_numpy_restatement():
     ya = np.sum(na, axis=1)
     wa = (a["spks"] * a["weights"][:, None]).sum(axis=0)
     assert np.corrcoef(ya, wa)[0, 1] > 0.98
+
+
+def test_random_design_contract():
+    """design='random' (:65-77): equal power representation, H targets per trial drawn with replacement"""
+    a = so.simulate(N=40, trials=301, design="random", seed=4)
+    st = a["stim_matrix"]
+    nt = (st > 0).sum(axis=0)
+    assert nt.max() <= 10 and nt.min() >= 1 and (nt < 10).any()            # repeated draws collapse
+    counts = sorted((a["I"] == p).sum() for p in (45.0, 55.0, 65.0))
+    assert counts == [100, 100, 101]                                       # np.array_split sizes
+    assert np.array_equal(a["I"], st.max(axis=0))
+    for k in range(301):
+        c = a["trial_cells"][k]
+        assert sorted(c[c >= 0]) == sorted(np.flatnonzero(st[:, k]))
