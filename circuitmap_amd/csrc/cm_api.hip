@@ -510,12 +510,18 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
     tm->sum_active = sum_active;
     int meta[8] = {0};
     if (hipMemcpy(meta, p->seq_meta, sizeof(meta), hipMemcpyDeviceToHost) == hipSuccess) { tm->sum_seq_rows = meta[4]; tm->sum_seq_records = meta[5]; }
+    static const bool trace_iters = getenv("CAVIAR_HIP_TRACE_ITERS") != nullptr;
     for (int it = 0; it < iters; ++it) {
       float d = 0;
       hipEventElapsedTime(&d, EV(it, 3), EV(it, 4));
       tm->sweep_seq_ms += d;
       hipEventElapsedTime(&d, EV(it, 8), EV(it, 9));
       tm->mid_ms += d;
+      if (trace_iters && it > 0) {                                            // diagnostic: wall time of every iteration
+        float e = 0;
+        hipEventElapsedTime(&e, EV(it - 1, 9), EV(it, 9));
+        fprintf(stderr, "it %2d %8.1f us (k_iter_mid incl. its launch gap %.1f)\n", it, e * 1e3, d * 1e3);
+      }
       if (!phases) continue;
       hipEventElapsedTime(&d, EV(it, 0), EV(it, 1)); tm->solve_ms += d;        // host wait + large-set solve (small sets are fused)
       hipEventElapsedTime(&d, EV(it, 1), EV(it, 3)); tm->sweep_indep_ms += d;  // pre-sweep + pack
