@@ -24,9 +24,14 @@ class Model:
     def fit(self, obs, stimuli, method='caviar', fit_options=dict()):
         if method == 'caviar':
             self._fit_caviar(obs, stimuli, fit_options)
-        elif method in ('mbcs', 'cavi_sns'):
-            raise NotImplementedError("method '%s' is outside the MI355X hot-path scope (SURVEY.md section 2); "
-                                      "only method='caviar' is implemented" % method)
+        elif method == 'cavi_sns':
+            # the reference's own cavi_sns cannot run: its update_lam reads `key` before assigning it inside body_fun
+            # (circuitmap/optimise/cavi_sns.py:138-146 unpacks the carry as `current_key`, then splits `key`) -> UnboundLocalError
+            raise NotImplementedError("method 'cavi_sns' is not implemented: the reference's implementation raises UnboundLocalError "
+                                      "(cavi_sns.py:146), so there is no behaviour to reproduce; use method='caviar'")
+        elif method == 'mbcs':
+            raise NotImplementedError("method 'mbcs' is outside the MI355X hot-path scope (SURVEY.md section 2); "
+                                      "only method='caviar' is implemented")
         else:
             raise Exception          # reference circuitmap/model.py:44
 

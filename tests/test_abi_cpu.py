@@ -108,6 +108,22 @@ def test_model_defaults_and_dispatch():
         m.fit(None, None, method="bogus")
     with pytest.raises(NotImplementedError):
         m.fit(None, None, method="mbcs")
+    with pytest.raises(NotImplementedError, match="UnboundLocalError"):
+        m.fit(None, None, method="cavi_sns")
+
+
+def test_reference_cavi_sns_cannot_run():
+    """Why method='cavi_sns' has no MI355X counterpart: in the reference's update_lam the loop body unpacks the carried key as
+    `current_key` and then evaluates `jax.random.split(key)` while assigning `key` in the same scope (cavi_sns.py:138-146).
+    The same scoping, restated, raises UnboundLocalError in any Python -- there is no behaviour to reproduce."""
+    def update_lam(key):
+        def body_fun(m, carry):
+            lam_vector, current_key = carry
+            key, key_next = (key, key)          # noqa: F821,F841  (shape of the reference statement: `key, key_next = split(key)`)
+            return lam_vector, key_next
+        return body_fun(0, (None, key))
+    with pytest.raises(UnboundLocalError):
+        update_lam(1)
 
 
 def test_simulate_contract():
