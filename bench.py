@@ -7,10 +7,12 @@
 
 A "step" is one complete `caviar()` run of one circuit per GPU: `iters` (50) CAVIaR iterations plus the
 false-negative scan and final phi update (reference circuitmap/optimise/caviar.py:79-98), on synthetic data of the
-BASELINE shape (N=1000 neurons, K=2000 trials, T=900 samples; seeded restatement of the reference's `simulate`).
+BASELINE shape (N=1000 neurons, K=2000 trials, T=900 samples; seeded restatement of the reference's `simulate`, generated on the
+GPU by default -- include/sim_hip.h -- or on the host with --host-sim).
 Inputs (PSC integrals + encoded stimulus) are resident in HBM before the timed region; results stay in HBM.
 value = (circuits x iterations) / wall time, whole job, max over ranks.  For N > 1 GPUs every rank fits its own
-independent circuit (seed 2000 + rank): embarrassingly parallel, no data-path collective ("weak" scaling).
+independent circuit (N circuits, seeds 2000 .. 2000 + N - 1, rotated over the ranks step by step so that every GPU sees the same
+mix): embarrassingly parallel, no data-path collective ("weak" scaling).
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, live HIP-event timing from the library) and
 `cpu_baseline` (the literal float64 oracle timed on this host, N=1 only).
@@ -173,8 +175,9 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--phases", action="store_true", help="stamp every phase of every iteration (more host API calls)")
-    ap.add_argument("--device-sim", action="store_true", help="generate the synthetic experiment on the GPU (include/sim_hip.h): "
-                    "psc and stim_matrix never exist on the host")
+    ap.add_argument("--circuit-seed", type=int, default=2000, help="seed of rank 0's synthetic circuit (rank r uses seed + r)")
+    ap.add_argument("--host-sim", action="store_true", help="generate the synthetic experiments with the NumPy restatement on the host "
+                    "(default: on the GPU, include/sim_hip.h -- psc and stim_matrix never exist on the host)")
     a = ap.parse_args()
     if a.workload == "nwd":
         return bench_nwd(a)
@@ -212,17 +215,24 @@ def main():
     wl = WORKLOADS[a.workload]
     N, K, T, H = wl["N"], wl["K"], wl["T"], wl["H"]
     pri = default_priors(N)
-    gen_ms = None
-    if a.device_sim:
-        from circuitmap_amd.simulation import simulate_device
-        dsim = simulate_device(N=N, T=T, H=H, trials=K, seed=2000 + rank, device_id=local_rank, keep_on_device=True)
-        ctx, gen_ms = dsim["ctx"], dsim["device_ms"]
-        prob = Problem(ctx, None, None, device_ptrs=(N, K, T, dsim["psc_ptr"], dsim["stim_ptr"]))   # one-off prologue: outside the timed region
-        sim = None
-    else:
-        sim = simulate(N=N, T=T, H=H, trials=K, seed=2000 + rank, lite=(N > 2000))
-        ctx = _lib.Context(local_rank)
-        prob = Problem(ctx, sim["psc"], sim["stim_matrix"])        # H2D + one-off prologue: outside the timed region
+    # One independent circuit per GPU and step.  With N ranks there are N circuits (seeds circuit_seed .. circuit_seed + N - 1), every
+    # rank holds all of them in HBM and fits circuit (rank + step) mod N at step `step`: at any moment the N GPUs work on N different
+    # circuits, and over the run every GPU sees the same mix, so the max-over-ranks time measures the machine, not which rank drew
+    # the circuit with the slowest active-set trajectory (fit time varies +-4 % between these seeds).  N = 1: one circuit.
+    gen_ms, dsims, sims, probs = None, [], [], []
+    ctx = _lib.Context(local_rank) if a.host_sim else None
+    for c in range(world):
+        if a.host_sim:
+            sim = simulate(N=N, T=T, H=H, trials=K, seed=a.circuit_seed + c, lite=(N > 2000))
+            sims.append(sim)
+            probs.append(Problem(ctx, sim["psc"], sim["stim_matrix"]))        # H2D + one-off prologue: outside the timed region
+        else:
+            from circuitmap_amd.simulation import simulate_device
+            d = simulate_device(N=N, T=T, H=H, trials=K, seed=a.circuit_seed + c, device_id=local_rank, keep_on_device=True)
+            ctx, gen_ms = d["ctx"], d["device_ms"]
+            dsims.append(d)
+            probs.append(Problem(ctx, None, None, device_ptrs=(N, K, T, d["psc_ptr"], d["stim_ptr"])))   # one-off prologue: outside the timed region
+    prob = probs[0]
     nnz, nvals = prob.nnz
     run_args = (pri["mu"], pri["beta"], pri["shape"], pri["rate"], pri["phi"], pri["phi_cov"])
     opts = dict(iters=a.iters, seed=0)
@@ -235,13 +245,15 @@ def main():
         torch.cuda.synchronize()
         ctx.synchronize()
 
-    for _ in range(a.warmup):
-        prob.run(*run_args, **opts)
+    for w in range(a.warmup):
+        probs[(rank + w) % world].run(*run_args, **opts)
+    for c in range(a.warmup, world):                       # every circuit of the rotation has run once before the clock starts
+        probs[(rank + c) % world].run(*run_args, **opts)
     barrier()
     t0 = time.perf_counter()
     tms = []
-    for _ in range(a.steps):
-        tms.append(prob.run(*run_args, **opts).as_dict())
+    for step in range(a.steps):
+        tms.append(probs[(rank + step) % world].run(*run_args, **opts).as_dict())
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -279,7 +291,8 @@ def main():
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic" if gen_ms is None else "synthetic (generated on the GPU in %.2f ms)" % gen_ms,
             "config": {"workload": "%s: N=%d neurons, K=%d trials, T=%d, H=%d targets/trial, %d iterations + fn_scan per step, "
-                                   "1 circuit per GPU" % (a.workload, N, K, T, H, its),
+                                   "1 circuit per GPU and step%s" % (a.workload, N, K, T, H, its,
+                                                                      "" if world == 1 else ", %d circuits rotated over the ranks" % world),
                        "nnz_targeted": int(nnz), "distinct_powers": int(nvals) - 1,
                        "mean_active_set": float(np.mean([t["sum_active"] for t in tms])) / max(its, 1)},
             "roofline": {"bound": "hbm", "kernel": "k_iter_mid", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -294,13 +307,17 @@ def main():
             "phase_ms_per_step": phase,
         }
         if world == 1 and not a.no_cpu_baseline:
-            if sim is None:                                    # the oracle needs host copies of what the GPU generated
-                sim = {"psc": ctx.download(dsim["psc_ptr"], np.empty((K, T))), "stim_matrix": ctx.download(dsim["stim_ptr"], np.empty((N, K)))}
+            if sims:
+                sim = sims[0]
+            else:                                              # the oracle needs host copies of what the GPU generated
+                sim = {"psc": ctx.download(dsims[0]["psc_ptr"], np.empty((K, T))),
+                       "stim_matrix": ctx.download(dsims[0]["stim_ptr"], np.empty((N, K)))}
             out["cpu_baseline"] = cpu_baseline(sim, pri, wl)
         print(json.dumps(out), flush=True)
-    prob.close()
-    if a.device_sim:
-        ctx.free(dsim["psc_ptr"]); ctx.free(dsim["stim_ptr"])
+    for q in probs:
+        q.close()
+    for d in dsims:
+        ctx.free(d["psc_ptr"]); ctx.free(d["stim_ptr"])
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
