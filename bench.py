@@ -34,6 +34,11 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def circuit_for(rank, step, world):
+    """which of the `world` circuits rank `rank` fits at step `step` (see main): a Latin-square rotation"""
+    return (rank + step) % world
+
+
 def default_priors(N):
     import numpy as np
     return dict(mu=np.zeros(N), beta=1e1 * np.ones(N), shape=1.0, rate=1e-1,
@@ -246,14 +251,14 @@ def main():
         ctx.synchronize()
 
     for w in range(a.warmup):
-        probs[(rank + w) % world].run(*run_args, **opts)
+        probs[circuit_for(rank, w, world)].run(*run_args, **opts)
     for c in range(a.warmup, world):                       # every circuit of the rotation has run once before the clock starts
-        probs[(rank + c) % world].run(*run_args, **opts)
+        probs[circuit_for(rank, c, world)].run(*run_args, **opts)
     barrier()
     t0 = time.perf_counter()
     tms = []
     for step in range(a.steps):
-        tms.append(probs[(rank + step) % world].run(*run_args, **opts).as_dict())
+        tms.append(probs[circuit_for(rank, step, world)].run(*run_args, **opts).as_dict())
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:

@@ -80,3 +80,14 @@ def test_shard_indices_partition():
             parts = [shard_indices(n, r, w) for r in range(w)]
             assert sorted(sum(parts, [])) == list(range(n))
             assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_bench_circuit_rotation():
+    """bench.py with N ranks: at every step the ranks fit N different circuits, and over any N consecutive steps every rank
+    fits every circuit once (equal work per GPU by construction)."""
+    import bench
+    for world in (1, 2, 4, 8):
+        for step in range(3 * world):
+            assert sorted(bench.circuit_for(r, step, world) for r in range(world)) == list(range(world))
+        for r in range(world):
+            assert sorted(bench.circuit_for(r, s, world) for s in range(5, 5 + world)) == list(range(world))
