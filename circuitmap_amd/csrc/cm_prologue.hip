@@ -186,33 +186,35 @@ __global__ __launch_bounds__(256) void k_stim_fill_csr(const double* __restrict_
   }
 }
 
-// CSC: one thread per trial column walks the rows in order (coalesced across the wave), so each
-// column's entries come out sorted by neuron -> deterministic summation order downstream.
-__global__ __launch_bounds__(256) void k_stim_colcount(const double* __restrict__ stim, int N, int K, int* __restrict__ col_cnt) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= K) return;
-  int c = 0;
-  for (int n = 0; n < N; ++n) c += (stim[(size_t)n * K + k] > 0.0);
-  col_cnt[k] = c;
+// CSC from the CSR entries (nnz-sized work; the dense matrix is not read again): count the entries of every trial column,
+// scan, scatter (neuron, CSR position) pairs through per-column cursors, then order each column by neuron so that the
+// summation order downstream is deterministic (the cursor order is not).
+__global__ __launch_bounds__(256) void k_csc_count(const int* __restrict__ row_ptr, const int* __restrict__ col, int N, int* __restrict__ col_cnt) {
+  const int n = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE, lane = threadIdx.x % CM_WAVE;
+  if (n >= N) return;
+  for (int e = row_ptr[n] + lane; e < row_ptr[n + 1]; e += CM_WAVE) atomicAdd(&col_cnt[col[e]], 1);
 }
-
-__global__ __launch_bounds__(256) void k_stim_fill_csc(const double* __restrict__ stim, int N, int K, const int* __restrict__ col_ptr,
-                                                        const int* __restrict__ row_ptr, const int* __restrict__ col,
-                                                        int* __restrict__ csc_row, int* __restrict__ csc_pos) {
+__global__ __launch_bounds__(256) void k_csc_scatter(const int* __restrict__ row_ptr, const int* __restrict__ col, int N,
+                                                      const int* __restrict__ col_ptr, int* __restrict__ cursor,
+                                                      int* __restrict__ csc_row, int* __restrict__ csc_pos) {
+  const int n = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE, lane = threadIdx.x % CM_WAVE;
+  if (n >= N) return;
+  for (int e = row_ptr[n] + lane; e < row_ptr[n + 1]; e += CM_WAVE) {
+    const int k = col[e];
+    const int w = col_ptr[k] + atomicAdd(&cursor[k], 1);
+    csc_row[w] = n;
+    csc_pos[w] = e;
+  }
+}
+__global__ __launch_bounds__(256) void k_csc_sort(const int* __restrict__ col_ptr, int K, int* __restrict__ csc_row, int* __restrict__ csc_pos) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= K) return;
-  int w = col_ptr[k];
-  for (int n = 0; n < N; ++n) {
-    if (stim[(size_t)n * K + k] > 0.0) {
-      int lo = row_ptr[n], hi = row_ptr[n + 1] - 1;   // binary search of k in the row's sorted trial list
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (col[mid] < k) lo = mid + 1; else hi = mid;
-      }
-      csc_row[w] = n;
-      csc_pos[w] = lo;
-      ++w;
-    }
+  const int b = col_ptr[k], e = col_ptr[k + 1];
+  for (int i = b + 1; i < e; ++i) {                     // insertion sort by neuron (a neuron appears once per column)
+    const int r = csc_row[i], q = csc_pos[i];
+    int j = i - 1;
+    while (j >= b && csc_row[j] > r) { csc_row[j + 1] = csc_row[j]; csc_pos[j + 1] = csc_pos[j]; --j; }
+    csc_row[j + 1] = r; csc_pos[j + 1] = q;
   }
 }
 
@@ -241,8 +243,6 @@ int cm_encode_stim(cm_ctx* ctx, cm_problem* p, const double* d_stim) {
   const int row_blocks = (N + 3) / 4;
   hipLaunchKernelGGL(k_stim_rowcount, dim3(row_blocks), dim3(256), 0, st, d_stim, N, K, p->vals, d_flags + 1, p->rowcnt, d_row_nnz);
   hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, st, d_row_nnz, N, p->row_ptr);
-  hipLaunchKernelGGL(k_stim_colcount, dim3((K + 255) / 256), dim3(256), 0, st, d_stim, N, K, d_col_cnt);
-  hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, st, d_col_cnt, K, p->col_ptr);
   CM_HIP(hipGetLastError());
 
   int h_flags[4];
@@ -266,8 +266,12 @@ int cm_encode_stim(cm_ctx* ctx, cm_problem* p, const double* d_stim) {
   CM_HIP(hipMalloc(&p->csc_row, nnz_alloc * sizeof(int)));
   CM_HIP(hipMalloc(&p->csc_pos, nnz_alloc * sizeof(int)));
   hipLaunchKernelGGL(k_stim_fill_csr, dim3(row_blocks), dim3(256), 0, st, d_stim, N, K, p->vals, d_flags + 1, p->row_ptr, p->col, p->grp);
-  hipLaunchKernelGGL(k_stim_fill_csc, dim3((K + 255) / 256), dim3(256), 0, st, d_stim, N, K, p->col_ptr, p->row_ptr, p->col,
-                     p->csc_row, p->csc_pos);
+  CM_HIP(hipMemsetAsync(d_col_cnt, 0, (size_t)K * sizeof(int), st));
+  hipLaunchKernelGGL(k_csc_count, dim3(row_blocks), dim3(256), 0, st, p->row_ptr, p->col, N, d_col_cnt);
+  hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, st, d_col_cnt, K, p->col_ptr);
+  CM_HIP(hipMemsetAsync(d_col_cnt, 0, (size_t)K * sizeof(int), st));            // reused as the per-column cursors
+  hipLaunchKernelGGL(k_csc_scatter, dim3(row_blocks), dim3(256), 0, st, p->row_ptr, p->col, N, p->col_ptr, d_col_cnt, p->csc_row, p->csc_pos);
+  hipLaunchKernelGGL(k_csc_sort, dim3((K + 255) / 256), dim3(256), 0, st, p->col_ptr, K, p->csc_row, p->csc_pos);
   CM_HIP(hipGetLastError());
   p->h_col.resize(nnz_alloc);
   p->h_grp.resize(nnz_alloc);
