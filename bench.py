@@ -279,9 +279,9 @@ def main():
         mid_ms = float(np.mean([t["mid_ms"] for t in tms])) / its                # average launch duration, ms
         mid_bytes = K * (8 + 8 + 1 + 1 + 8) + N * (8 + 8 + 32) + nnz * 9 + N * (8 + 4 * nvals + 48 + 48 + 4 + 8 + 2 * S * 8 + 8 * (nvals - 1))
         achieved = mid_bytes / (mid_ms * 1e-3) / 1e9
-        # HBM traffic of the same kernel from rocprofv3 PMC passes (profiles/r01_d_pmc_*: FETCH_SIZE 1235.0 KB, doubled as the
+        # HBM traffic of the same kernel from rocprofv3 PMC passes (profiles/r01_h_cfg3_pmc_summary.csv: FETCH_SIZE 1227.6 KB, doubled as the
         # MI355X guide prescribes for gfx950, + WRITE_SIZE 102.1 KB per launch); measured for cfg3 only
-        traffic = {"cfg3": int((2 * 1235.0 + 102.1) * 1024)}.get(a.workload)
+        traffic = {"cfg3": int((2 * 1227.6 + 102.1) * 1024)}.get(a.workload)
         # --- the Gauss-Seidel chain kernel (k_sweep_par), second opinion: its launch time and the records it actually streamed
         seq_ms = float(np.mean([t["sweep_seq_ms"] for t in tms])) / its
         recs = float(np.mean([t["sum_seq_records"] for t in tms])) / its         # 32-B records per launch (average over the fit)
