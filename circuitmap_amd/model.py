@@ -44,8 +44,10 @@ class Model:
         t_end = time.time()
         names = ['mu', 'beta', 'lam', 'shape', 'rate', 'phi', 'phi_cov', 'z', 'receptive_fields']
         for name, val in zip(names, result[:9]):
-            self.state[name] = np.array(val)       # np.array(None) for receptive_fields, as model.py:126
+            # the reference copies device arrays into fresh NumPy arrays (model.py:118-126); optimise.caviar already returns fresh
+            # host arrays, so they are adopted without a second 16 MB copy of lam.  np.array(None) for receptive_fields, as :126.
+            self.state[name] = np.asarray(val) if val is not None else np.array(val)
         self.trial_count = self.state['lam'].shape[1]
         self.time = t_end - t_start
-        self.history = {k: np.array(v) for k, v in zip(['mu', 'beta', 'lam', 'shape', 'rate', 'phi', 'phi_cov', 'z'], result[9:17])}
+        self.history = {k: (np.asarray(v) if v is not None else np.array(v)) for k, v in zip(['mu', 'beta', 'lam', 'shape', 'rate', 'phi', 'phi_cov', 'z'], result[9:17])}
         return

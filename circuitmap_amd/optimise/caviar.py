@@ -39,7 +39,7 @@ class Problem:
             self._keep = None
         else:
             psc = _lib.f64(y_psc)
-            stim = _lib.f64(np.asarray(I).astype(float))          # caviar.py:35 (callers may pass ints)
+            stim = _lib.f64(I)                                    # caviar.py:35 (callers may pass ints); no copy if already float64
             if psc.ndim != 2 or stim.ndim != 2 or psc.shape[0] != stim.shape[1]:
                 raise ValueError("y_psc must be K x T and I must be N x K (got %s, %s)" % (psc.shape, stim.shape))
             N, K, T = stim.shape[0], stim.shape[1], psc.shape[1]
