@@ -42,6 +42,7 @@ struct cm_ctx {
   int num_cus = 256;
   void* h_stage = nullptr;        // pinned staging buffer (priors upload, fn_scan round trip), grown on demand
   size_t h_stage_bytes = 0;
+  size_t lds_attr[24] = {};       // dynamic-LDS caps already raised for this context's device, by kernel slot (cm_raise_lds)
   std::vector<hipEvent_t> pool;   // per-iteration events (CM_EV_PER_IT per iteration): phase stamps + cross-stream edges
 };
 
@@ -217,6 +218,19 @@ inline void cm_threefry2x32(uint32_t k0, uint32_t k1, uint32_t& x0, uint32_t& x1
   }
 }
 #endif
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, device): remember per context what has been raised, so that
+// a process driving several GPUs (one context each) configures every device, and no launch pays for a redundant call.
+enum cm_lds_slot { CM_LDS_ITER = 0 /* 7 x 2 template variants */, CM_LDS_SOLVE_SMALL = 14, CM_LDS_SWEEP_PAR, CM_LDS_SWEEP_PAR2, CM_LDS_SWEEP_SEQ,
+                   CM_LDS_NWD, CM_LDS_SIM_SORT };
+inline int cm_raise_lds(cm_ctx* ctx, int slot, const void* fn, size_t bytes, size_t floor_bytes) {
+  const size_t cur = ctx->lds_attr[slot] > floor_bytes ? ctx->lds_attr[slot] : floor_bytes;
+  if (bytes > cur) {
+    CM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    ctx->lds_attr[slot] = bytes;
+  }
+  return CM_OK;
+}
 
 // ------------------------------------------------------------------------------------------------
 // phase launchers (each enqueues kernels on ctx->stream; no host sync unless stated)

@@ -74,11 +74,8 @@ int cm_small_cap(const cm_problem* p) {
 
 template <int SEG, bool FULLMC>
 static int launch_iter2(cm_ctx* ctx, const IterArgs& a, size_t lds, int blocks) {
-  static thread_local size_t attr_set = 48 * 1024;
-  if (lds > attr_set) {
-    CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_iter_mid<SEG, FULLMC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = lds;
-  }
+  const int slot = CM_LDS_ITER + 2 * (31 - __builtin_clz((unsigned)SEG)) + (FULLMC ? 1 : 0);          // SEG = 1, 2, 4 .. 64
+  CM_TRY(cm_raise_lds(ctx, slot, reinterpret_cast<const void*>(k_iter_mid<SEG, FULLMC>), lds, 48 * 1024));
   hipLaunchKernelGGL((k_iter_mid<SEG, FULLMC>), dim3(blocks), dim3(CM_ITER_THREADS), lds, ctx->stream, a);
   CM_HIP(hipGetLastError());
   return CM_OK;

@@ -552,11 +552,7 @@ extern "C" int cm_nwd_demix(cm_ctx* ctx, const cm_nwd* nwd, int K, int T, const 
     d_out = tmp_out;
     if (raw) { NWD_HIP(hipMalloc(&tmp_raw, n * sizeof(float))); d_raw = tmp_raw; }
   }
-  static thread_local bool attr_set = false;
-  if (!attr_set) {
-    NWD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_nwd_forward), hipFuncAttributeMaxDynamicSharedMemorySize, NWD_LDS_LIMIT - 256));
-    attr_set = true;
-  }
+  if (cm_raise_lds(ctx, CM_LDS_NWD, reinterpret_cast<const void*>(k_nwd_forward), NWD_LDS_LIMIT - 256, 0) != CM_OK) { cleanup(); return CM_ERR_HIP; }
   const size_t lds_bytes = (size_t)pl.lds_floats * sizeof(float);
   NWD_HIP(hipEventRecord(ctx->ev[0], st));
   static const int stop = getenv("CAVIAR_NWD_STOP") ? atoi(getenv("CAVIAR_NWD_STOP")) : 0;

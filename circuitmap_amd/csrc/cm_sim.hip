@@ -385,11 +385,7 @@ extern "C" int cm_simulate(cm_ctx* ctx, const cm_sim_options* o, int design, con
   SIM_HIP(hipEventRecord(ctx->ev[0], st));
   int npad = 1;
   while (npad < std::max(N, K)) npad <<= 1;
-  static thread_local bool attr = false;
-  if (!attr) {
-    SIM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sim_sort), hipFuncAttributeMaxDynamicSharedMemorySize, CM_SIM_MAX_DIM * 8));
-    attr = true;
-  }
+  if (cm_raise_lds(ctx, CM_LDS_SIM_SORT, reinterpret_cast<const void*>(k_sim_sort), CM_SIM_MAX_DIM * 8, 0) != CM_OK) { hipFree(slab); return CM_ERR_HIP; }
   hipLaunchKernelGGL(k_sim_sort, dim3(s.R + 2), dim3(1024), (size_t)npad * sizeof(uint64_t), st, s);
   hipLaunchKernelGGL(k_sim_neurons, dim3(1), dim3(1024), 0, st, s);
   hipLaunchKernelGGL(k_sim_design, dim3((K + 3) / 4), dim3(256), 0, st, s);

@@ -472,11 +472,7 @@ int cm_solve_launch(cm_ctx* ctx, cm_problem* p, int na) {
     const int tot_cap = na * p->max_row_len;
     const size_t lds = small_lds_bytes(na, tot_cap);
     if (lds <= 150 * 1024) {
-      static thread_local size_t attr_set = 48 * 1024;
-      if (lds > attr_set) {
-        CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_small), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = lds;
-      }
+      CM_TRY(cm_raise_lds(ctx, CM_LDS_SOLVE_SMALL, reinterpret_cast<const void*>(k_solve_small), lds, 48 * 1024));
       hipLaunchKernelGGL(k_solve_small, dim3(1), dim3(1024), lds, st, p->lam, p->row_ptr, p->col, p->act_idx, p->rs, p->scal, p->mu_prior,
                          p->beta_prior, na, p->N, tot_cap, p->mu, p->beta, p->n_act + 1);
       CM_HIP(hipGetLastError());

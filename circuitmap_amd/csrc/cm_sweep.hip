@@ -726,27 +726,15 @@ int cm_launch_sweep(cm_ctx* ctx, cm_problem* p, int it, const cm_options* o, hip
   const int packed_cap = (int)std::min<long long>(cap, nrec);
   const int nchunks_cap = (int)std::min<long long>(CM_SEQ_LDS_CHUNKS - 1, nrec / 256 + 7);
   if (par == 1) {
-    static thread_local size_t attr_par = 0;
-    if (lds_par > attr_par) {
-      CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_par<CM_SEQ_CAP, int>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_par));
-      attr_par = lds_par;
-    }
+    CM_TRY(cm_raise_lds(ctx, CM_LDS_SWEEP_PAR, reinterpret_cast<const void*>(k_sweep_par<CM_SEQ_CAP, int>), lds_par, 0));
     hipLaunchKernelGGL((k_sweep_par<CM_SEQ_CAP, int>), dim3(1), dim3(1024), lds_par, st, a, (const SeqRec*)p->packed, packed_cap, nchunks_cap,
                        p->seq_off, p->chunk_first, p->seq_meta, p->K, p->R, p->n_act + 2);
   } else if (par == 2) {
-    static thread_local size_t attr_par2 = 0;
-    if (lds_par > attr_par2) {
-      CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_par<512, uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_par));
-      attr_par2 = lds_par;
-    }
+    CM_TRY(cm_raise_lds(ctx, CM_LDS_SWEEP_PAR2, reinterpret_cast<const void*>(k_sweep_par<512, uint8_t>), lds_par, 0));
     hipLaunchKernelGGL((k_sweep_par<512, uint8_t>), dim3(1), dim3(1024), lds_par, st, a, (const SeqRec*)p->packed, packed_cap, nchunks_cap,
                        p->seq_off, p->chunk_first, p->seq_meta, p->K, p->R, p->n_act + 2);
   } else if (lds <= 88 * 1024) {     // 64 KiB of record buffers + R must fit the CU's 160 KiB
-    static thread_local size_t attr_set = 0;      // raise the dynamic-LDS cap only when it has to grow
-    if (lds > attr_set) {
-      CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_seq<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set = lds;
-    }
+    CM_TRY(cm_raise_lds(ctx, CM_LDS_SWEEP_SEQ, reinterpret_cast<const void*>(k_sweep_seq<true>), lds, 0));   // only when it has to grow
     hipLaunchKernelGGL(k_sweep_seq<true>, dim3(1), dim3(1024), lds, st, a, (const SeqRec*)p->packed, packed_cap, nchunks_cap, p->seq_off, p->chunk_first,
                        p->seq_meta, p->K, p->col_ptr, p->csc_row, p->csc_pos, p->R);
   } else {
