@@ -146,7 +146,7 @@ __global__ __launch_bounds__(1024) void k_exclusive_scan(const int* __restrict__
     part[threadIdx.x] = v;
     __syncthreads();
     for (int o = 1; o < 1024; o <<= 1) {
-      int t = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+      int t = (int)threadIdx.x >= o ? part[threadIdx.x - o] : 0;
       __syncthreads();
       part[threadIdx.x] += t;
       __syncthreads();

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(1024) void k_sim_traces(SimDev s) {
   double* hf = zs + W;
   for (int q = threadIdx.x; q < W; q += blockDim.x) zs[q] = sim_normal(o.seed, S_GP, (uint64_t)k * W + q);
   for (int q = threadIdx.x; q < 2 * J + 1; q += blockDim.x) hf[q] = s.hfilt[q];
-  if (threadIdx.x < H) {
+  if ((int)threadIdx.x < H) {
     const int i = threadIdx.x, n = s.cells[(size_t)k * H + i];
     int sidx = -1;
     double amp = 0.0, td = 1.0, tr = 1.0;
