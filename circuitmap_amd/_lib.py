@@ -105,6 +105,7 @@ SYMBOLS = {
     "cm_k_update_phi": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, _dp, _dp, _dp, _dp]),
     "cm_k_reconnect": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_double]),
     "cm_k_rng_streams": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, _ip, _dp]),
+    "cm_k_event_pair_overhead": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float)]),
     # include/nwd_hip.h
     "cm_nwd_create": (C.c_int, [C.c_void_p, C.POINTER(CmNwdParams), C.POINTER(C.c_void_p)]),
     "cm_nwd_destroy": (None, [C.c_void_p]),

@@ -690,6 +690,27 @@ extern "C" int cm_k_reconnect(cm_ctx* ctx, int32_t N, int32_t K, const double* s
   return CM_OK;
 }
 
+__global__ void k_nop(int* sink) { if (sink && threadIdx.x == 0xFFFFFF) *sink = 0; }
+
+extern "C" int cm_k_event_pair_overhead(cm_ctx* ctx, int32_t reps, int32_t blocks, int32_t threads, float* ms_per_pair) {
+  if (!ctx || !ms_per_pair || reps < 1 || blocks < 1 || threads < 1 || threads > 1024) { cm_set_error("cm_k_event_pair_overhead: bad argument"); return CM_ERR_INVALID; }
+  CM_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  double sum = 0.0;
+  for (int r = 0; r < reps; ++r) {
+    hipLaunchKernelGGL(k_nop, dim3(blocks), dim3(threads), 0, st, (int*)nullptr);     // predecessor: the pair starts behind a running kernel
+    CM_HIP(hipEventRecord(ctx->ev[0], st));
+    hipLaunchKernelGGL(k_nop, dim3(blocks), dim3(threads), 0, st, (int*)nullptr);
+    CM_HIP(hipEventRecord(ctx->ev[1], st));
+    CM_HIP(hipStreamSynchronize(st));
+    float d = 0.0f;
+    CM_HIP(hipEventElapsedTime(&d, ctx->ev[0], ctx->ev[1]));
+    sum += d;
+  }
+  *ms_per_pair = (float)(sum / reps);
+  return CM_OK;
+}
+
 extern "C" int cm_k_rng_streams(cm_ctx* ctx, uint64_t seed, int32_t it, int32_t N, int32_t S, int32_t* order, double* u) {
   if (!ctx || !order || !u || N < 2 || S < 1 || it < 0) { cm_set_error("cm_k_rng_streams: bad argument"); return CM_ERR_INVALID; }
   CM_HIP(hipSetDevice(ctx->device));

@@ -177,6 +177,12 @@ int cm_k_reconnect(cm_ctx* ctx, int32_t N, int32_t K, const double* stim, double
 /* Threefry streams as the device generates them (for comparison with oracle/threefry.py): order[N], u[N*S*2] of iteration `it` */
 int cm_k_rng_streams(cm_ctx* ctx, uint64_t seed, int32_t it, int32_t N, int32_t S, int32_t* order, double* u);
 
+/* Measurement aid: cm_timings brackets a kernel with two HIP events recorded on the stream, so each figure contains one
+ * dependent-launch boundary besides the kernel itself.  This returns that boundary, measured the same way around a kernel that
+ * does nothing (average over `reps` event pairs behind a busy stream), so that bench.py can report kernel durations comparable
+ * with a profiler's kernel trace. */
+int cm_k_event_pair_overhead(cm_ctx* ctx, int32_t reps, int32_t blocks, int32_t threads, float* ms_per_pair);
+
 #ifdef __cplusplus
 }
 #endif
