@@ -151,7 +151,10 @@ def bench_nwd(a):
                "config": {"workload": "nwd: NeuralDemixer forward (U-Net + rescale + monotone filter) on %d traces x %d samples per GPU, "
                                       "seeded random parameters" % (K, T)},
                "roofline": {"bound": "mfma", "kernel": "k_nwd_forward", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s",
-                            "frac": achieved / 157.3, "traffic": None, "avg_launch_ms": k_ms,
+                            "frac": achieved / 157.3,
+                            # HBM bytes per launch from the PMC passes in profiles/r01_f_nwd_pmc.csv (FETCH_SIZE 8558.6 KB doubled per the
+                            # MI355X guide + WRITE_SIZE 14062.5 KB); algorithmic: 28.8 MB of float64 traces in and out
+                            "traffic": int((2 * 8558.6 + 14062.5) * 1024), "avg_launch_ms": k_ms,
                             "algorithmic_flops_per_launch": int(flops),
                             "hbm_bytes_per_launch": int(K * T * 16)}}
         if world == 1 and not a.no_cpu_baseline:
