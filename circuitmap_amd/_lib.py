@@ -30,7 +30,7 @@ class CmOptions(C.Structure):
                 ("scale_factor", C.c_double), ("penalty", C.c_double), ("save_histories", C.c_int32),
                 ("max_backtrack_iters", C.c_int32), ("tol", C.c_double), ("spont_orthogonality", C.c_double),
                 ("fn_scan", C.c_int32), ("rng_mode", C.c_int32), ("update_orders", _ip), ("uniforms", _dp),
-                ("verbose", C.c_int32)]
+                ("verbose", C.c_int32), ("timing", C.c_int32)]
 
 
 class CmResult(C.Structure):

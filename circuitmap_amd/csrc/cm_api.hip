@@ -36,7 +36,7 @@ extern "C" void cm_options_default(cm_options* o) {   // caviar.py:21-23
   o->iters = 50; o->num_mc_samples = 100; o->seed = 0; o->y_xcorr_thresh = 1e-2; o->minimum_spike_count = 3;
   o->delay_spont_est = 1; o->msrmp = 0.3; o->scale_factor = 0.75; o->penalty = 5e0; o->save_histories = 0;
   o->max_backtrack_iters = 20; o->tol = 0.05; o->spont_orthogonality = 0.1; o->fn_scan = 1;
-  o->rng_mode = CM_RNG_THREEFRY; o->update_orders = nullptr; o->uniforms = nullptr; o->verbose = 0;
+  o->rng_mode = CM_RNG_THREEFRY; o->update_orders = nullptr; o->uniforms = nullptr; o->verbose = 0; o->timing = 0;
 }
 
 extern "C" int cm_ctx_create(int device_id, void* hip_stream, cm_ctx** out) {
@@ -416,8 +416,9 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
   }
   if (o->save_histories && iters > 0) CM_TRY(alloc_hist(p, iters)); else free_hist(p);
 
-  const bool timed = tm != nullptr;              // stamps around k_sweep_seq (events 3, 4)
-  const bool phases = timed && o->verbose >= 1;  // all phase stamps (adds host API calls per iteration)
+  static const bool trace_iters = getenv("CAVIAR_HIP_TRACE_ITERS") != nullptr;   // diagnostic: implies the per-kernel stamps
+  const bool timed = tm != nullptr && (o->timing >= 1 || trace_iters);   // stamps around the chain kernel (events 3, 4) and k_iter_mid (8, 9)
+  const bool phases = tm != nullptr && o->timing >= 2;  // all phase stamps (more events and host API calls per iteration)
   while (ctx->pool.size() < (size_t)(iters + 1) * CM_EV_PER_IT) { hipEvent_t e; CM_HIP(hipEventCreate(&e)); ctx->pool.push_back(e); }
   auto EV = [&](int it, int j) { return ctx->pool[(size_t)it * CM_EV_PER_IT + j]; };
   auto post_wait_fallback = [&]() -> int {       // CAVIAR_HIP_NO_MAILBOX=1: classic copy + event instead of the mapped mailbox
@@ -475,7 +476,7 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
     CM_TRY(post_wait_fallback());
     if (o->save_histories) CM_TRY(record_hist(ctx, p, it, 1));       // shape, rate, phi, phi_cov, z
     if (phases) CM_HIP(hipEventRecord(EV(it, 5), st));
-    if (o->verbose >= 2) {
+    if (o->verbose >= 3) {
       CM_HIP(hipStreamSynchronize(st));
       fprintf(stderr, "[caviar_hip] it %d active %d\n", it, last_active);
     }
@@ -510,8 +511,7 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
     tm->sum_active = sum_active;
     int meta[8] = {0};
     if (hipMemcpy(meta, p->seq_meta, sizeof(meta), hipMemcpyDeviceToHost) == hipSuccess) { tm->sum_seq_rows = meta[4]; tm->sum_seq_records = meta[5]; }
-    static const bool trace_iters = getenv("CAVIAR_HIP_TRACE_ITERS") != nullptr;
-    for (int it = 0; it < iters; ++it) {
+    for (int it = 0; timed && it < iters; ++it) {
       float d = 0;
       hipEventElapsedTime(&d, EV(it, 3), EV(it, 4));
       tm->sweep_seq_ms += d;

@@ -15,7 +15,7 @@ _OPTION_NAMES = ["iters", "num_mc_samples", "seed", "y_xcorr_thresh", "minimum_s
 
 def make_options(lib, iters=50, num_mc_samples=100, seed=0, y_xcorr_thresh=1e-2, minimum_spike_count=3,
                  delay_spont_est=1, msrmp=0.3, scale_factor=0.75, penalty=5e0, save_histories=False,
-                 max_backtrack_iters=20, tol=0.05, spont_orthogonality=0.1, fn_scan=True, verbose=0):
+                 max_backtrack_iters=20, tol=0.05, spont_orthogonality=0.1, fn_scan=True, verbose=0, timing=0):
     o = _lib.CmOptions()
     lib.cm_options_default(C.byref(o))
     o.iters, o.num_mc_samples, o.seed = int(iters), int(num_mc_samples), int(seed)
@@ -23,6 +23,7 @@ def make_options(lib, iters=50, num_mc_samples=100, seed=0, y_xcorr_thresh=1e-2,
     o.delay_spont_est, o.msrmp, o.scale_factor, o.penalty = int(delay_spont_est), float(msrmp), float(scale_factor), float(penalty)
     o.save_histories, o.max_backtrack_iters, o.tol = int(bool(save_histories)), int(max_backtrack_iters), float(tol)
     o.spont_orthogonality, o.fn_scan, o.verbose = float(spont_orthogonality), int(bool(fn_scan)), int(verbose)
+    o.timing = int(timing)
     return o
 
 
@@ -58,13 +59,14 @@ class Problem:
         return nnz.value, nv.value
 
     def run(self, mu_prior, beta_prior, shape_prior, rate_prior, phi_prior, phi_cov_prior, update_orders=None,
-            uniforms=None, verbose=0, **fit_options):
-        """cm_caviar_run: results stay in HBM.  Returns the device timings."""
+            uniforms=None, verbose=0, timing=0, **fit_options):
+        """cm_caviar_run: results stay in HBM.  Returns the device timings (`timing` = 0: fit totals; 1: + per-kernel stamps of the
+        chain and mid-iteration kernels; 2: + all phase stamps -- the stamps cost ~8 % of a fit)."""
         N = self.N
         unknown = set(fit_options) - set(_OPTION_NAMES)
         if unknown:
             raise TypeError("caviar() got an unexpected keyword argument '%s'" % sorted(unknown)[0])
-        o = make_options(self.lib, verbose=verbose, **fit_options)
+        o = make_options(self.lib, verbose=verbose, timing=timing, **fit_options)
         keep = [_lib.f64(mu_prior, (N,)), _lib.f64(beta_prior, (N,)), _lib.f64(phi_prior, (N, 2)), _lib.f64(phi_cov_prior, (N, 2, 2))]
         pr = _lib.CmPriors(_lib.dptr(keep[0]), _lib.dptr(keep[1]), float(shape_prior), float(rate_prior), _lib.dptr(keep[2]),
                            _lib.dptr(keep[3]))
@@ -121,18 +123,19 @@ def caviar(y_psc, I, mu_prior, beta_prior, shape_prior, rate_prior, phi_prior, p
            iters=50, num_mc_samples=100, seed=0, y_xcorr_thresh=1e-2, minimum_spike_count=3,
            delay_spont_est=1, msrmp=0.3, scale_factor=0.75, penalty=5e0, save_histories=False,
            max_backtrack_iters=20, tol=0.05, spont_orthogonality=0.1, fn_scan=True, *,
-           device_id=0, update_orders=None, uniforms=None, verbose=0, return_timings=False):
+           device_id=0, update_orders=None, uniforms=None, verbose=0, return_timings=False, timing=0):
     """Coordinate-ascent variational inference and isotonic regularisation on one MI355X.
 
     Positional arguments, keyword names, defaults and the 17-element return value are those of the reference
     (circuitmap/optimise/caviar.py:20-23,100).  Keyword-only extras: `device_id`; `update_orders` [iters, N] and
-    `uniforms` [iters, N, S, 2] to replace the seeded threefry stream by explicit RNG streams.
+    `uniforms` [iters, N, S, 2] to replace the seeded threefry stream by explicit RNG streams; `return_timings` with
+    `timing` = 0 (fit totals), 1 (+ per-kernel stamps) or 2 (+ all phase stamps).
     """
     ctx = _lib.default_context(device_id)
     prob = Problem(ctx, y_psc, I)
     try:
         tm = prob.run(mu_prior, beta_prior, shape_prior, rate_prior, phi_prior, phi_cov_prior, update_orders=update_orders,
-                      uniforms=uniforms, verbose=verbose, iters=iters, num_mc_samples=num_mc_samples, seed=seed,
+                      uniforms=uniforms, verbose=verbose, timing=timing, iters=iters, num_mc_samples=num_mc_samples, seed=seed,
                       y_xcorr_thresh=y_xcorr_thresh, minimum_spike_count=minimum_spike_count, delay_spont_est=delay_spont_est,
                       msrmp=msrmp, scale_factor=scale_factor, penalty=penalty, save_histories=save_histories,
                       max_backtrack_iters=max_backtrack_iters, tol=tol, spont_orthogonality=spont_orthogonality, fn_scan=fn_scan)

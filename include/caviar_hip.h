@@ -76,7 +76,10 @@ typedef struct cm_options {
   int32_t rng_mode;                /* cm_rng_mode */
   const int32_t* update_orders;    /* CM_RNG_EXPLICIT: [iters*N] host, sweep order per iteration               */
   const double* uniforms;          /* CM_RNG_EXPLICIT: [iters*N*S*2] host, U[0,1) indexed by sweep step         */
-  int32_t verbose;
+  int32_t verbose;                 /* >= 1: the reference's progress messages of the false-negative scan (stderr); >= 3: one line per iteration */
+  int32_t timing;                  /* cm_timings detail.  0: fit totals only (4 events per fit, the default: per-kernel events cost ~2 us
+                                      of launch boundary each, ~8 % of a fit); 1: + events around the chain kernel and the mid-iteration
+                                      kernel of every iteration (sweep_seq_ms, mid_ms); 2: + all phase stamps                                  */
 } cm_options;
 
 /* Caller-allocated host output buffers (any pointer may be NULL = not wanted).  Replaces the 17-tuple of caviar.py:100. */
