@@ -7,7 +7,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <queue>
+#include <vector>
 
 #include "cm_internal.h"
 
@@ -417,6 +419,8 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
   if (o->save_histories && iters > 0) CM_TRY(alloc_hist(p, iters)); else free_hist(p);
 
   static const bool trace_iters = getenv("CAVIAR_HIP_TRACE_ITERS") != nullptr;   // diagnostic: implies the per-kernel stamps
+  static const bool trace_host = getenv("CAVIAR_HIP_TRACE_HOST") != nullptr;     // diagnostic: host clock at every mailbox arrival (no events)
+  std::vector<std::chrono::steady_clock::time_point> host_stamps;
   const bool timed = tm != nullptr && (o->timing >= 1 || trace_iters);   // stamps around the chain kernel (events 3, 4) and k_iter_mid (8, 9)
   const bool phases = tm != nullptr && o->timing >= 2;  // all phase stamps (more events and host API calls per iteration)
   while (ctx->pool.size() < (size_t)(iters + 1) * CM_EV_PER_IT) { hipEvent_t e; CM_HIP(hipEventCreate(&e)); ctx->pool.push_back(e); }
@@ -440,6 +444,7 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
     p->order = p->orders_all + (size_t)it * N;
     if (phases) CM_HIP(hipEventRecord(EV(it, 0), st));
     CM_TRY(cm_wait_active(ctx, p));                                  // the one host wait of an iteration: size of the active set
+    if (trace_host) host_stamps.push_back(std::chrono::steady_clock::now());
     last_active = ctx->mb_n;
     sum_active += last_active;
     if (ctx->mb_flag) { cm_set_error("iteration %d: weight precision matrix not positive definite", it); return CM_ERR_NOT_SPD; }
@@ -501,6 +506,9 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
     if (ctx->h_pinned[9]) { cm_set_error("weight precision matrix not positive definite"); return CM_ERR_NOT_SPD; }
     if (ctx->h_pinned[10]) { cm_set_error("sweep ticket wait timed out (internal error)"); return CM_ERR_STATE; }
   }
+  if (trace_host)
+    for (size_t i = 1; i < host_stamps.size(); ++i)
+      fprintf(stderr, "mailbox %2zu -> %2zu: %7.1f us\n", i - 1, i, std::chrono::duration<double, std::micro>(host_stamps[i] - host_stamps[i - 1]).count());
   if (tm) {
     float a = 0, b = 0, c = 0;
     hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[3]);
