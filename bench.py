@@ -35,6 +35,24 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+_REAL_STDOUT = None
+
+
+def quiet_stdout():
+    """Native libraries print to fd 1 too (RCCL's version banner under NCCL_DEBUG=VERSION, rocm warnings): route fd 1 to stderr for the
+    whole run and keep the real stdout for the ONE JSON line."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line):
+    sys.stdout.flush()
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (line + "\n").encode())
+
+
 def circuit_for(rank, step, world):
     """which of the `world` circuits rank `rank` fits at step `step` (see main): a Latin-square rotation"""
     return (rank + step) % world
@@ -167,7 +185,7 @@ def bench_nwd(a):
             out["cpu_baseline"] = {"value": nb / dtc, "unit": "traces/s", "cores": int(nthreads), "kind": "port",
                                    "sample": "float32 PyTorch-CPU oracle on the first %d traces, %.2f s" % (nb, dtc),
                                    "max_abs_diff_vs_gpu_over_scale": float(np.max(np.abs(got - ref)) / max(np.max(np.abs(ref)), 1e-30))}
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     ctx.free(d_in); ctx.free(d_out)
     dm.close()
     if dist is not None:
@@ -188,6 +206,7 @@ def main():
     ap.add_argument("--host-sim", action="store_true", help="generate the synthetic experiments with the NumPy restatement on the host "
                     "(default: on the GPU, include/sim_hip.h -- psc and stim_matrix never exist on the host)")
     a = ap.parse_args()
+    quiet_stdout()
     if a.workload == "nwd":
         return bench_nwd(a)
 
@@ -337,7 +356,7 @@ def main():
                 sim = {"psc": ctx.download(dsims[0]["psc_ptr"], np.empty((K, T))),
                        "stim_matrix": ctx.download(dsims[0]["stim_ptr"], np.empty((N, K)))}
             out["cpu_baseline"] = cpu_baseline(sim, pri, wl)
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     for q in probs:
         q.close()
     for d in dsims:
