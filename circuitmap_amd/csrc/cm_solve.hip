@@ -135,38 +135,62 @@ __device__ __forceinline__ void tile_linv(double (*C)[TP], double (*Rt)[TP], dou
 // column are broadcast through a double-buffered 64 doubles of LDS -- ONE 4-wave barrier, 4 LDS operations and 4 FMAs per
 // thread per pivot instead of an LDS read-modify-write per element.  C is read, Li written.  All of the first 256 threads of
 // the workgroup must call it and every other wave must have retired (a retired wave no longer counts at s_barrier).
+__device__ __forceinline__ double cm_recip(double d) {
+  // hardware reciprocal estimate (~26 bits) + two Newton steps: full double precision for the normal-range pivots of an SPD
+  // tile, a third of the latency of the IEEE division sequence on the 32-pivot dependency chain
+  double rd = __builtin_amdgcn_rcp(d);
+  rd = fma(fma(-d, rd, 1.0), rd, rd);
+  return fma(fma(-d, rd, 1.0), rd, rd);
+}
+// TWO pivots (k, q = k + 1) per broadcast round: both pivot rows and both pivot columns go through LDS together, every thread
+// derives the second pivot (row q after step k) itself, operation for operation as its owner would, and applies both
+// elimination steps to its four elements.  16 barriers and LDS round trips instead of 32; results are bitwise those of the
+// one-pivot-per-round elimination.
 __device__ __forceinline__ void tile_linv_reg(const double (*C)[TP], double (*Li)[TP], int* __restrict__ flag) {
-  __shared__ __attribute__((aligned(16))) double rowv[2][TS];
-  __shared__ double colv[2][TS], dk[TS];
+  __shared__ __attribute__((aligned(16))) double rowk[2][TS], rowq[2][TS];
+  __shared__ double colk[2][TS], colq[2][TS], dk[TS];
   const int r = threadIdx.x & 31, g = threadIdx.x >> 5;
   double v[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) v[c] = C[r][4 * g + c];
 #pragma unroll
-  for (int k = 0; k < TS; ++k) {
-    const int b = k & 1;
+  for (int k = 0; k < TS; k += 2) {
+    const int q = k + 1, b = (k >> 1) & 1, gk = k >> 2;      // k is even: both pivot columns live in the same 4-column group
     if (r == k) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) rowv[b][4 * g + c] = v[c];
+      for (int c = 0; c < 4; ++c) rowk[b][4 * g + c] = v[c];
     }
-    if (g == (k >> 2)) colv[b][r] = v[k & 3];
+    if (r == q) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) rowq[b][4 * g + c] = v[c];
+    }
+    if (g == gk) { colk[b][r] = v[k & 3]; colq[b][r] = v[q & 3]; }
     __syncthreads();
-    // all LDS reads of the pivot are issued together, before the reciprocal chain (no branch on r > k: a select)
-    const double d = rowv[b][k];
-    const double cv = colv[b][r];
-    double rw[4];
+    const double dkk = rowk[b][k], akq = rowk[b][q], aqk = colk[b][q], aqq = rowq[b][q];
+    const double cvk = colk[b][r], cvq = colq[b][r];
+    double rk[4], rq[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) rw[c] = rowv[b][4 * g + c];
-    // 1/d sits on the 32-pivot dependency chain: hardware reciprocal estimate + two Newton steps (full double precision for
-    // the normal-range pivots of an SPD tile) instead of the ~3x longer IEEE division sequence
-    double rd = __builtin_amdgcn_rcp(d);
-    rd = fma(fma(-d, rd, 1.0), rd, rd);
-    rd = fma(fma(-d, rd, 1.0), rd, rd);
-    if (threadIdx.x == 0) { dk[k] = d; if (!(d > 0.0)) *flag = 1; }   // not SPD (also catches NaN)
-    const double m = (r > k) ? cv * rd : 0.0;
+    for (int c = 0; c < 4; ++c) { rk[c] = rowk[b][4 * g + c]; rq[c] = rowq[b][4 * g + c]; }
+    // step k
+    const double rdk = cm_recip(dkk);
+    const double mq = aqk * rdk;                           // multiplier of row q at step k
+    const double dq = fma(-mq, akq, aqq);                  // second pivot = a[q][q] after step k
+    const double rdq = cm_recip(dq);
+    const double mi = (r > k) ? cvk * rdk : 0.0;
+    const double aiq = fma(-mi, akq, cvq);                 // a[r][q] after step k
+    const double mi2 = (r > q) ? aiq * rdq : 0.0;
+    if (threadIdx.x == 0) { dk[k] = dkk; dk[q] = dq; if (!(dkk > 0.0) || !(dq > 0.0)) *flag = 1; }   // not SPD (also catches NaN)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) v[c] = fma(-m, rw[c], v[c]);
-    if (g == (k >> 2) && r > k) v[k & 3] = -m;
+    for (int c = 0; c < 4; ++c) {
+      const bool slot_k = (g == gk) && (c == (k & 3)), slot_q = (g == gk) && (c == (q & 3));
+      double rqp = fma(-mq, rk[c], rq[c]);                 // row q after step k ...
+      rqp = slot_k ? -mq : rqp;                            // ... whose slot k holds -m_q
+      double x = fma(-mi, rk[c], v[c]);                    // step k
+      x = (slot_k && r > k) ? -mi : x;
+      x = fma(-mi2, rqp, x);                               // step q
+      x = (slot_q && r > q) ? -mi2 : x;
+      v[c] = x;
+    }
   }
   __syncthreads();
   const double rs = 1.0 / sqrt(dk[r]);               // L^-1 = D^-1/2 Ltilde^-1
