@@ -142,11 +142,88 @@ __device__ __forceinline__ double cm_recip(double d) {
   rd = fma(fma(-d, rd, 1.0), rd, rd);
   return fma(fma(-d, rd, 1.0), rd, rd);
 }
-// TWO pivots (k, q = k + 1) per broadcast round: both pivot rows and both pivot columns go through LDS together, every thread
+// FOUR pivots (k .. k + 3, one 4-column group) per broadcast round: the four pivot rows and, for every row, its four entries
+// in the pivot columns go through LDS together; every thread then replays the four elimination steps on the 4 x 4 pivot
+// block, on the pivot rows' entries in its own columns and on its own four elements -- operation for operation what the
+// one-pivot-per-round elimination does, so the result is bitwise the same, with 8 barriers / LDS round trips instead of 32.
+__device__ __forceinline__ void tile_linv_reg(const double (*C)[TP], double (*Li)[TP], int* __restrict__ flag) {
+  __shared__ __attribute__((aligned(16))) double prow[2][4][TS];     // pivot rows as they stand before the round
+  __shared__ __attribute__((aligned(16))) double pcol[2][TS][4];     // a[r][k .. k+3] of every row r
+  __shared__ double dk[TS];
+  const int r = threadIdx.x & 31, g = threadIdx.x >> 5;
+  double v[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) v[c] = C[r][4 * g + c];
+#pragma unroll
+  for (int k = 0; k < TS; k += 4) {
+    const int b = (k >> 2) & 1, gk = k >> 2;
+    if (r >= k && r < k + 4) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) prow[b][r - k][4 * g + c] = v[c];
+    }
+    if (g == gk) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) pcol[b][r][c] = v[c];
+    }
+    __syncthreads();
+    double B[4][4], pr[4][4], ac[4];
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { B[s_][c] = prow[b][s_][k + c]; pr[s_][c] = prow[b][s_][4 * g + c]; }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ac[c] = pcol[b][r][c];
+    const bool own = (g == gk);                            // this thread's columns ARE the pivot columns: v == ac, pr == B
+    double dloc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const double d = B[t][t];
+      dloc[t] = d;
+      const double rd = cm_recip(d);
+      // pivot rows below pivot t: inside the block, and in this thread's columns
+#pragma unroll
+      for (int s_ = t + 1; s_ < 4; ++s_) {
+        const double ms = B[s_][t] * rd;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          B[s_][u] = (u == t) ? -ms : fma(-ms, B[t][u], B[s_][u]);
+          const double x = fma(-ms, pr[t][u], pr[s_][u]);
+          pr[s_][u] = (own && u == t) ? -ms : x;
+        }
+      }
+      // this thread's own row
+      const double m = (r > k + t) ? ac[t] * rd : 0.0;
+      const bool below = r > k + t;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double xa = fma(-m, B[t][u], ac[u]);
+        ac[u] = (u == t && below) ? -m : xa;
+        const double xv = fma(-m, pr[t][u], v[u]);
+        v[u] = (own && u == t && below) ? -m : xv;
+      }
+    }
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { dk[k + t] = dloc[t]; if (!(dloc[t] > 0.0)) *flag = 1; }   // not SPD (also catches NaN)
+    }
+  }
+  __syncthreads();
+  const double rs = 1.0 / sqrt(dk[r]);               // L^-1 = D^-1/2 Ltilde^-1
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int col = 4 * g + c;
+    Li[r][col] = (col < r) ? v[c] * rs : ((col == r) ? rs : 0.0);
+  }
+  __syncthreads();
+}
+
+// The same with TWO pivots (k, q = k + 1) per broadcast round -- 54 instead of 100 VGPRs, for the bandwidth-bound kernel whose
+// occupancy matters more than the last microsecond of its single factoring workgroup: both pivot rows and both pivot columns go through LDS together, every thread
 // derives the second pivot (row q after step k) itself, operation for operation as its owner would, and applies both
 // elimination steps to its four elements.  16 barriers and LDS round trips instead of 32; results are bitwise those of the
 // one-pivot-per-round elimination.
-__device__ __forceinline__ void tile_linv_reg(const double (*C)[TP], double (*Li)[TP], int* __restrict__ flag) {
+__device__ __forceinline__ void tile_linv_reg2(const double (*C)[TP], double (*Li)[TP], int* __restrict__ flag) {
   __shared__ __attribute__((aligned(16))) double rowk[2][TS], rowq[2][TS];
   __shared__ double colk[2][TS], colq[2][TS], dk[TS];
   const int r = threadIdx.x & 31, g = threadIdx.x >> 5;
@@ -262,7 +339,7 @@ __global__ __launch_bounds__(256) void k_chol_bulk(double* __restrict__ A, const
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) Sm[2][BLK_ROW(rb, lane, reg)][BLK_COL(cb, lane)] = oprev[reg] - c[reg];
   __syncthreads();                                 // all reads of Xi are done: tile 1 receives L^-1
-  tile_linv_reg(Sm[2], Sm[1], flag);
+  tile_linv_reg2(Sm[2], Sm[1], flag);
   tile_store(Dinv + (size_t)(j + 1) * TS * TS, TS, Sm[1]);
 }
 
