@@ -399,6 +399,8 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
   uint32_t chain[2] = {(uint32_t)(o->seed >> 32), (uint32_t)(o->seed & 0xFFFFFFFFull)};
   const size_t key_per = (size_t)(N + 3) * 2;
   bool rng_deferred = false;
+  hipEvent_t pending_ev[2] = {nullptr, nullptr};   // long RNG chunks whose event the main stream has not waited on yet
+  int pending_from[2] = {0, 0}, n_pending = 0;     // first iteration each of them serves
   int rng_done = 1;                              // iterations whose keys / orders / tables exist (iteration 0 is done up front)
   if (o->rng_mode == CM_RNG_THREEFRY && iters > 0) {
     keys.assign(key_per * iters, 0u);
@@ -455,10 +457,12 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
     CM_TRY(cm_launch_stats(ctx, p, o->spont_orthogonality));         // row + column statistics of the new lam
     if (rng_deferred) {
       // The work of this iteration is enqueued and the GPU is busy with it: extend the (sequential, host-side) threefry key
-      // chain and turn it into sweep orders / ndtri tables on the side stream.  Two chunks so that nothing ever waits on the
-      // long part: iterations 1-2 right after iteration 0 (~35 us of host time), the rest in two halves behind iterations 1
-      // and 2 (each of those keeps the GPU busy for > 1 ms at the benchmark shape).
-      const int upto = (it == 0) ? std::min(iters, 3) : (it == 1) ? std::min(iters, 3 + (iters - 3 + 1) / 2) : iters;
+      // chain (~17 us per iteration at N = 1000) and turn it into sweep orders / ndtri tables on the side stream.  Three chunks,
+      // each sized to the slack the host has while the GPU works through a full-size solve (the first three iterations keep
+      // it busy for 0.6-0.9 ms each, of which the ~55 launches take 0.25 ms of host time): iterations 1-12, 13-28, the rest.
+      // Only the first chunk is consumed by the very next kernel (the MC logit of iteration 1); the main stream waits for the
+      // other two where their first table is read, a dozen iterations later.
+      const int upto = (it == 0) ? std::min(iters, 13) : (it == 1) ? std::min(iters, 29) : iters;
       if (upto > rng_done) {
         const int n_new = upto - rng_done;
         cm_host_key_schedule_range(chain, rng_done, n_new, N, keys.data());
@@ -467,12 +471,16 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
                               hipMemcpyHostToDevice, ctx->side));
         CM_TRY(cm_launch_rng(ctx, p, rng_done, n_new, ctx->side));   // orders of the new iterations (:196)
         CM_TRY(cm_launch_ndtri_table(ctx, p, rng_done, n_new, S, o->rng_mode, ctx->side));
-        CM_HIP(hipEventRecord(ctx->ev[6], ctx->side));
-        CM_HIP(hipStreamWaitEvent(st, ctx->ev[6], 0));               // the MC logit of the next iteration (next kernel) needs them
+        hipEvent_t chunk_ev = (it == 0) ? ctx->ev[6] : (it == 1 ? ctx->ev[4] : ctx->ev[5]);
+        CM_HIP(hipEventRecord(chunk_ev, ctx->side));
+        if (it == 0) CM_HIP(hipStreamWaitEvent(st, chunk_ev, 0));     // the MC logit of iteration 1 (next kernel) needs it
+        else { pending_ev[n_pending] = chunk_ev; pending_from[n_pending] = rng_done; ++n_pending; }
         rng_done = upto;
       }
       rng_deferred = rng_done < iters;
     }
+    for (int q = 0; q < n_pending; ++q)                               // k_iter_mid below draws the MC logit of iteration it + 1
+      if (pending_ev[q] && it + 1 >= pending_from[q]) { CM_HIP(hipStreamWaitEvent(st, pending_ev[q], 0)); pending_ev[q] = nullptr; }
     if (o->save_histories) CM_TRY(record_hist(ctx, p, it, 0));       // mu, beta, lam of this iteration (:90-92)
     // :84-88 update_sigma, update_phi, z, spont_rate; then block_update_mu (small sets) and the MC logit of iteration it + 1
     if (timed) CM_HIP(hipEventRecord(EV(it, 8), st));
