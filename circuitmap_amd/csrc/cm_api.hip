@@ -281,7 +281,11 @@ static void host_reconnect(const cm_problem* p, double* mu, double* beta, double
     long c = 0;
     for (int e = p->h_row_ptr[n]; e < p->h_row_ptr[n + 1]; ++e) c += (z[p->h_col[e]] != 0.0);
     cnt[n] = c;
-    heap.push({c, n});
+    // A cell can only reconnect with spike_count >= minimum_spike_count (:130), spike_count is exactly this count (every targeted
+    // entry belongs to one power), and counts only decrease: cells below the threshold are examined by the reference to no
+    // effect, so they never enter the heap (identical outcome; most cells have 0 or 1 spontaneous events on their trials).
+    if (!(minimum_spike_count > 0.0) || (double)c >= minimum_spike_count) heap.push({c, n});
+    else cnt[n] = -1;
   }
   std::vector<double> srates(P > 0 ? P : 0);
   std::vector<int> locs;
@@ -290,7 +294,11 @@ static void host_reconnect(const cm_problem* p, double* mu, double* beta, double
     const Ent top = heap.top();
     heap.pop();
     if (cnt[top.n] < 0) continue;                                             // already visited
-    if (top.c != cnt[top.n]) { heap.push({cnt[top.n], top.n}); continue; }    // stale: re-queue with the current count
+    if (top.c != cnt[top.n]) {                                                // stale: re-queue with the current count
+      if (!(minimum_spike_count > 0.0) || (double)cnt[top.n] >= minimum_spike_count) heap.push({cnt[top.n], top.n});
+      else cnt[top.n] = -1;
+      continue;
+    }
     const int focus = top.n;
     double spike_count = 0.0;
     for (int i = 0; i < P; ++i) {                                             // :121-127
