@@ -516,10 +516,18 @@ __global__ __launch_bounds__(64) void k_colsum_partial(const double* __restrict_
   const int rbeg = chunk * CM_COLCHUNK, rend = min(n, rbeg + CM_COLCHUNK);
   double sm = 0.0, sb = 0.0;
   if (c < n) {
-    for (int r = max(rbeg, c); r < rend; ++r) {
-      const double x = X[(size_t)r * ld + c];
-      sm = fma(x, w[r], sm);
-      sb = fma(x, x, sb);
+    // 8 independent loads in flight, then the 8 accumulations in row order (the summation order is part of the result)
+    for (int r0 = max(rbeg, c); r0 < rend; r0 += 8) {
+      double x[8], ww[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = r0 + i < rend ? r0 + i : rend - 1;
+        x[i] = X[(size_t)r * ld + c];
+        ww[i] = w[r];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (r0 + i < rend) { sm = fma(x[i], ww[i], sm); sb = fma(x[i], x[i], sb); }
     }
   }
   if (c < ld) {
