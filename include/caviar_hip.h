@@ -103,19 +103,20 @@ typedef struct cm_result {
   double* z_hist;        /* [iters*K]   */
 } cm_result;
 
-/* Per-run device timings in milliseconds, from HIP events recorded on the ctx stream around each phase of every
- * iteration (no extra host synchronisation; elapsed times are read after the run's final sync). */
+/* Per-run device timings in milliseconds, from HIP events recorded on the ctx stream (no extra host synchronisation; elapsed
+ * times are read after the run's final sync).  The three totals are always filled; the per-kernel sums need
+ * cm_options.timing >= 1 (sweep_seq_ms, mid_ms) or >= 2 (the rest) and are 0 otherwise -- every event is a launch boundary. */
 typedef struct cm_timings {
   double total_ms;       /* whole run: state init + iterations + fn_scan                      */
   double iters_ms;       /* the `iters` CAVIaR iterations only                                */
   double fn_scan_ms;     /* reconnect_spont_cells (host) + final update_phi                   */
-  double solve_ms;       /* sum over iterations: block_update_mu (build + Cholesky + inverse) */
-  double mc_ms;          /* sum: update_phi(it) + Monte-Carlo logit(it+1) on the side stream (overlapped) */
-  double mc_wait_ms;     /* sum: main stream waiting for the side stream before the sweep     */
-  double sweep_indep_ms; /* sum: k_sweep_indep launches                                       */
-  double sweep_seq_ms;   /* sum: chain-kernel launches (k_sweep_par / k_sweep_seq: the Gauss-Seidel chain) */
-  double mid_ms;         /* sum: k_iter_mid launches (sigma, z, small solve || phi + next MC logit) */
-  double post_ms;        /* sum: row/col stats, update_sigma, soft-threshold (main stream)    */
+  double solve_ms;       /* timing >= 2, sum over iterations: host wait + block_update_mu of large active sets (build + Cholesky + inverse) */
+  double mc_ms;          /* unused (kept for layout compatibility)                             */
+  double mc_wait_ms;     /* unused (kept for layout compatibility)                             */
+  double sweep_indep_ms; /* timing >= 2, sum: k_presweep + k_seq_pack launches                */
+  double sweep_seq_ms;   /* timing >= 1, sum: chain-kernel launches (k_sweep_par / k_sweep_seq: the Gauss-Seidel chain) */
+  double mid_ms;         /* timing >= 1, sum: k_iter_mid launches (sigma, z, small solve || phi + next MC logit), each incl. one launch boundary */
+  double post_ms;        /* timing >= 2, sum: k_stats + k_iter_mid                            */
   int32_t iters;
   int32_t last_active;   /* size of the active (lam row != 0) set in the last iteration       */
   int64_t sum_active;    /* sum over iterations of the active-set size                        */
