@@ -304,7 +304,13 @@ __device__ __forceinline__ void phi_body(int n, int lane, const double* __restri
     have_f = accepted >= 0;                        // b = 40 is taken without an evaluation: recompute next step
     if (accepted < 0) accepted = 40;
     const double step = ldexp(1.0, -accepted);
-    p0 += step * v0; p1 += step * v1;                                             // caviar.py:301
+    const double q0 = p0 + step * v0, q1 = p1 + step * v1;                        // caviar.py:301
+    // A step that leaves phi bit-for-bit unchanged is a fixed point of the loop body: every later step would recompute the same
+    // J, H, covariance and (rejected) candidates and leave phi unchanged again, so the remaining steps are skipped -- exactly
+    // the reference's result.  Converged neurons are the expensive ones otherwise: their Armijo test fails for all 40 candidates.
+    const bool fixed = (q0 == p0) && (q1 == p1);
+    p0 = q0; p1 = q1;
+    if (fixed) break;
   }
   if (lane == 0) {
     phi[2 * n] = p0; phi[2 * n + 1] = p1;
