@@ -139,6 +139,10 @@ __device__ __forceinline__ int post_single_body(const double* __restrict__ y, co
     for (int k = threadIdx.x; k < K; k += blockDim.x) { rl[k] = y[k] - R[k]; bl[k] = (uint8_t)(colany[k] || !mask[k]); }
     __syncthreads();
   }
+  // z itself is only needed from the LAST pass: the passes accumulate the error norm, and z is written once afterwards with the
+  // penalty of that last pass (a store to z in every pass puts a global-store round trip inside each of up to 20 barriers).
+  bool ran = false;
+  double last_pen = pen;
   while (itc < max_iters && err > tol) {
     double e = 0.0;
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
@@ -147,17 +151,29 @@ __device__ __forceinline__ int post_single_body(const double* __restrict__ y, co
       double zz = resid < pen ? 0.0 : resid - pen;                       // :154
       zz = zz < 0.0 ? 0.0 : zz;                                          // :155
       zz = blocked ? 0.0 : zz;                                           // :156-157
-      z[k] = zz;
       const double d = resid - zz;
       e = fma(d, d, e);                                                  // :158
     }
     err = block_sum(e, sh) / ysq;
     ++itc;
+    last_pen = pen;
+    ran = true;
     pen *= scale_factor;
   }
-  __syncthreads();
   double cnt = 0.0;
-  for (int k = threadIdx.x; k < K; k += blockDim.x) cnt += (z[k] != 0.0) ? 1.0 : 0.0;
+  if (ran) {
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+      const double resid = staged ? rl[k] : y[k] - R[k];
+      const bool blocked = staged ? (bl[k] != 0) : (colany[k] || !mask[k]);
+      double zz = resid < last_pen ? 0.0 : resid - last_pen;
+      zz = zz < 0.0 ? 0.0 : zz;
+      zz = blocked ? 0.0 : zz;
+      z[k] = zz;
+      cnt += (zz != 0.0) ? 1.0 : 0.0;
+    }
+  } else {
+    for (int k = threadIdx.x; k < K; k += blockDim.x) cnt += (z[k] != 0.0) ? 1.0 : 0.0;   // z is frozen (caviar.py:86-87 with it >= 20)
+  }
   cnt = block_sum(cnt, sh);
   if (threadIdx.x == 0) scal[CM_S_SPONT_RATE] = cnt / (double)K;
   return n_active;
