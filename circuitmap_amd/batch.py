@@ -18,11 +18,21 @@ def shard_indices(n_circuits, rank, world_size):
     return list(range(rank, n_circuits, world_size))
 
 
-def _default_fit(psc, stim, priors, fit_options, device_id):
-    from .optimise import caviar
-    res = caviar(psc, stim, priors["mu"], priors["beta"], priors["shape"], priors["rate"], priors["phi"], priors["phi_cov"],
-                 device_id=device_id, **fit_options)
+def _default_fit(psc, stim, priors, fit_options, device_id, ctx=None):
+    """One circuit on one GPU.  `ctx` = a private `_lib.Context` (own stream and mailbox) when several fits share the GPU."""
     names = ["mu", "beta", "lam", "shape", "rate", "phi", "phi_cov", "z"]
+    if ctx is None:
+        from .optimise import caviar
+        res = caviar(psc, stim, priors["mu"], priors["beta"], priors["shape"], priors["rate"], priors["phi"], priors["phi_cov"],
+                     device_id=device_id, **fit_options)
+        return dict(zip(names, res[:8]))
+    from .optimise.caviar import Problem
+    prob = Problem(ctx, psc, stim)
+    try:
+        prob.run(priors["mu"], priors["beta"], priors["shape"], priors["rate"], priors["phi"], priors["phi_cov"], **fit_options)
+        res = prob.fetch()
+    finally:
+        prob.close()
     return dict(zip(names, res[:8]))
 
 
@@ -50,13 +60,18 @@ def packed_length(N, K):
     return 8 * N + 2 + K
 
 
-def fit_batch(circuits, priors=None, fit_options=None, fit_fn=None, device=None, group=None):
+def fit_batch(circuits, priors=None, fit_options=None, fit_fn=None, device=None, group=None, per_gpu_concurrency=1):
     """Fit a list of circuits [(psc K x T, stim N x K), ...] (same N, K) across the ranks of the default process group.
 
     Rank 0's `priors` / `fit_options` are broadcast to every rank.  Returns, on rank 0, a list of result dicts
     (mu, beta, shape, rate, phi, phi_cov, z) in circuit order; on other ranks None.  Without an initialised process
     group it degenerates to a sequential loop on one GPU.  `fit_fn(psc, stim, priors, fit_options, device_id)` is
     injectable so that the sharding / collective logic can be exercised on CPU with the gloo backend.
+
+    `per_gpu_concurrency` > 1 runs that many of this rank's fits at a time on its GPU, each from its own host thread with a private
+    context (stream + mailbox).  A single fit is a latency chain that occupies ~2 % of an MI355X, so fits overlap: measured
+    aggregate at N=1000, K=2000: 1.55x with 2, 2.1x with 3 (erratic beyond: the latency-critical chains start to queue behind each
+    other's wide early-iteration kernels).  Results are identical to the serial loop (each fit is deterministic on its own stream).
     """
     import torch
     import torch.distributed as dist
@@ -87,9 +102,25 @@ def fit_batch(circuits, priors=None, fit_options=None, fit_fn=None, device=None,
     L = packed_length(N, K)
     n_slots = (n_total + world - 1) // world                       # equal-size gather payloads
     local = torch.zeros((n_slots, L), dtype=torch.float64)
-    for slot, ci in enumerate(mine):
-        psc, stim = circuits[ci]
-        local[slot] = torch.from_numpy(_pack(fit_fn(psc, stim, priors, fit_options, device_id), N, K))
+    if per_gpu_concurrency > 1 and fit_fn is _default_fit and len(mine) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        import threading
+        from . import _lib
+        tls = threading.local()
+
+        def work(job):
+            slot, ci = job
+            if not hasattr(tls, "ctx"):
+                tls.ctx = _lib.Context(device_id)                  # one private context per worker thread (closed by its finaliser)
+            psc, stim = circuits[ci]
+            return slot, _pack(_default_fit(psc, stim, priors, fit_options, device_id, ctx=tls.ctx), N, K)
+        with ThreadPoolExecutor(max_workers=int(per_gpu_concurrency)) as ex:
+            for slot, vec in ex.map(work, list(enumerate(mine))):
+                local[slot] = torch.from_numpy(vec)
+    else:
+        for slot, ci in enumerate(mine):
+            psc, stim = circuits[ci]
+            local[slot] = torch.from_numpy(_pack(fit_fn(psc, stim, priors, fit_options, device_id), N, K))
 
     # ---- gather of the results (all -> rank 0)
     if not distributed:

@@ -268,3 +268,19 @@ def test_fit_batch_single_gpu_equals_direct():
         for i, nm in enumerate(OUT_NAMES):
             if nm != "lam":
                 assert np.array_equal(np.asarray(res[i], dtype=float), np.asarray(g[nm], dtype=float), equal_nan=True), nm
+
+
+def test_fit_batch_concurrent_fits_equal_serial():
+    """per_gpu_concurrency: several fits share the GPU from private contexts; every result equals the serial one bit for bit."""
+    from circuitmap_amd.batch import fit_batch
+    circuits = []
+    for s_ in range(5):
+        sim, _ = _sim_case(120, 400, 300 + s_)
+        circuits.append((sim["psc"], sim["stim_matrix"]))
+    opts = dict(iters=12, seed=0)
+    serial = fit_batch(circuits, fit_options=opts)
+    conc = fit_batch(circuits, fit_options=opts, per_gpu_concurrency=3)
+    assert len(serial) == len(conc) == 5
+    for a, b in zip(serial, conc):
+        for k in ("mu", "beta", "shape", "rate", "phi", "phi_cov", "z"):
+            np.testing.assert_array_equal(np.asarray(a[k]), np.asarray(b[k]))
