@@ -1,17 +1,20 @@
 """circuitmap_amd -- MI355X-native CAVIaR: drop-in for circuitmap's `Model.fit(method='caviar')` path.
 
-Public names follow the reference package (circuitmap/__init__.py:1-3): `Model`, `simulate`.
-`NeuralDemixer` (the PSC demixing network) is outside this hot path and is not provided.
-Imports are lazy so that importing the package never needs a GPU.
+Public names follow the reference package (circuitmap/__init__.py:1-3): `Model`, `NeuralDemixer`, `simulate`.
+Imports are lazy (the reference's eager import pulls torch + pytorch_lightning + jax) so that importing the package never
+needs a GPU.
 """
 
-__all__ = ["Model", "simulate", "optimise"]
+__all__ = ["Model", "NeuralDemixer", "simulate", "optimise"]
 
 
 def __getattr__(name):
     if name == "Model":
         from .model import Model
         return Model
+    if name == "NeuralDemixer":
+        from .neural_waveform_demixing import NeuralDemixer
+        return NeuralDemixer
     if name == "simulate":
         from .simulation import simulate
         return simulate
