@@ -5,6 +5,7 @@ visible, loading / context creation raises.
 """
 import ctypes as C
 import os
+import threading
 
 import numpy as np
 
@@ -106,6 +107,7 @@ SYMBOLS = {
     "cm_k_reconnect": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_double]),
     "cm_k_rng_streams": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, _ip, _dp]),
     "cm_k_event_pair_overhead": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float)]),
+    "cm_test_lds_request": (C.c_int64, [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64]),
     # include/nwd_hip.h
     "cm_nwd_create": (C.c_int, [C.c_void_p, C.POINTER(CmNwdParams), C.POINTER(C.c_void_p)]),
     "cm_nwd_destroy": (None, [C.c_void_p]),
@@ -132,6 +134,13 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise CaviarHipError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                  "(there is no CPU fallback)" % LIB_PATH)
+        # One HIP runtime per process: PyTorch ships its own copy of libamdhip64, and whichever library is loaded
+        # first decides which copy the process uses.  Device pointers and streams are exchanged with torch (bench.py, batch.py,
+        # the demixer), so torch goes first whenever it is installed.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)
@@ -163,6 +172,7 @@ class Context:
     def __init__(self, device_id=0, stream=None):
         self.lib = load()
         self.handle = C.c_void_p()
+        self.lock = threading.RLock()       # calls on one context must be serialised (caviar_hip.h): Problem.run / fetch take it
         check(self.lib.cm_ctx_create(int(device_id), C.c_void_p(stream) if stream else None, C.byref(self.handle)))
 
     def synchronize(self):
@@ -199,9 +209,11 @@ class Context:
 
 
 _default_ctx = {}
+_default_ctx_lock = threading.Lock()
 
 
 def default_context(device_id=0):
-    if device_id not in _default_ctx:
-        _default_ctx[device_id] = Context(device_id)
-    return _default_ctx[device_id]
+    with _default_ctx_lock:
+        if device_id not in _default_ctx:
+            _default_ctx[device_id] = Context(device_id)
+        return _default_ctx[device_id]

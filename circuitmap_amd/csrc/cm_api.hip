@@ -8,7 +8,10 @@
 
 #include <algorithm>
 #include <chrono>
+#include <map>
+#include <mutex>
 #include <queue>
+#include <utility>
 #include <vector>
 
 #include "cm_internal.h"
@@ -25,6 +28,22 @@ void cm_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* cm_last_error(void) { return g_err; }
+
+// dynamic-LDS caps in force, per (device, kernel): only ever raised (see cm_raise_lds, cm_internal.h)
+static std::mutex g_lds_mu;
+static std::map<std::pair<int, const void*>, size_t> g_lds_table;
+size_t cm_lds_table_request(int device, const void* fn, size_t bytes, size_t floor_bytes) {
+  std::lock_guard<std::mutex> lk(g_lds_mu);
+  size_t& slot = g_lds_table[std::make_pair(device, fn)];
+  const size_t cur = slot > floor_bytes ? slot : floor_bytes;
+  if (bytes <= cur) return 0;
+  slot = bytes;
+  return bytes;
+}
+extern "C" int64_t cm_test_lds_request(int32_t device, uint64_t kernel_key, uint64_t bytes, uint64_t floor_bytes) {
+  // keys of this hook live in their own range of the table: odd addresses, which no kernel has
+  return (int64_t)cm_lds_table_request(device, reinterpret_cast<const void*>((uintptr_t)(2 * kernel_key + 1)), (size_t)bytes, (size_t)floor_bytes);
+}
 extern "C" const char* cm_version(void) { return "caviar_hip 0.1 (gfx950)"; }
 
 extern "C" int cm_device_count(void) {
@@ -41,6 +60,22 @@ extern "C" void cm_options_default(cm_options* o) {   // caviar.py:21-23
   o->rng_mode = CM_RNG_THREEFRY; o->update_orders = nullptr; o->uniforms = nullptr; o->verbose = 0; o->timing = 0;
 }
 
+extern "C" int cm_ctx_destroy(cm_ctx* c);
+static int ctx_init(cm_ctx* c, int device_id, void* hip_stream) {
+  if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
+  else { CM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+  CM_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+  for (auto& e : c->ev) CM_HIP(hipEventCreate(&e));
+  CM_HIP(hipHostMalloc((void**)&c->h_pinned, CM_MAILBOX_WORDS * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent));
+  memset(c->h_pinned, 0, CM_MAILBOX_WORDS * sizeof(int32_t));
+  CM_HIP(hipHostGetDevicePointer((void**)&c->d_mailbox, c->h_pinned, 0));
+  c->use_mailbox = getenv("CAVIAR_HIP_NO_MAILBOX") == nullptr;
+  hipDeviceProp_t prop;
+  CM_HIP(hipGetDeviceProperties(&prop, device_id));
+  c->num_cus = prop.multiProcessorCount;
+  return CM_OK;
+}
+
 extern "C" int cm_ctx_create(int device_id, void* hip_stream, cm_ctx** out) {
   if (!out) { cm_set_error("cm_ctx_create: out is NULL"); return CM_ERR_INVALID; }
   int n = 0;
@@ -52,17 +87,8 @@ extern "C" int cm_ctx_create(int device_id, void* hip_stream, cm_ctx** out) {
   CM_HIP(hipSetDevice(device_id));
   cm_ctx* c = new cm_ctx();
   c->device = device_id;
-  if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
-  else { CM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
-  CM_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-  for (auto& e : c->ev) CM_HIP(hipEventCreate(&e));
-  CM_HIP(hipHostMalloc((void**)&c->h_pinned, 64 * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent));
-  memset(c->h_pinned, 0, 64 * sizeof(int32_t));
-  CM_HIP(hipHostGetDevicePointer((void**)&c->d_mailbox, c->h_pinned, 0));
-  c->use_mailbox = getenv("CAVIAR_HIP_NO_MAILBOX") == nullptr;
-  hipDeviceProp_t prop;
-  CM_HIP(hipGetDeviceProperties(&prop, device_id));
-  c->num_cus = prop.multiProcessorCount;
+  const int rc = ctx_init(c, device_id, hip_stream);
+  if (rc != CM_OK) { cm_ctx_destroy(c); return rc; }      // a half-built context is released, not leaked
   *out = c;
   return CM_OK;
 }
@@ -70,13 +96,13 @@ extern "C" int cm_ctx_create(int device_id, void* hip_stream, cm_ctx** out) {
 extern "C" int cm_ctx_destroy(cm_ctx* c) {
   if (!c) return CM_OK;
   hipSetDevice(c->device);
-  hipStreamSynchronize(c->stream);
+  if (c->stream) hipStreamSynchronize(c->stream);
   if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
   for (auto& e : c->ev) if (e) hipEventDestroy(e);
   for (auto& e : c->pool) hipEventDestroy(e);
   if (c->h_pinned) hipHostFree(c->h_pinned);
   if (c->h_stage) hipHostFree(c->h_stage);
-  if (c->own_stream) hipStreamDestroy(c->stream);
+  if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   delete c;
   return CM_OK;
 }
@@ -361,7 +387,21 @@ static int record_hist(cm_ctx* ctx, cm_problem* p, int it, int part) {
   return CM_OK;
 }
 
+static int caviar_run_impl(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, const cm_options* o, cm_timings* tm);
+
+// Single exit path: an error return (bad argument, HIP failure, not-SPD, ...) may leave kernels and asynchronous copies queued on
+// both streams that still read host arrays of the CALLER (explicit RNG streams) or of this problem (key schedule); both streams
+// are drained before the error is handed back, so that nothing outlives the buffers it reads.
 extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, const cm_options* o, cm_timings* tm) {
+  const int rc = caviar_run_impl(ctx, p, pr, o, tm);
+  if (rc != CM_OK && ctx) {
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    if (ctx->side) hipStreamSynchronize(ctx->side);
+  }
+  return rc;
+}
+
+static int caviar_run_impl(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, const cm_options* o, cm_timings* tm) {
   if (!ctx || !p || !pr || !o) { cm_set_error("cm_caviar_run: NULL argument"); return CM_ERR_INVALID; }
   if (!pr->mu || !pr->beta || !pr->phi || !pr->phi_cov) { cm_set_error("cm_caviar_run: NULL prior array"); return CM_ERR_INVALID; }
   if (o->iters < 0 || o->num_mc_samples < 1) { cm_set_error("cm_caviar_run: iters >= 0 and num_mc_samples >= 1 required"); return CM_ERR_INVALID; }
@@ -403,7 +443,7 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
   CM_HIP(hipMemsetAsync(p->seq_meta, 0, 8 * sizeof(int), st));
   // Threefry key chain (host, sequential by nature): only iteration 0's keys are produced here; the rest is computed while
   // the GPU works on iteration 0 and turned into permutations / ndtri tables on the side stream (see the loop below).
-  std::vector<uint32_t> keys;
+  std::vector<uint32_t>& keys = p->h_keys;           // lives in the problem: asynchronous uploads read it after this function returns
   uint32_t chain[2] = {(uint32_t)(o->seed >> 32), (uint32_t)(o->seed & 0xFFFFFFFFull)};
   const size_t key_per = (size_t)(N + 3) * 2;
   bool rng_deferred = false;

@@ -472,7 +472,9 @@ __device__ __forceinline__ void mc_logit_body(int n, int m, int lane, double mea
     else q = (arg == u) ? wrow[j] : cm_quantile_slow(arg);
     mc[j] = q * sd + mean;
   }
-  // same-wave LDS write -> read: the LDS pipe is in order for one wave
+  // same-wave LDS write -> read: the LDS pipe is in order for one wave; the (free) wave barrier keeps the compiler from moving the
+  // reads above the writes of other lanes
+  __builtin_amdgcn_wave_barrier();
   for (int g = 0; g < V; ++g) {
     const double v = vals[g];
     if (!(v > 0.0)) continue;

@@ -10,6 +10,7 @@
 #define CM_WAVE 64
 #define CM_TILE 32          // tile edge of the blocked SPD solve
 #define CM_EV_PER_IT 10
+#define CM_MAILBOX_WORDS 64  // int32 words of host-mapped pinned memory per context: [0..1] mailbox, [8..11] scratch
 
 void cm_set_error(const char* fmt, ...);
 
@@ -42,7 +43,7 @@ struct cm_ctx {
   int num_cus = 256;
   void* h_stage = nullptr;        // pinned staging buffer (priors upload, fn_scan round trip), grown on demand
   size_t h_stage_bytes = 0;
-  size_t lds_attr[24] = {};       // dynamic-LDS caps already raised for this context's device, by kernel slot (cm_raise_lds)
+  size_t lds_attr[40] = {};       // dynamic-LDS caps already raised for this context's device, by kernel slot (cm_raise_lds)
   std::vector<hipEvent_t> pool;   // per-iteration events (CM_EV_PER_IT per iteration): phase stamps + cross-stream edges
 };
 
@@ -72,6 +73,7 @@ struct cm_problem {
   std::vector<int32_t> h_row_ptr, h_col, h_col_ptr, h_csc_row;
   std::vector<uint8_t> h_grp;
   std::vector<double> h_vals;
+  std::vector<uint32_t> h_keys;   // host copy of the threefry key schedule (source of asynchronous uploads)
   // --- CAVIaR state ---
   uint8_t* mask = nullptr;    // [K] lam_mask
   double* slab = nullptr;     // one allocation: mu | beta | z | lam (so the false-negative scan moves them in one copy each way)
@@ -219,16 +221,19 @@ inline void cm_threefry2x32(uint32_t k0, uint32_t k1, uint32_t& x0, uint32_t& x1
 }
 #endif
 
-// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, device): remember per context what has been raised, so that
-// a process driving several GPUs (one context each) configures every device, and no launch pays for a redundant call.
-enum cm_lds_slot { CM_LDS_ITER = 0 /* 7 x 2 template variants */, CM_LDS_SOLVE_SMALL = 14, CM_LDS_SWEEP_PAR, CM_LDS_SWEEP_PAR2, CM_LDS_SWEEP_SEQ,
-                   CM_LDS_NWD, CM_LDS_SIM_SORT };
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, device), and setting it REPLACES the previous value (it is
+// not a running maximum).  Several contexts can live on one device (cm_batch, fit_batch workers), so the value in force is kept
+// in ONE process-wide table keyed (device, kernel) under a mutex and is only ever raised; the per-context array is a cache of
+// lower bounds of that table (valid because the table never decreases), so the common launch pays no lock and no runtime call.
+enum cm_lds_slot { CM_LDS_ITER = 0 /* 7 x 2 x 2 template variants */, CM_LDS_SOLVE_SMALL = 28, CM_LDS_SWEEP_PAR, CM_LDS_SWEEP_PAR2, CM_LDS_SWEEP_SEQ,
+                   CM_LDS_NWD, CM_LDS_SIM_SORT, CM_LDS_BUILD_PREC, CM_LDS_SLOTS = 40 };
+// table update: returns the value hipFuncSetAttribute has to be called with (0 = the value in force already covers `bytes`)
+size_t cm_lds_table_request(int device, const void* fn, size_t bytes, size_t floor_bytes);
 inline int cm_raise_lds(cm_ctx* ctx, int slot, const void* fn, size_t bytes, size_t floor_bytes) {
-  const size_t cur = ctx->lds_attr[slot] > floor_bytes ? ctx->lds_attr[slot] : floor_bytes;
-  if (bytes > cur) {
-    CM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    ctx->lds_attr[slot] = bytes;
-  }
+  if (bytes <= floor_bytes || bytes <= ctx->lds_attr[slot]) return CM_OK;
+  const size_t set = cm_lds_table_request(ctx->device, fn, bytes, floor_bytes);
+  if (set) CM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)set));
+  ctx->lds_attr[slot] = bytes;
   return CM_OK;
 }
 

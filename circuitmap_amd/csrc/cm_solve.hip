@@ -595,8 +595,7 @@ int cm_solve_launch(cm_ctx* ctx, cm_problem* p, int na) {
   double* A = p->A;
   double* X = p->X;
   if ((size_t)ld * sizeof(double) > 150 * 1024) { cm_set_error("active set of %d neurons exceeds the LDS row accumulator", na); return CM_ERR_INVALID; }
-  if ((size_t)ld * sizeof(double) > 48 * 1024)
-    CM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_build_precision), hipFuncAttributeMaxDynamicSharedMemorySize, ld * (int)sizeof(double)));
+  CM_TRY(cm_raise_lds(ctx, CM_LDS_BUILD_PREC, reinterpret_cast<const void*>(k_build_precision), (size_t)ld * sizeof(double), 48 * 1024));
   hipLaunchKernelGGL(k_build_precision, dim3(ld), dim3(64), (size_t)ld * sizeof(double), st, p->lam, p->row_ptr, p->col, p->col_ptr,
                      p->csc_row, p->csc_pos, p->act_idx, p->act_inv, p->rs, p->scal, p->mu_prior, p->beta_prior, na, ld, A, p->rhs);
   // Cholesky

@@ -48,8 +48,9 @@ class Problem:
             kind = _lib.CM_MEM_HOST
             self._keep = (psc, stim)
         self.N, self.K, self.T = int(N), int(K), int(T)
-        _lib.check(self.lib.cm_problem_create(ctx.handle, self.N, self.K, self.T, C.c_void_p(psc_ptr), C.c_void_p(stim_ptr),
-                                              kind, C.byref(self.handle)))
+        with ctx.lock:
+            _lib.check(self.lib.cm_problem_create(ctx.handle, self.N, self.K, self.T, C.c_void_p(psc_ptr), C.c_void_p(stim_ptr),
+                                                  kind, C.byref(self.handle)))
         self._keep = None
 
     @property
@@ -79,7 +80,8 @@ class Problem:
             o.update_orders = uo.ctypes.data_as(C.POINTER(C.c_int32))
             o.uniforms = _lib.dptr(uu)
         tm = _lib.CmTimings()
-        _lib.check(self.lib.cm_caviar_run(self.ctx.handle, self.handle, C.byref(pr), C.byref(o), C.byref(tm)))
+        with self.ctx.lock:
+            _lib.check(self.lib.cm_caviar_run(self.ctx.handle, self.handle, C.byref(pr), C.byref(o), C.byref(tm)))
         self._last = (o.iters, bool(o.save_histories))
         return tm
 
@@ -102,14 +104,16 @@ class Problem:
                 a = np.empty(shp)
                 setattr(r, k, _lib.dptr(a))
                 hists.append(a)
-        _lib.check(self.lib.cm_caviar_fetch(self.ctx.handle, self.handle, C.byref(r)))
+        with self.ctx.lock:
+            _lib.check(self.lib.cm_caviar_fetch(self.ctx.handle, self.handle, C.byref(r)))
         receptive_fields = None                                      # caviar.py:51
         return (out["mu"], out["beta"], out["lam"], np.float64(r.shape), np.float64(r.rate), out["phi"], out["phi_cov"],
                 out["z"], receptive_fields, *hists)
 
     def close(self):
         if self.handle:
-            self.lib.cm_problem_destroy(self.handle)
+            with self.ctx.lock:
+                self.lib.cm_problem_destroy(self.handle)
             self.handle = C.c_void_p()
 
     def __del__(self):

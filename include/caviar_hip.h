@@ -187,6 +187,11 @@ int cm_k_rng_streams(cm_ctx* ctx, uint64_t seed, int32_t it, int32_t N, int32_t 
  * with a profiler's kernel trace. */
 int cm_k_event_pair_overhead(cm_ctx* ctx, int32_t reps, int32_t blocks, int32_t threads, float* ms_per_pair);
 
+/* Test hook for the library's dynamic-LDS bookkeeping (no GPU needed): hipFuncAttributeMaxDynamicSharedMemorySize REPLACES the value in
+ * force for a (kernel, device), so the library keeps one process-wide table and only ever raises it.  Returns the value the runtime
+ * would be called with for this request (0 = the value in force already covers it).  `kernel_key` is an arbitrary test key. */
+int64_t cm_test_lds_request(int32_t device, uint64_t kernel_key, uint64_t bytes, uint64_t floor_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -140,3 +140,16 @@ def test_simulate_contract():
     assert set(np.unique(stim)) == {0.0, 45.0, 55.0, 65.0}
     assert int((sim["weights"] > 0).sum()) == 2                      # connection_prob 0.05
     assert np.all(sim["spks"][stim == 0] == 0)
+
+
+def test_dynamic_lds_caps_are_only_ever_raised(lib):
+    """hipFuncAttributeMaxDynamicSharedMemorySize replaces the value in force for a (kernel, device); with several contexts on one
+    device the library must never lower it: grow / smaller request / grow again, per device, default floor respected."""
+    key = 12345
+    assert lib.cm_test_lds_request(0, key, 40 * 1024, 48 * 1024) == 0            # below the static default: no call
+    assert lib.cm_test_lds_request(0, key, 130 * 1024, 48 * 1024) == 130 * 1024   # context A raises
+    assert lib.cm_test_lds_request(0, key, 110 * 1024, 48 * 1024) == 0            # context B (empty cache) asks for less: nothing is lowered
+    assert lib.cm_test_lds_request(0, key, 130 * 1024, 48 * 1024) == 0            # A again: still covered
+    assert lib.cm_test_lds_request(0, key, 150 * 1024, 48 * 1024) == 150 * 1024   # genuine growth
+    assert lib.cm_test_lds_request(1, key, 110 * 1024, 48 * 1024) == 110 * 1024   # another device has its own value
+    assert lib.cm_test_lds_request(0, key + 1, 60 * 1024, 0) == 60 * 1024         # another kernel too
