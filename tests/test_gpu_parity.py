@@ -97,12 +97,12 @@ def _sim_case(N, K, seed, **kw):
     return sim, default_priors(N)
 
 
-@pytest.mark.parametrize("N,K,iters", [(300, 1000, 50), (1000, 2000, 12), (2000, 4000, 3), (1000, 6000, 3)])
+@pytest.mark.parametrize("N,K,iters", [(300, 1000, 50), (1000, 2000, 50), (2000, 4000, 3), (1000, 6000, 3)])
 def test_caviar_vs_oracle_bench_sizes(N, K, iters):
-    """BASELINE configs[1] (full) and configs[2] (first 12 iterations: covers the ungated full-size solves, the gating
-    transition and the shrinking active set) against the running-residual oracle on identical inputs; N = 2000 exercises
-    the two-round shuffle (N > 1625), the large-matrix Cholesky path (63 tiles) and K > 2048; K = 6000 takes the multi-wave
-    chain with 8-bit tickets and 512-record buffers."""
+    """BASELINE configs[1] and configs[2] (the headline shape), FULL trajectories: all 50 iterations + the false-negative scan
+    + the final update_phi (reference caviar.py:79-98) against the running-residual oracle on identical inputs.  N = 2000
+    exercises the two-round shuffle (N > 1625), the large-matrix Cholesky path (63 tiles) and K > 2048; K = 6000 takes the
+    multi-wave chain with 8-bit tickets and 512-record buffers."""
     from circuitmap_amd.optimise import caviar
     from oracle import caviar_oracle as co
     sim, pri = _sim_case(N, K, 1000 + N)
@@ -112,11 +112,29 @@ def test_caviar_vs_oracle_bench_sizes(N, K, iters):
     for i, nm in enumerate(OUT_NAMES):
         assert rel_err(res[i], ref[i]) < 1e-6, nm
     if iters == 50:
-        w = sim["weights"]
-        r2 = np.corrcoef(w, res[0])[0, 1] ** 2
-        # 33 trials per cell at this size: oracle and HIP path alike miss 2 of the 15 connections (R^2 = 0.726);
-        # the reference's 0.9546 is quoted at 180 trials per cell
-        assert r2 > 0.6, r2
+        # the connected set the two sides report is the same set (gate decisions are discontinuous: a flipped gate would show here)
+        assert np.array_equal(np.asarray(res[0]) != 0, np.asarray(ref[0]) != 0)
+        assert np.array_equal(np.any(res[2] != 0, axis=1), np.any(ref[2] != 0, axis=1))
+
+
+@pytest.mark.parametrize("seed", [7, 8])
+def test_accuracy_anchor_notebook_shape(seed):
+    """End-to-end accuracy anchor: the reference's demo recovers the synaptic weights with R^2 = 0.9546 at N = 200
+    neurons, K ~ 3600 trials, H = 10, connection_prob = 0.1 (examples/demo_compressive_connectivity_mapping.ipynb:593; ~180 trials
+    per cell).  Same shape here on seeded synthetic trial data, default fit options: R^2(weights, mu) >= 0.9 for the HIP path AND
+    for the oracle, no false positives, and the two agree to parity tolerance."""
+    from circuitmap_amd.optimise import caviar
+    from oracle import caviar_oracle as co
+    sim, pri = _sim_case(200, 3600, seed, H=10, connection_prob=0.1)
+    w = sim["weights"]
+    res = caviar(sim["psc"], sim["stim_matrix"], *prior_args(pri), iters=50, seed=0)
+    ref = co.caviar(sim["psc"], sim["stim_matrix"], *prior_args(pri), literal=False, iters=50, seed=0)
+    r2_hip = np.corrcoef(w, res[0])[0, 1] ** 2
+    r2_ref = np.corrcoef(w, ref[0])[0, 1] ** 2
+    assert r2_hip >= 0.9 and r2_ref >= 0.9, (r2_hip, r2_ref)
+    assert not np.any((np.asarray(res[0]) != 0) & (w == 0))                 # no false positives
+    for i, nm in enumerate(OUT_NAMES):
+        assert rel_err(res[i], ref[i]) < 1e-6, nm
 
 
 def test_invariants_full_size():
@@ -133,22 +151,32 @@ def test_invariants_full_size():
     dead = ~np.any(lam != 0, axis=1)
     assert np.all(z[np.any(lam >= 0.1, axis=0)] == 0)
     assert np.all(z >= 0)
-    r2 = np.corrcoef(sim["weights"], mu)[0, 1] ** 2
-    assert r2 > 0.6, r2                                                  # 20 trials per cell at this shape (0.77 measured)
+    # (the R^2 >= 0.9 accuracy anchor is tested at the shape it is quoted on: test_accuracy_anchor_notebook_shape; this shape has 20
+    # trials per cell, where the oracle and the HIP path alike reach 0.77 -- held to the oracle in test_caviar_vs_oracle_bench_sizes)
     assert dead.sum() > 0.5 * len(dead)                                  # most cells are disconnected and pruned
 
 
-def test_invariants_stress_size():
-    """The same size-independent properties at BASELINE configs[4] (N=5000, K=10000: 157-tile Cholesky, two-round shuffle,
-    8-bit chain tickets), plus: a row whose lam is identically 0 has exactly the prior mean and the prior VARIANCE
-    (quirk: `beta` returns diag(Sigma)), and a second run of the same problem object reproduces the first bit for bit."""
+def test_stress_size_vs_oracle_and_invariants():
+    """BASELINE configs[4] (N=5000, K=10000: 157-tile Cholesky with the panel-solve + bulk trailing-update kernels, the tiled
+    inverse at scale, two-round shuffle, 8-bit chain tickets).  (1) The first 3 iterations + false-negative scan + final update_phi
+    against the running-residual oracle on identical inputs (~100 s of CPU): every large-matrix kernel meets an oracle, not only
+    invariants.  (2) The full 50 iterations: size-independent properties, plus: a row whose lam is identically 0 has exactly the
+    prior mean and the prior VARIANCE (quirk: `beta` returns diag(Sigma)), and a second run of the same problem object reproduces
+    the first bit for bit."""
     from circuitmap_amd import _lib
     from circuitmap_amd.optimise.caviar import Problem
+    from oracle import caviar_oracle as co
     sim, pri = _sim_case(5000, 10000, 2005, lite=True)
     stim = sim["stim_matrix"]
     ctx = _lib.default_context(0)
     prob = Problem(ctx, sim["psc"], stim)
     args = prior_args(pri)
+    prob.run(*args, iters=3, seed=0)
+    res3 = prob.fetch()
+    ref3 = co.caviar(sim["psc"], stim, *args, literal=False, iters=3, seed=0)
+    for i, nm in enumerate(OUT_NAMES):
+        assert rel_err(res3[i], ref3[i]) < 1e-6, nm
+    del ref3, res3
     prob.run(*args, iters=50, seed=0)
     res = prob.fetch()
     mu, beta, lam, shape, rate, phi, phi_cov, z = res[:8]
@@ -160,8 +188,7 @@ def test_invariants_stress_size():
     dead = ~np.any(lam != 0, axis=1)
     assert dead.sum() > 0.5 * len(dead)
     assert np.all(mu[dead] == pri["mu"][dead]) and np.all(beta[dead] == pri["beta"][dead] ** 2)
-    r2 = np.corrcoef(sim["weights"], mu)[0, 1] ** 2
-    assert r2 > 0.6, r2
+    assert np.corrcoef(sim["weights"], mu)[0, 1] ** 2 > 0.6               # 20 trials per cell (anchor: test_accuracy_anchor_notebook_shape)
     prob.run(*args, iters=50, seed=0)
     res2 = prob.fetch()
     for a, b in zip(res[:8], res2[:8]):
