@@ -42,8 +42,9 @@ class CmResult(C.Structure):
 
 class CmTimings(C.Structure):
     _fields_ = [("total_ms", C.c_double), ("iters_ms", C.c_double), ("fn_scan_ms", C.c_double), ("solve_ms", C.c_double),
-                ("mc_ms", C.c_double), ("mc_wait_ms", C.c_double), ("sweep_indep_ms", C.c_double), ("sweep_seq_ms", C.c_double), ("mid_ms", C.c_double), ("post_ms", C.c_double),
-                ("iters", C.c_int32), ("last_active", C.c_int32), ("sum_active", C.c_int64), ("sum_seq_rows", C.c_int64), ("sum_seq_records", C.c_int64)]
+                ("sweep_indep_ms", C.c_double), ("sweep_seq_ms", C.c_double), ("mid_ms", C.c_double), ("post_ms", C.c_double), ("fact_ms", C.c_double),
+                ("iters", C.c_int32), ("batch", C.c_int32), ("last_active", C.c_int32), ("sum_active", C.c_int64), ("sum_seq_rows", C.c_int64), ("sum_seq_records", C.c_int64),
+                ("fact_launches", C.c_int64), ("fact_tile_updates", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -100,6 +101,14 @@ SYMBOLS = {
     "cm_caviar_fetch": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CmResult)]),
     "cm_caviar_fit": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _dp, _dp, C.POINTER(CmPriors), C.POINTER(CmOptions),
                                 C.POINTER(CmResult), C.POINTER(CmTimings)]),
+    "cm_caviar_run_batch": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(CmPriors), C.POINTER(CmOptions), C.POINTER(CmTimings)]),
+    "cm_caviar_fit_batch": (C.c_int, [C.c_int32, _ip, _ip, _ip, C.POINTER(_dp), C.POINTER(_dp), C.POINTER(CmPriors), C.POINTER(CmOptions),
+                                      _ip, C.c_int32, C.POINTER(CmResult), C.POINTER(CmTimings)]),
+    "cm_k_sigma": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_double, _dp, _dp]),
+    "cm_k_spont": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, _dp, C.POINTER(C.c_uint8), _dp, C.c_int32, C.c_int32, C.c_double,
+                             C.c_double, C.c_double, C.c_double, _dp, _dp]),
+    "cm_k_lam_sweep": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, _dp, C.POINTER(C.c_uint8), _dp, _dp, C.c_double, C.c_double, _dp, _dp,
+                                 C.POINTER(C.c_uint32), C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32]),
     "cm_k_prologue": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, _dp]),
     "cm_pava_last": (C.c_int, [_dp, C.c_int32, _dp]),
     "cm_k_block_update_mu": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, _dp, C.c_double, C.c_double, _dp, _dp, _dp, _dp]),

@@ -18,21 +18,12 @@ def shard_indices(n_circuits, rank, world_size):
     return list(range(rank, n_circuits, world_size))
 
 
-def _default_fit(psc, stim, priors, fit_options, device_id, ctx=None):
-    """One circuit on one GPU.  `ctx` = a private `_lib.Context` (own stream and mailbox) when several fits share the GPU."""
+def _default_fit(psc, stim, priors, fit_options, device_id):
+    """One circuit on one GPU through the drop-in `caviar()`."""
     names = ["mu", "beta", "lam", "shape", "rate", "phi", "phi_cov", "z"]
-    if ctx is None:
-        from .optimise import caviar
-        res = caviar(psc, stim, priors["mu"], priors["beta"], priors["shape"], priors["rate"], priors["phi"], priors["phi_cov"],
-                     device_id=device_id, **fit_options)
-        return dict(zip(names, res[:8]))
-    from .optimise.caviar import Problem
-    prob = Problem(ctx, psc, stim)
-    try:
-        prob.run(priors["mu"], priors["beta"], priors["shape"], priors["rate"], priors["phi"], priors["phi_cov"], **fit_options)
-        res = prob.fetch()
-    finally:
-        prob.close()
+    from .optimise import caviar
+    res = caviar(psc, stim, priors["mu"], priors["beta"], priors["shape"], priors["rate"], priors["phi"], priors["phi_cov"],
+                 device_id=device_id, **fit_options)
     return dict(zip(names, res[:8]))
 
 
@@ -60,22 +51,40 @@ def packed_length(N, K):
     return 8 * N + 2 + K
 
 
-def fit_batch(circuits, priors=None, fit_options=None, fit_fn=None, device=None, group=None, per_gpu_concurrency=1):
-    """Fit a list of circuits [(psc K x T, stim N x K), ...] (same N, K) across the ranks of the default process group.
+def _fit_lockstep(circuits, mine, priors, fit_options, device_id, max_group):
+    """This rank's circuits as lock-step batches on its GPU (cm_caviar_run_batch): the circuit is the outer grid dimension of every
+    launch.  Returns the result dicts in the order of `mine`."""
+    from . import _lib
+    from .optimise.caviar import Problem, run_batch
+    names = ["mu", "beta", "lam", "shape", "rate", "phi", "phi_cov", "z"]
+    ctx = _lib.default_context(device_id)
+    out = []
+    for g0 in range(0, len(mine), max_group):
+        probs = [Problem(ctx, *circuits[ci]) for ci in mine[g0:g0 + max_group]]
+        try:
+            run_batch(probs, priors, **fit_options)
+            for q in probs:
+                out.append(dict(zip(names, q.fetch(want_lam=False)[:8])))
+        finally:
+            for q in probs:
+                q.close()
+    return out
+
+
+def fit_batch(circuits, priors=None, fit_options=None, fit_fn=None, device=None, group=None, circuits_per_launch=64):
+    """Fit a list of circuits [(psc K x T, stim N x K), ...] across the ranks of the default process group.
 
     Rank 0's `priors` / `fit_options` are broadcast to every rank.  Returns, on rank 0, a list of result dicts
     (mu, beta, shape, rate, phi, phi_cov, z) in circuit order; on other ranks None.  Without an initialised process
-    group it degenerates to a sequential loop on one GPU.  `fit_fn(psc, stim, priors, fit_options, device_id)` is
-    injectable so that the sharding / collective logic can be exercised on CPU with the gloo backend.
+    group it degenerates to one GPU.  `fit_fn(psc, stim, priors, fit_options, device_id)` is injectable so that the sharding /
+    collective logic can be exercised on CPU with the gloo backend (then the circuits are fitted one by one).
 
-    `per_gpu_concurrency` > 1 runs that many of this rank's fits at a time on its GPU, each from its own host thread with a private
-    context (stream + mailbox).  A single fit is a latency chain that occupies ~2 % of an MI355X, so fits overlap: measured
-    aggregate at N=1000, K=2000: 1.55x with 2, 2.1x with 3 (erratic beyond: the latency-critical chains start to queue behind each
-    other's wide early-iteration kernels).  Results are identical to the serial loop (each fit is deterministic on its own stream).
+    On a GPU each rank fits its share as LOCK-STEP BATCHES of up to `circuits_per_launch` circuits (C ABI cm_caviar_run_batch): one
+    set of kernel launches per phase for the whole batch, one Gauss-Seidel workgroup per circuit.  A single fit is a latency
+    chain that occupies a few percent of an MI355X; the batch fills it.  Every result is bit-identical to the circuit's own fit.
     """
     import torch
     import torch.distributed as dist
-    fit_fn = fit_fn or _default_fit
     distributed = dist.is_available() and dist.is_initialized()
     rank = dist.get_rank(group) if distributed else 0
     world = dist.get_world_size(group) if distributed else 1
@@ -102,21 +111,9 @@ def fit_batch(circuits, priors=None, fit_options=None, fit_fn=None, device=None,
     L = packed_length(N, K)
     n_slots = (n_total + world - 1) // world                       # equal-size gather payloads
     local = torch.zeros((n_slots, L), dtype=torch.float64)
-    if per_gpu_concurrency > 1 and fit_fn is _default_fit and len(mine) > 1:
-        from concurrent.futures import ThreadPoolExecutor
-        import threading
-        from . import _lib
-        tls = threading.local()
-
-        def work(job):
-            slot, ci = job
-            if not hasattr(tls, "ctx"):
-                tls.ctx = _lib.Context(device_id)                  # one private context per worker thread (closed by its finaliser)
-            psc, stim = circuits[ci]
-            return slot, _pack(_default_fit(psc, stim, priors, fit_options, device_id, ctx=tls.ctx), N, K)
-        with ThreadPoolExecutor(max_workers=int(per_gpu_concurrency)) as ex:
-            for slot, vec in ex.map(work, list(enumerate(mine))):
-                local[slot] = torch.from_numpy(vec)
+    if fit_fn is None:
+        for slot, res in enumerate(_fit_lockstep(circuits, mine, priors, fit_options, device_id, max(1, int(circuits_per_launch)))):
+            local[slot] = torch.from_numpy(_pack(res, N, K))
     else:
         for slot, ci in enumerate(mine):
             psc, stim = circuits[ci]

@@ -7,10 +7,12 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <map>
 #include <mutex>
 #include <queue>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -102,6 +104,8 @@ extern "C" int cm_ctx_destroy(cm_ctx* c) {
   for (auto& e : c->pool) hipEventDestroy(e);
   if (c->h_pinned) hipHostFree(c->h_pinned);
   if (c->h_stage) hipHostFree(c->h_stage);
+  if (c->h_pdev) hipHostFree(c->h_pdev);
+  if (c->d_pdev) hipFree(c->d_pdev);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   delete c;
   return CM_OK;
@@ -223,25 +227,8 @@ extern "C" int cm_problem_nnz(const cm_problem* p, int64_t* nnz, int32_t* n_vals
 }
 
 // ------------------------------------------------------------------------------------------------
-// host side of the driver
+// host side of the driver (the sequential host-only pieces live in cm_host.cpp, plain C++: also built with sanitizers on the CPU)
 // ------------------------------------------------------------------------------------------------
-double cm_host_pava_last(const double* y, int n) {   // pava.py:9-88, gamma = 1, literal pool walk
-  if (n <= 0) return 0.0;
-  std::vector<double> v(n), w(n);
-  int i = 0;
-  v[0] = y[0]; w[0] = 1.0;
-  for (int t = 1; t < n; ++t) {
-    ++i;
-    v[i] = y[t]; w[i] = 1.0;
-    while (i > 0 && (v[i - 1] / w[i - 1]) > (v[i] / w[i])) {
-      --i;
-      v[i] += v[i + 1];
-      w[i] += w[i + 1];
-    }
-  }
-  return v[i] / w[i];
-}
-
 extern "C" int cm_pava_last(const double* y, int32_t n, double* out) {
   if (!y || !out || n < 1) { cm_set_error("cm_pava_last: bad argument"); return CM_ERR_INVALID; }
   *out = cm_host_pava_last(y, n);
@@ -257,106 +244,101 @@ static int stage_reserve(cm_ctx* ctx, size_t bytes) {
   return CM_OK;
 }
 
-// priors -> device in ONE pinned transfer (mu_prior | beta_prior | phi_prior | phi_cov_prior | scalars), then the state is
-// initialised from them on the device (caviar.py:44-49)
-__global__ __launch_bounds__(256) void k_state_from_priors(const double* __restrict__ pslab, int N, double* __restrict__ mu,
-                                                            double* __restrict__ beta, double* __restrict__ phi, double* __restrict__ phi_cov) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < N) { mu[i] = pslab[i]; beta[i] = pslab[N + i]; }
-  if (i < 2 * N) phi[i] = pslab[2 * (size_t)N + i];
-  if (i < 4 * N) phi_cov[i] = pslab[4 * (size_t)N + i];
+// ------------------------------------------------------------------------------------------------
+// launch sets
+// ------------------------------------------------------------------------------------------------
+void cm_fill_pdev(const cm_problem* p, const cm_problem* r, int* mailbox, cm_pdev* d) {
+  memset(d, 0, sizeof(*d));
+  d->N = p->N; d->K = p->K; d->V = p->V; d->small_cap = p->small_cap; d->max_row_len = p->max_row_len; d->ld_alloc = p->ld; d->nnz = p->nnz;
+  d->y = p->y; d->ss = p->ss; d->sum_y = p->sum_y; d->vals = p->vals; d->row_ptr = p->row_ptr; d->col = p->col; d->grp = p->grp;
+  d->rowcnt = p->rowcnt; d->col_ptr = p->col_ptr; d->csc_row = p->csc_row; d->csc_pos = p->csc_pos; d->mask = p->mask; d->colany = p->colany;
+  d->lam = p->lam; d->mu = p->mu; d->beta = p->beta; d->phi = p->phi; d->phi_cov = p->phi_cov; d->scal = p->scal; d->R = p->R; d->z = p->z;
+  d->mcE = p->mcE; d->rs = p->rs; d->pslab = p->pslab; d->mu_prior = p->mu_prior; d->beta_prior = p->beta_prior; d->phi_prior = p->phi_prior;
+  d->phi_cov_prior = p->phi_cov_prior; d->act_idx = p->act_idx; d->act_inv = p->act_inv; d->n_act = p->n_act; d->seq_n = p->seq_n;
+  d->seq_off = p->seq_off; d->seq_pos = p->seq_pos; d->chunk_first = p->chunk_first; d->seq_meta = p->seq_meta; d->packed = p->packed;
+  d->A = p->A; d->X = p->X; d->Lf = p->Lf; d->Dinv = p->Dinv; d->rhs = p->rhs; d->mailbox = mailbox;
+  d->orders_all = r->orders_all; d->inv_all = r->inv_all; d->wtab = r->wtab; d->uexp = r->uexp; d->keys = r->keys;
 }
 
-static int upload_priors(cm_ctx* ctx, cm_problem* p, const cm_priors* pr) {
-  hipStream_t st = ctx->stream;
-  const size_t N = p->N, n = 8 * N + CM_S_COUNT;
-  CM_HIP(hipStreamSynchronize(st));                 // the staging buffer may still feed an earlier transfer of this context
-  CM_TRY(stage_reserve(ctx, std::max(n, 2 * N + (size_t)p->K + (size_t)p->nnz) * sizeof(double)));
-  double* h = (double*)ctx->h_stage;
-  memcpy(h, pr->mu, N * 8); memcpy(h + N, pr->beta, N * 8); memcpy(h + 2 * N, pr->phi, 2 * N * 8); memcpy(h + 4 * N, pr->phi_cov, 4 * N * 8);
-  double* sc = h + 8 * N;
-  for (int i = 0; i < CM_S_COUNT; ++i) sc[i] = 0.0;
-  sc[CM_S_SHAPE] = pr->shape; sc[CM_S_RATE] = pr->rate; sc[CM_S_SHAPE_PRIOR] = pr->shape; sc[CM_S_RATE_PRIOR] = pr->rate;
-  CM_HIP(hipMemcpyAsync(p->pslab, h, n * sizeof(double), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(k_state_from_priors, dim3((unsigned)((4 * N + 255) / 256)), dim3(256), 0, st, p->pslab, (int)N, p->mu, p->beta, p->phi, p->phi_cov);
-  CM_HIP(hipGetLastError());
+static void set_limits(cm_set* s) {
+  s->small_cap_max = s->max_row_len_max = s->max_col_len_max = 0;
+  s->nnz_max = 0; s->nnz_min = s->ps.empty() ? 0 : s->ps[0]->nnz;
+  s->small_lds_max = 0;
+  for (const cm_problem* q : s->ps) {
+    if (q->small_cap > 0) s->small_lds_max = std::max(s->small_lds_max, small_lds_bytes(q->small_cap, q->small_cap * q->max_row_len));
+    s->small_cap_max = std::max(s->small_cap_max, q->small_cap);
+    s->max_row_len_max = std::max(s->max_row_len_max, q->max_row_len);
+    s->max_col_len_max = std::max(s->max_col_len_max, q->max_col_len);
+    s->nnz_max = std::max<long long>(s->nnz_max, q->nnz);
+    s->nnz_min = std::min<long long>(s->nnz_min, q->nnz);
+  }
+}
+
+// (re)builds the descriptors of a set; the random tables of every circuit are those of the leader
+static int set_build(cm_ctx* ctx, cm_set* s) {
+  s->B = (int)s->ps.size();
+  s->lead = s->ps[0];
+  set_limits(s);
+  s->na.assign(s->B, 0);
+  s->na_max = 0;
+  if (s->B == 1) {
+    cm_fill_pdev(s->lead, s->lead, ctx->use_mailbox ? ctx->d_mailbox : nullptr, &s->h0);
+    s->d_arr = nullptr;
+    return CM_OK;
+  }
+  if (s->B > CM_MAX_BATCH) { cm_set_error("batch of %d circuits exceeds CM_MAX_BATCH = %d", s->B, CM_MAX_BATCH); return CM_ERR_INVALID; }
+  if (!ctx->use_mailbox) { cm_set_error("CAVIAR_HIP_NO_MAILBOX is a single-circuit diagnostic: batches need the mailbox"); return CM_ERR_INVALID; }
+  const size_t bytes = (size_t)s->B * sizeof(cm_pdev);
+  if (ctx->pdev_cap < bytes) {
+    if (ctx->d_pdev) hipFree(ctx->d_pdev);
+    if (ctx->h_pdev) hipHostFree(ctx->h_pdev);
+    ctx->d_pdev = nullptr; ctx->h_pdev = nullptr; ctx->pdev_cap = 0;
+    CM_HIP(hipMalloc(&ctx->d_pdev, bytes));
+    CM_HIP(hipHostMalloc(&ctx->h_pdev, bytes, hipHostMallocDefault));
+    ctx->pdev_cap = bytes;
+  }
+  CM_HIP(hipStreamSynchronize(ctx->stream));           // the pinned copy may still feed the previous run's upload
+  cm_pdev* h = (cm_pdev*)ctx->h_pdev;
+  for (int c = 0; c < s->B; ++c)
+    cm_fill_pdev(s->ps[c], s->lead, ctx->d_mailbox + 2 * (CM_MAILBOX_BATCH0 + c), &h[c]);
+  CM_HIP(hipMemcpyAsync(ctx->d_pdev, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+  s->h0 = h[0];
+  s->d_arr = (const cm_pdev*)ctx->d_pdev;
   return CM_OK;
 }
 
-// reconnect_spont_cells, caviar.py:102-144.  Host C++ on the compressed rows (one-off, after the last iteration).
-static void host_reconnect(const cm_problem* p, double* mu, double* beta, double* lam, double* z, double minimax_spk_prob,
-                           double minimum_spike_count, int verbose) {
-  const int N = p->N, K = p->K, V = p->V;
-  const int P = V - 1;
-  std::vector<int> disc;
-  for (int n = 0; n < N; ++n) if (mu[n] == 0.0) disc.push_back(n);           // :103 exact zero test (quirk 7)
-  const size_t init = disc.size();
-  // np.where(stim_matrix[n]) selects NON-ZERO entries; targeted entries (> 0) are the CSR row.  Negative stimulus values
-  // are outside the reference's contract (powers are non-negative) and are treated as untargeted here.
-  // The reference re-scans all remaining cells in every pass (:109-117): it takes the cell with the most spontaneous events on
-  // its targeted trials (first maximum in ascending cell order), tests it, and removes it.  Counts only ever decrease (a
-  // reconnection clears events from z), so a max-heap keyed (count desc, cell asc) with lazy refresh of stale entries visits
-  // the cells in exactly that order; a reconnection updates the counts of the cells sharing the cleared trials (host CSC).
-  long nz = 0;
-  for (int k = 0; k < K; ++k) nz += (z[k] != 0.0);
-  std::vector<long> cnt(N, -1);                         // -1: not a candidate (connected, or already visited)
-  struct Ent { long c; int n; };
-  auto worse = [](const Ent& a, const Ent& b) { return a.c < b.c || (a.c == b.c && a.n > b.n); };
-  std::priority_queue<Ent, std::vector<Ent>, decltype(worse)> heap(worse);
-  for (int n : disc) {
-    long c = 0;
-    for (int e = p->h_row_ptr[n]; e < p->h_row_ptr[n + 1]; ++e) c += (z[p->h_col[e]] != 0.0);
-    cnt[n] = c;
-    // A cell can only reconnect with spike_count >= minimum_spike_count (:130), spike_count is exactly this count (every targeted
-    // entry belongs to one power), and counts only decrease: cells below the threshold are examined by the reference to no
-    // effect, so they never enter the heap (identical outcome; most cells have 0 or 1 spontaneous events on their trials).
-    if (!(minimum_spike_count > 0.0) || (double)c >= minimum_spike_count) heap.push({c, n});
-    else cnt[n] = -1;
+int cm_set_single(cm_ctx* ctx, cm_problem* p, cm_set* s) {
+  s->ps.assign(1, p);
+  return set_build(ctx, s);
+}
+
+// priors -> device, one pinned transfer per circuit (mu_prior | beta_prior | phi_prior | phi_cov_prior | scalars); the state is
+// then initialised from them on the device (k_init_state, caviar.py:44-49)
+static int upload_priors(cm_ctx* ctx, cm_set& s, const cm_priors* prs) {
+  hipStream_t st = ctx->stream;
+  const size_t N = s.lead->N, n = 8 * N + CM_S_COUNT;
+  CM_HIP(hipStreamSynchronize(st));                 // the staging buffer may still feed an earlier transfer of this context
+  size_t slab_tot = 0;
+  for (const cm_problem* q : s.ps) slab_tot += 2 * N + (size_t)q->K + (size_t)q->nnz;
+  CM_TRY(stage_reserve(ctx, std::max(n * s.B, slab_tot) * sizeof(double)));
+  for (int c = 0; c < s.B; ++c) {
+    const cm_priors* pr = &prs[c];
+    double* h = (double*)ctx->h_stage + n * c;
+    memcpy(h, pr->mu, N * 8); memcpy(h + N, pr->beta, N * 8); memcpy(h + 2 * N, pr->phi, 2 * N * 8); memcpy(h + 4 * N, pr->phi_cov, 4 * N * 8);
+    double* sc = h + 8 * N;
+    for (int i = 0; i < CM_S_COUNT; ++i) sc[i] = 0.0;
+    sc[CM_S_SHAPE] = pr->shape; sc[CM_S_RATE] = pr->rate; sc[CM_S_SHAPE_PRIOR] = pr->shape; sc[CM_S_RATE_PRIOR] = pr->rate;
+    CM_HIP(hipMemcpyAsync(s.ps[c]->pslab, h, n * sizeof(double), hipMemcpyHostToDevice, st));
   }
-  std::vector<double> srates(P > 0 ? P : 0);
-  std::vector<int> locs;
-  while (!heap.empty()) {
-    if (!((double)nz > minimum_spike_count)) break;                           // :111,141
-    const Ent top = heap.top();
-    heap.pop();
-    if (cnt[top.n] < 0) continue;                                             // already visited
-    if (top.c != cnt[top.n]) {                                                // stale: re-queue with the current count
-      if (!(minimum_spike_count > 0.0) || (double)cnt[top.n] >= minimum_spike_count) heap.push({cnt[top.n], top.n});
-      else cnt[top.n] = -1;
-      continue;
-    }
-    const int focus = top.n;
-    double spike_count = 0.0;
-    for (int i = 0; i < P; ++i) {                                             // :121-127
-      long c = 0, hit = 0;
-      for (int e = p->h_row_ptr[focus]; e < p->h_row_ptr[focus + 1]; ++e)
-        if (p->h_grp[e] == i + 1) { ++c; hit += (z[p->h_col[e]] != 0.0); }
-      srates[i] = c > 0 ? (double)hit / (double)c : 0.0;
-      if (c > 0) spike_count += (double)hit;
-    }
-    const double pava = P > 0 ? cm_host_pava_last(srates.data(), P) : 0.0;    // :128
-    cnt[focus] = -1;                                                          // :139 (removed whether or not it reconnects)
-    if (pava >= minimax_spk_prob && spike_count >= minimum_spike_count) {     // :130
-      locs.clear();
-      for (int e = p->h_row_ptr[focus]; e < p->h_row_ptr[focus + 1]; ++e) if (z[p->h_col[e]] != 0.0) locs.push_back(e);
-      const size_t m = locs.size();
-      double s = 0.0;
-      for (int e : locs) s += z[p->h_col[e]];
-      const double mean = s / (double)m;
-      double ssd = 0.0;
-      for (int e : locs) { const double d = z[p->h_col[e]] - mean; ssd += d * d; }
-      mu[focus] = mean;                                                        // :134
-      beta[focus] = m > 1 ? sqrt(ssd / (double)(m - 1)) / sqrt((double)m) : NAN;   // :135 scipy.stats.sem, ddof = 1
-      for (int e : locs) {                                                     // :136-137
-        const int k = p->h_col[e];
-        lam[e] = 1.0; z[k] = 0.0;
-        for (int ce = p->h_col_ptr[k]; ce < p->h_col_ptr[k + 1]; ++ce) { const int mrow = p->h_csc_row[ce]; if (cnt[mrow] > 0) --cnt[mrow]; }
-      }
-      nz -= (long)m;
-      if (verbose) fprintf(stderr, "Reconnecting cell %d with maximal pava spike rate %.2f\n", focus, pava);
-    }
-  }
-  if (verbose) fprintf(stderr, "Examined %zu/%d cells for false negatives. Cell reconnection complete.\n", init, N);
+  return CM_OK;
+}
+
+static cm_host_rows host_rows(const cm_problem* p) {
+  cm_host_rows r;
+  r.N = p->N; r.K = p->K; r.V = p->V;
+  r.row_ptr = p->h_row_ptr.data(); r.col = p->h_col.data(); r.grp = p->h_grp.data();
+  r.col_ptr = p->h_col_ptr.data(); r.csc_row = p->h_csc_row.data();
+  return r;
 }
 
 static int alloc_hist(cm_problem* p, int iters) {
@@ -387,39 +369,95 @@ static int record_hist(cm_ctx* ctx, cm_problem* p, int it, int part) {
   return CM_OK;
 }
 
-static int caviar_run_impl(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, const cm_options* o, cm_timings* tm);
+static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_options* o, cm_timings* tm);
 
 // Single exit path: an error return (bad argument, HIP failure, not-SPD, ...) may leave kernels and asynchronous copies queued on
-// both streams that still read host arrays of the CALLER (explicit RNG streams) or of this problem (key schedule); both streams
+// both streams that still read host arrays of the CALLER (explicit RNG streams) or of the problem (key schedule); both streams
 // are drained before the error is handed back, so that nothing outlives the buffers it reads.
-extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, const cm_options* o, cm_timings* tm) {
-  const int rc = caviar_run_impl(ctx, p, pr, o, tm);
-  if (rc != CM_OK && ctx) {
+static int run_guarded(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_options* o, cm_timings* tm) {
+  const int rc = run_set(ctx, s, prs, o, tm);
+  if (rc != CM_OK) {
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     if (ctx->side) hipStreamSynchronize(ctx->side);
   }
   return rc;
 }
 
-static int caviar_run_impl(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, const cm_options* o, cm_timings* tm) {
-  if (!ctx || !p || !pr || !o) { cm_set_error("cm_caviar_run: NULL argument"); return CM_ERR_INVALID; }
-  if (!pr->mu || !pr->beta || !pr->phi || !pr->phi_cov) { cm_set_error("cm_caviar_run: NULL prior array"); return CM_ERR_INVALID; }
-  if (o->iters < 0 || o->num_mc_samples < 1) { cm_set_error("cm_caviar_run: iters >= 0 and num_mc_samples >= 1 required"); return CM_ERR_INVALID; }
+static int check_run_args(const char* who, cm_ctx* ctx, const cm_priors* pr, int n, const cm_options* o) {
+  if (!ctx || !pr || !o) { cm_set_error("%s: NULL argument", who); return CM_ERR_INVALID; }
+  for (int c = 0; c < n; ++c)
+    if (!pr[c].mu || !pr[c].beta || !pr[c].phi || !pr[c].phi_cov) { cm_set_error("%s: NULL prior array (circuit %d)", who, c); return CM_ERR_INVALID; }
+  if (o->iters < 0 || o->num_mc_samples < 1) { cm_set_error("%s: iters >= 0 and num_mc_samples >= 1 required", who); return CM_ERR_INVALID; }
   if (o->rng_mode == CM_RNG_EXPLICIT && (!o->update_orders || !o->uniforms)) {
-    cm_set_error("cm_caviar_run: CM_RNG_EXPLICIT needs update_orders and uniforms"); return CM_ERR_INVALID;
+    cm_set_error("%s: CM_RNG_EXPLICIT needs update_orders and uniforms", who); return CM_ERR_INVALID;
+  }
+  return CM_OK;
+}
+
+extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, const cm_options* o, cm_timings* tm) {
+  if (!p) { cm_set_error("cm_caviar_run: NULL argument"); return CM_ERR_INVALID; }
+  CM_TRY(check_run_args("cm_caviar_run", ctx, pr, 1, o));
+  if (p->ctx != ctx) { cm_set_error("cm_caviar_run: the problem belongs to another context"); return CM_ERR_INVALID; }
+  CM_HIP(hipSetDevice(ctx->device));
+  cm_set s;
+  s.ps.assign(1, p);
+  return run_guarded(ctx, s, pr, o, tm);
+}
+
+// Lock-step batch (include/caviar_hip.h): circuits with the same launch configuration form a group and share every launch (the
+// circuit is the outer grid dimension); groups run one after the other.
+extern "C" int cm_caviar_run_batch(cm_ctx* ctx, int32_t n, cm_problem* const* problems, const cm_priors* priors, const cm_options* o,
+                                   cm_timings* timings) {
+  if (!problems || n < 1) { cm_set_error("cm_caviar_run_batch: need n_circuits >= 1 and a problem array"); return CM_ERR_INVALID; }
+  CM_TRY(check_run_args("cm_caviar_run_batch", ctx, priors, n, o));
+  for (int c = 0; c < n; ++c) {
+    if (!problems[c]) { cm_set_error("cm_caviar_run_batch: problem %d is NULL", c); return CM_ERR_INVALID; }
+    if (problems[c]->ctx != ctx) { cm_set_error("cm_caviar_run_batch: problem %d belongs to another context", c); return CM_ERR_INVALID; }
+    for (int d = 0; d < c; ++d)
+      if (problems[d] == problems[c]) { cm_set_error("cm_caviar_run_batch: problem %d appears twice", c); return CM_ERR_INVALID; }
   }
   CM_HIP(hipSetDevice(ctx->device));
+  std::vector<char> done(n, 0);
+  for (int c0 = 0; c0 < n; ++c0) {
+    if (done[c0]) continue;
+    cm_set s;
+    std::vector<int> idx;
+    for (int c = c0; c < n && (int)idx.size() < CM_MAX_BATCH; ++c)
+      if (!done[c] && cm_same_launch_config(problems[c0], problems[c])) { idx.push_back(c); done[c] = 1; s.ps.push_back(problems[c]); }
+    std::vector<cm_priors> prs(idx.size());
+    std::vector<cm_timings> tms(idx.size());
+    for (size_t i = 0; i < idx.size(); ++i) prs[i] = priors[idx[i]];
+    CM_TRY(run_guarded(ctx, s, prs.data(), o, timings ? tms.data() : nullptr));
+    if (timings) for (size_t i = 0; i < idx.size(); ++i) timings[idx[i]] = tms[i];
+  }
+  return CM_OK;
+}
+
+// circuits that can share launches: same sizes (grids, table layouts), same lane-segment class of V (kernel template), and every
+// static property the kernel variants are chosen by
+static int seg_class(int V) { int c = 1; while (c < V) c <<= 1; return c; }
+bool cm_same_launch_config(const cm_problem* a, const cm_problem* b) {
+  if (a->N != b->N || a->K != b->K || seg_class(a->V) != seg_class(b->V)) return false;
+  auto par_ok = [](const cm_problem* q) { return q->max_row_len <= CM_WAVE && q->max_col_len <= 255 && q->nnz < (1 << 24); };
+  return par_ok(a) == par_ok(b);
+}
+
+static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_options* o, cm_timings* tm) {
   hipStream_t st = ctx->stream;
-  const int N = p->N, K = p->K, S = o->num_mc_samples, iters = o->iters;
-  p->ran = false;
+  cm_problem* p = s.ps[0];                           // the leader: sizes and random tables of the whole set
+  const int B = (int)s.ps.size();
+  const int N = p->N, S = o->num_mc_samples, iters = o->iters;
+  for (cm_problem* q : s.ps) q->ran = false;
   CM_HIP(hipEventRecord(ctx->ev[0], st));
 
-  // RNG streams: sweep orders of all iterations live in orders_all (uploaded, or generated below in one batched launch)
+  // RNG streams: sweep orders of all iterations live in orders_all (uploaded, or generated below in one batched launch).  They are
+  // data independent: the circuits of a batch share the leader's tables (same seed, N, S).
   if (p->orders_cap < iters) {
     if (p->orders_all) hipFree(p->orders_all);
     if (p->orders_tmp) hipFree(p->orders_tmp);
     if (p->inv_all) hipFree(p->inv_all);
     p->orders_all = p->orders_tmp = p->inv_all = nullptr;
+    p->orders_cap = 0;
     CM_TRY(dmalloc(&p->orders_all, (size_t)iters * N));
     CM_TRY(dmalloc(&p->orders_tmp, (size_t)iters * N));
     CM_TRY(dmalloc(&p->inv_all, (size_t)iters * N));
@@ -427,7 +465,7 @@ static int caviar_run_impl(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, cons
   }
   if (p->wtab_cap < (size_t)iters * N * S * 2) {
     if (p->wtab) hipFree(p->wtab);
-    p->wtab = nullptr;
+    p->wtab = nullptr; p->wtab_cap = 0;
     CM_TRY(dmalloc(&p->wtab, (size_t)iters * N * S * 2));
     p->wtab_cap = (size_t)iters * N * S * 2;
   }
@@ -437,27 +475,28 @@ static int caviar_run_impl(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, cons
     CM_HIP(hipMemcpyAsync(p->uexp, o->uniforms, (size_t)iters * N * S * 2 * sizeof(double), hipMemcpyHostToDevice, st));
     CM_HIP(hipMemcpyAsync(p->orders_all, o->update_orders, (size_t)iters * N * sizeof(int32_t), hipMemcpyHostToDevice, st));
   }
-  CM_TRY(upload_priors(ctx, p, pr));
-  CM_TRY(cm_launch_init_state(ctx, p, o->y_xcorr_thresh));
-  CM_HIP(hipMemsetAsync(p->n_act, 0, 4 * sizeof(int), st));
-  CM_HIP(hipMemsetAsync(p->seq_meta, 0, 8 * sizeof(int), st));
   // Threefry key chain (host, sequential by nature): only iteration 0's keys are produced here; the rest is computed while
   // the GPU works on iteration 0 and turned into permutations / ndtri tables on the side stream (see the loop below).
   std::vector<uint32_t>& keys = p->h_keys;           // lives in the problem: asynchronous uploads read it after this function returns
   uint32_t chain[2] = {(uint32_t)(o->seed >> 32), (uint32_t)(o->seed & 0xFFFFFFFFull)};
   const size_t key_per = (size_t)(N + 3) * 2;
+  if (o->rng_mode == CM_RNG_THREEFRY && iters > 0) {
+    keys.assign(key_per * iters, 0u);
+    if (p->keys_iters < iters) {
+      if (p->keys) hipFree(p->keys);
+      p->keys = nullptr; p->keys_iters = 0;
+      CM_TRY(dmalloc(&p->keys, keys.size()));
+      p->keys_iters = iters;
+    }
+  }
+  CM_TRY(set_build(ctx, &s));                        // descriptors (after the table allocations they point to)
+  CM_TRY(upload_priors(ctx, s, prs));
+  CM_TRY(cm_launch_init_state(ctx, s, o->y_xcorr_thresh));
   bool rng_deferred = false;
   hipEvent_t pending_ev[2] = {nullptr, nullptr};   // long RNG chunks whose event the main stream has not waited on yet
   int pending_from[2] = {0, 0}, n_pending = 0;     // first iteration each of them serves
   int rng_done = 1;                              // iterations whose keys / orders / tables exist (iteration 0 is done up front)
   if (o->rng_mode == CM_RNG_THREEFRY && iters > 0) {
-    keys.assign(key_per * iters, 0u);
-    if (p->keys_iters < iters) {
-      if (p->keys) hipFree(p->keys);
-      p->keys = nullptr;
-      CM_TRY(dmalloc(&p->keys, keys.size()));
-      p->keys_iters = iters;
-    }
     cm_host_key_schedule_range(chain, 0, 1, N, keys.data());
     CM_HIP(hipMemcpyAsync(p->keys, keys.data(), key_per * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     CM_TRY(cm_launch_rng(ctx, p, 0, 1, st));                       // :196 update order of iteration 0
@@ -466,7 +505,7 @@ static int caviar_run_impl(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, cons
   } else {
     CM_TRY(cm_launch_ndtri_table(ctx, p, 0, iters, S, o->rng_mode, st));   // explicit streams: tabulate the uploaded uniforms
   }
-  if (o->save_histories && iters > 0) CM_TRY(alloc_hist(p, iters)); else free_hist(p);
+  for (cm_problem* q : s.ps) { if (o->save_histories && iters > 0) CM_TRY(alloc_hist(q, iters)); else free_hist(q); }
 
   static const bool trace_iters = getenv("CAVIAR_HIP_TRACE_ITERS") != nullptr;   // diagnostic: implies the per-kernel stamps
   static const bool trace_host = getenv("CAVIAR_HIP_TRACE_HOST") != nullptr;     // diagnostic: host clock at every mailbox arrival (no events)
@@ -475,7 +514,7 @@ static int caviar_run_impl(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, cons
   const bool phases = tm != nullptr && o->timing >= 2;  // all phase stamps (more events and host API calls per iteration)
   while (ctx->pool.size() < (size_t)(iters + 1) * CM_EV_PER_IT) { hipEvent_t e; CM_HIP(hipEventCreate(&e)); ctx->pool.push_back(e); }
   auto EV = [&](int it, int j) { return ctx->pool[(size_t)it * CM_EV_PER_IT + j]; };
-  auto post_wait_fallback = [&]() -> int {       // CAVIAR_HIP_NO_MAILBOX=1: classic copy + event instead of the mapped mailbox
+  auto post_wait_fallback = [&]() -> int {       // CAVIAR_HIP_NO_MAILBOX=1 (one circuit): classic copy + event instead of the mapped mailbox
     if (!ctx->use_mailbox) {
       CM_HIP(hipMemcpyAsync(ctx->h_pinned + 8, p->n_act, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
       CM_HIP(hipEventRecord(ctx->ev[7], st));
@@ -483,26 +522,30 @@ static int caviar_run_impl(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, cons
     return CM_OK;
   };
   CM_HIP(hipEventRecord(ctx->ev[1], st));
-  CM_TRY(cm_launch_stats(ctx, p, o->spont_orthogonality));           // row sums of lam0
+  CM_TRY(cm_launch_stats(ctx, s, o->spont_orthogonality));           // row sums of lam0
   if (iters > 0) {                                                   // active set + block_update_mu + MC logit of iteration 0
-    CM_TRY(cm_launch_iter_mid(ctx, p, -1, iters, S, o->rng_mode, o, 0, 0));
+    CM_TRY(cm_launch_iter_mid(ctx, s, -1, iters, S, o->rng_mode, o, 0, 0));
     CM_TRY(post_wait_fallback());
   }
   int last_active = 0;
-  long long sum_active = 0;
+  std::vector<long long> sum_active(B, 0);
+  std::vector<int> last_act(B, 0);
+  std::vector<char> fact_it(iters > 0 ? iters : 1, 0);      // iterations that ran a tiled solve
   for (int it = 0; it < iters; ++it) {                               // caviar.py:79
     p->order = p->orders_all + (size_t)it * N;
     if (phases) CM_HIP(hipEventRecord(EV(it, 0), st));
-    CM_TRY(cm_wait_active(ctx, p));                                  // the one host wait of an iteration: size of the active set
+    CM_TRY(cm_wait_active(ctx, s));                                  // the one host wait of an iteration: sizes of the active sets
     if (trace_host) host_stamps.push_back(std::chrono::steady_clock::now());
-    last_active = ctx->mb_n;
-    sum_active += last_active;
+    last_active = s.na_max;
+    bool any_big = false;
+    for (int c = 0; c < B; ++c) { sum_active[c] += s.na[c]; last_act[c] = s.na[c]; any_big |= s.na[c] > s.ps[c]->small_cap; }
     if (ctx->mb_flag) { cm_set_error("iteration %d: weight precision matrix not positive definite", it); return CM_ERR_NOT_SPD; }
-    if (last_active > p->small_cap) CM_TRY(cm_solve_launch(ctx, p, last_active));   // :80 block_update_mu, large active set
+    if (any_big) CM_TRY(cm_solve_launch(ctx, s, 0, timed ? EV(it, 6) : nullptr, timed ? EV(it, 7) : nullptr));   // :80 block_update_mu, large active sets (small ones: fused kernel)
+    fact_it[it] = any_big && s.last_fact;
     if (phases) CM_HIP(hipEventRecord(EV(it, 1), st));
-    CM_TRY(cm_launch_sweep(ctx, p, it, o, timed ? EV(it, 3) : nullptr));  // :81  update_lam
+    CM_TRY(cm_launch_sweep(ctx, s, it, o, timed ? EV(it, 3) : nullptr));  // :81  update_lam
     if (timed) CM_HIP(hipEventRecord(EV(it, 4), st));
-    CM_TRY(cm_launch_stats(ctx, p, o->spont_orthogonality));         // row + column statistics of the new lam
+    CM_TRY(cm_launch_stats(ctx, s, o->spont_orthogonality));         // row + column statistics of the new lam
     if (rng_deferred) {
       // The work of this iteration is enqueued and the GPU is busy with it: extend the (sequential, host-side) threefry key
       // chain (~17 us per iteration at N = 1000) and turn it into sweep orders / ndtri tables on the side stream.  Three chunks,
@@ -529,38 +572,57 @@ static int caviar_run_impl(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, cons
     }
     for (int q = 0; q < n_pending; ++q)                               // k_iter_mid below draws the MC logit of iteration it + 1
       if (pending_ev[q] && it + 1 >= pending_from[q]) { CM_HIP(hipStreamWaitEvent(st, pending_ev[q], 0)); pending_ev[q] = nullptr; }
-    if (o->save_histories) CM_TRY(record_hist(ctx, p, it, 0));       // mu, beta, lam of this iteration (:90-92)
+    if (o->save_histories) for (cm_problem* q : s.ps) CM_TRY(record_hist(ctx, q, it, 0));   // mu, beta, lam of this iteration (:90-92)
     // :84-88 update_sigma, update_phi, z, spont_rate; then block_update_mu (small sets) and the MC logit of iteration it + 1
     if (timed) CM_HIP(hipEventRecord(EV(it, 8), st));
-    CM_TRY(cm_launch_iter_mid(ctx, p, it, iters, S, o->rng_mode, o, 1, 1));
+    CM_TRY(cm_launch_iter_mid(ctx, s, it, iters, S, o->rng_mode, o, 1, 1));
     if (timed) CM_HIP(hipEventRecord(EV(it, 9), st));
     CM_TRY(post_wait_fallback());
-    if (o->save_histories) CM_TRY(record_hist(ctx, p, it, 1));       // shape, rate, phi, phi_cov, z
+    if (o->save_histories) for (cm_problem* q : s.ps) CM_TRY(record_hist(ctx, q, it, 1));   // shape, rate, phi, phi_cov, z
     if (phases) CM_HIP(hipEventRecord(EV(it, 5), st));
     if (o->verbose >= 3) {
       CM_HIP(hipStreamSynchronize(st));
-      fprintf(stderr, "[caviar_hip] it %d active %d\n", it, last_active);
+      fprintf(stderr, "[caviar_hip] it %d largest active set %d (%d circuit%s)\n", it, last_active, B, B == 1 ? "" : "s");
     }
   }
   CM_HIP(hipEventRecord(ctx->ev[2], st));
 
   if (o->fn_scan) {                                                  // caviar.py:94-98
-    // mu | beta | z | lam are one device slab: one pinned copy down, the host scan, one copy back, final update_phi
-    const size_t nslab = 2 * (size_t)N + K + (size_t)p->nnz;
-    CM_TRY(stage_reserve(ctx, nslab * sizeof(double)));
-    double* h = (double*)ctx->h_stage;
-    CM_HIP(hipMemcpyAsync(h, p->slab, nslab * sizeof(double), hipMemcpyDeviceToHost, st));
+    // mu | beta | z | lam are one device slab per circuit: one pinned copy down, the host scan, one copy back, final update_phi.
+    // The scans of a batch are independent: they run on a few host threads.
+    std::vector<size_t> off(B + 1, 0);
+    for (int c = 0; c < B; ++c) off[c + 1] = off[c] + 2 * (size_t)N + s.ps[c]->K + (size_t)s.ps[c]->nnz;
+    CM_TRY(stage_reserve(ctx, off[B] * sizeof(double)));
+    double* hbase = (double*)ctx->h_stage;
+    for (int c = 0; c < B; ++c)
+      CM_HIP(hipMemcpyAsync(hbase + off[c], s.ps[c]->slab, (off[c + 1] - off[c]) * sizeof(double), hipMemcpyDeviceToHost, st));
     CM_HIP(hipStreamSynchronize(st));
-    host_reconnect(p, h, h + N, h + 2 * (size_t)N + K, h + 2 * (size_t)N, o->msrmp, o->minimum_spike_count, o->verbose);
-    CM_HIP(hipMemcpyAsync(p->slab, h, nslab * sizeof(double), hipMemcpyHostToDevice, st));
-    CM_TRY(cm_launch_update_phi(ctx, p, st));
+    auto scan = [&](int c) {
+      const cm_problem* q = s.ps[c];
+      double* h = hbase + off[c];
+      cm_host_reconnect(host_rows(q), h, h + N, h + 2 * (size_t)N + q->K, h + 2 * (size_t)N, o->msrmp, o->minimum_spike_count, o->verbose);
+    };
+    const int nthreads = (B > 1 && o->verbose == 0) ? std::min<int>(B, std::max(1u, std::min(8u, std::thread::hardware_concurrency()))) : 1;
+    if (nthreads <= 1) {
+      for (int c = 0; c < B; ++c) scan(c);
+    } else {
+      std::atomic<int> next(0);
+      std::vector<std::thread> pool;
+      for (int t = 0; t < nthreads; ++t) pool.emplace_back([&]() { for (int c; (c = next.fetch_add(1)) < B;) scan(c); });
+      for (auto& t : pool) t.join();
+    }
+    for (int c = 0; c < B; ++c)
+      CM_HIP(hipMemcpyAsync(s.ps[c]->slab, hbase + off[c], (off[c + 1] - off[c]) * sizeof(double), hipMemcpyHostToDevice, st));
+    CM_TRY(cm_launch_update_phi(ctx, s, st));
   }
   CM_HIP(hipEventRecord(ctx->ev[3], st));
   CM_HIP(hipStreamSynchronize(st));
   if (iters > 0) {
-    CM_HIP(hipMemcpy(ctx->h_pinned + 8, p->n_act, 4 * sizeof(int), hipMemcpyDeviceToHost));   // [8..11]: outside the mailbox words
-    if (ctx->h_pinned[9]) { cm_set_error("weight precision matrix not positive definite"); return CM_ERR_NOT_SPD; }
-    if (ctx->h_pinned[10]) { cm_set_error("sweep ticket wait timed out (internal error)"); return CM_ERR_STATE; }
+    for (int c = 0; c < B; ++c) {
+      CM_HIP(hipMemcpy(ctx->h_pinned + 8, s.ps[c]->n_act, 4 * sizeof(int), hipMemcpyDeviceToHost));   // [8..11]: outside the mailbox words
+      if (ctx->h_pinned[9]) { cm_set_error("weight precision matrix not positive definite (circuit %d of the set)", c); return CM_ERR_NOT_SPD; }
+      if (ctx->h_pinned[10]) { cm_set_error("sweep ticket wait timed out (internal error, circuit %d of the set)", c); return CM_ERR_STATE; }
+    }
   }
   if (trace_host)
     for (size_t i = 1; i < host_stamps.size(); ++i)
@@ -570,29 +632,36 @@ static int caviar_run_impl(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, cons
     hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[3]);
     hipEventElapsedTime(&b, ctx->ev[1], ctx->ev[2]);
     hipEventElapsedTime(&c, ctx->ev[2], ctx->ev[3]);
-    memset(tm, 0, sizeof(*tm));
-    tm->total_ms = a; tm->iters_ms = b; tm->fn_scan_ms = c; tm->iters = iters; tm->last_active = last_active;
-    tm->sum_active = sum_active;
-    int meta[8] = {0};
-    if (hipMemcpy(meta, p->seq_meta, sizeof(meta), hipMemcpyDeviceToHost) == hipSuccess) { tm->sum_seq_rows = meta[4]; tm->sum_seq_records = meta[5]; }
+    cm_timings t0;
+    memset(&t0, 0, sizeof(t0));
+    t0.total_ms = a; t0.iters_ms = b; t0.fn_scan_ms = c; t0.iters = iters; t0.batch = B;
+    t0.fact_launches = s.fact_launches; t0.fact_tile_updates = s.fact_tile_updates;
     for (int it = 0; timed && it < iters; ++it) {
       float d = 0;
       hipEventElapsedTime(&d, EV(it, 3), EV(it, 4));
-      tm->sweep_seq_ms += d;
+      t0.sweep_seq_ms += d;
       hipEventElapsedTime(&d, EV(it, 8), EV(it, 9));
-      tm->mid_ms += d;
+      t0.mid_ms += d;
+      if (fact_it[it] && hipEventElapsedTime(&d, EV(it, 6), EV(it, 7)) == hipSuccess) t0.fact_ms += d;
       if (trace_iters && it > 0) {                                            // diagnostic: wall time of every iteration
         float e = 0;
         hipEventElapsedTime(&e, EV(it - 1, 9), EV(it, 9));
         fprintf(stderr, "it %2d %8.1f us (k_iter_mid incl. its launch gap %.1f)\n", it, e * 1e3, d * 1e3);
       }
       if (!phases) continue;
-      hipEventElapsedTime(&d, EV(it, 0), EV(it, 1)); tm->solve_ms += d;        // host wait + large-set solve (small sets are fused)
-      hipEventElapsedTime(&d, EV(it, 1), EV(it, 3)); tm->sweep_indep_ms += d;  // pre-sweep + pack
-      hipEventElapsedTime(&d, EV(it, 4), EV(it, 5)); tm->post_ms += d;         // stats + fused mid-iteration kernel
+      hipEventElapsedTime(&d, EV(it, 0), EV(it, 1)); t0.solve_ms += d;        // host wait + large-set solve (small sets are fused)
+      hipEventElapsedTime(&d, EV(it, 1), EV(it, 3)); t0.sweep_indep_ms += d;  // pre-sweep + pack
+      hipEventElapsedTime(&d, EV(it, 4), EV(it, 5)); t0.post_ms += d;         // stats + fused mid-iteration kernel
+    }
+    for (int ci = 0; ci < B; ++ci) {                                          // the device times are those of the whole set
+      tm[ci] = t0;
+      tm[ci].last_active = last_act[ci];
+      tm[ci].sum_active = sum_active[ci];
+      int meta[8] = {0};
+      if (hipMemcpy(meta, s.ps[ci]->seq_meta, sizeof(meta), hipMemcpyDeviceToHost) == hipSuccess) { tm[ci].sum_seq_rows = meta[4]; tm[ci].sum_seq_records = meta[5]; }
     }
   }
-  p->ran = true;
+  for (cm_problem* q : s.ps) q->ran = true;
   return CM_OK;
 }
 
@@ -662,6 +731,53 @@ extern "C" int cm_caviar_fit(cm_ctx* ctx, int32_t N, int32_t K, int32_t T, const
   return rc;
 }
 
+// Batch of circuits over the GPUs of this process: circuit c goes to device_ids[c % n_devices]; every device gets one
+// host thread with its own context, which creates its circuits, runs them as ONE lock-step batch, fetches and destroys them.
+extern "C" int cm_caviar_fit_batch(int32_t n, const int32_t* N, const int32_t* K, const int32_t* T, const double* const* psc,
+                                   const double* const* stim, const cm_priors* priors, const cm_options* o, const int32_t* device_ids,
+                                   int32_t n_devices, cm_result* results, cm_timings* timings) {
+  if (n < 1 || !N || !K || !T || !psc || !stim || !priors || !o || !results) { cm_set_error("cm_caviar_fit_batch: NULL argument or n_circuits < 1"); return CM_ERR_INVALID; }
+  const int32_t dev0 = 0;
+  if (!device_ids || n_devices < 1) { device_ids = &dev0; n_devices = 1; }
+  std::vector<int> rcs(n_devices, CM_OK);
+  std::vector<std::string> msgs(n_devices);
+  auto work = [&](int d) {
+    auto fail = [&](int rc) { rcs[d] = rc; msgs[d] = cm_last_error(); };
+    std::vector<int> mine;
+    for (int c = d; c < n; c += n_devices) mine.push_back(c);
+    if (mine.empty()) return;
+    cm_ctx* ctx = nullptr;
+    int rc = cm_ctx_create(device_ids[d], nullptr, &ctx);
+    if (rc) return fail(rc);
+    std::vector<cm_problem*> ps;
+    std::vector<cm_priors> prs;
+    for (int c : mine) {
+      cm_problem* q = nullptr;
+      if ((rc = cm_problem_create(ctx, N[c], K[c], T[c], psc[c], stim[c], CM_MEM_HOST, &q))) break;
+      ps.push_back(q);
+      prs.push_back(priors[c]);
+    }
+    std::vector<cm_timings> tms(mine.size());
+    if (!rc) rc = cm_caviar_run_batch(ctx, (int)ps.size(), ps.data(), prs.data(), o, timings ? tms.data() : nullptr);
+    for (size_t i = 0; !rc && i < mine.size(); ++i) {
+      rc = cm_caviar_fetch(ctx, ps[i], &results[mine[i]]);
+      if (timings) timings[mine[i]] = tms[i];
+    }
+    if (rc) fail(rc);
+    for (cm_problem* q : ps) cm_problem_destroy(q);
+    cm_ctx_destroy(ctx);
+  };
+  if (n_devices == 1) work(0);
+  else {
+    std::vector<std::thread> th;
+    for (int d = 0; d < n_devices; ++d) th.emplace_back(work, d);
+    for (auto& t : th) t.join();
+  }
+  for (int d = 0; d < n_devices; ++d)
+    if (rcs[d] != CM_OK) { cm_set_error("device %d: %s", device_ids[d], msgs[d].c_str()); return rcs[d]; }
+  return CM_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // per-phase entry points for the parity tests
 // ------------------------------------------------------------------------------------------------
@@ -708,9 +824,11 @@ extern "C" int cm_k_block_update_mu(cm_ctx* ctx, int32_t N, int32_t K, const dou
       hipMemcpy(p->beta_prior, beta_prior, (size_t)N * 8, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemset(p->n_act, 0, 4 * sizeof(int)) != hipSuccess) { cm_set_error("upload failed"); rc = CM_ERR_HIP; }
   int na = 0;
-  if (!rc) rc = cm_launch_stats(ctx, p, 0.1);
-  if (!rc) rc = cm_launch_post_single(ctx, p, -1, nullptr, 0);
-  if (!rc) rc = cm_solve_mu(ctx, p, &na);
+  cm_set set;
+  if (!rc) rc = cm_set_single(ctx, p, &set);
+  if (!rc) rc = cm_launch_stats(ctx, set, 0.1);
+  if (!rc) rc = cm_launch_post_single(ctx, set, -1, nullptr, 0);
+  if (!rc) rc = cm_solve_mu(ctx, set, &na);
   if (!rc && (hipMemcpyAsync(mu, p->mu, (size_t)N * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
               hipMemcpyAsync(beta, p->beta, (size_t)N * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
               hipMemcpyAsync(ctx->h_pinned + 8, p->n_act, 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -729,11 +847,127 @@ extern "C" int cm_k_update_phi(cm_ctx* ctx, int32_t N, int32_t K, const double* 
   int rc = CM_OK;
   if (hipMemcpy(p->phi_prior, phi_prior, (size_t)N * 16, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(p->phi_cov_prior, phi_cov_prior, (size_t)N * 32, hipMemcpyHostToDevice) != hipSuccess) { cm_set_error("upload failed"); rc = CM_ERR_HIP; }
-  if (!rc) rc = cm_launch_update_phi(ctx, p, st);
+  cm_set set;
+  if (!rc) rc = cm_set_single(ctx, p, &set);
+  if (!rc) rc = cm_launch_update_phi(ctx, set, st);
   if (!rc && (hipMemcpyAsync(phi, p->phi, (size_t)N * 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
               hipMemcpyAsync(phi_cov, p->phi_cov, (size_t)N * 32, hipMemcpyDeviceToHost, st) != hipSuccess ||
               hipStreamSynchronize(st) != hipSuccess)) { cm_set_error("download failed: %s", hipGetErrorString(hipGetLastError())); rc = CM_ERR_HIP; }
   cm_problem_destroy(p);
+  return rc;
+}
+
+// update_sigma (caviar.py:238-244) and estimate_spont_act_soft_thresh + spont_rate (caviar.py:147-163, :88) on a dense lam: the
+// single-workgroup phases exactly as block 0 of the fused mid-iteration kernel runs them
+static int post_hook(cm_ctx* ctx, int N, int K, const double* stim, const double* lam, const double* y, const uint8_t* mask, const double* mu,
+                     const double* beta, double shape_prior, double rate_prior, int it, const cm_options* o, double* z, double* scal_out) {
+  cm_problem* p = nullptr;
+  CM_TRY(problem_from_dense(ctx, N, K, stim, lam, y, &p));
+  hipStream_t st = ctx->stream;
+  double h[CM_S_COUNT] = {0};
+  h[CM_S_SHAPE] = h[CM_S_SHAPE_PRIOR] = shape_prior; h[CM_S_RATE] = h[CM_S_RATE_PRIOR] = rate_prior;
+  std::vector<uint8_t> ones((size_t)K, 1);
+  std::vector<double> zeros((size_t)std::max(N, K), 0.0);
+  int rc = CM_OK;
+  if (hipMemcpy(p->scal, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(p->mu, mu, (size_t)N * 8, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(p->beta, beta ? beta : zeros.data(), (size_t)N * 8, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(p->mask, mask ? mask : ones.data(), (size_t)K, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(p->z, z ? z : zeros.data(), (size_t)K * 8, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemset(p->n_act, 0, 4 * sizeof(int)) != hipSuccess) { cm_set_error("upload failed"); rc = CM_ERR_HIP; }
+  cm_set set;
+  if (!rc) rc = cm_set_single(ctx, p, &set);
+  if (!rc) rc = cm_launch_sum_y(ctx, set);
+  if (!rc) rc = cm_launch_stats(ctx, set, o->spont_orthogonality);
+  if (!rc) rc = cm_launch_post_single(ctx, set, it, o, 1);
+  if (!rc && ((z && hipMemcpyAsync(z, p->z, (size_t)K * 8, hipMemcpyDeviceToHost, st) != hipSuccess) ||
+              hipMemcpyAsync(scal_out, p->scal, CM_S_COUNT * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+              hipStreamSynchronize(st) != hipSuccess)) { cm_set_error("download failed: %s", hipGetErrorString(hipGetLastError())); rc = CM_ERR_HIP; }
+  cm_problem_destroy(p);
+  return rc;
+}
+
+extern "C" int cm_k_sigma(cm_ctx* ctx, int32_t N, int32_t K, const double* stim, const double* lam, const double* y, const double* mu,
+                          const double* beta, double shape_prior, double rate_prior, double* shape, double* rate) {
+  if (!ctx || !stim || !lam || !y || !mu || !beta || !shape || !rate) { cm_set_error("cm_k_sigma: NULL argument"); return CM_ERR_INVALID; }
+  CM_HIP(hipSetDevice(ctx->device));
+  cm_options o;
+  cm_options_default(&o);
+  o.max_backtrack_iters = 0;                        // no soft-threshold passes: only update_sigma is wanted
+  double sc[CM_S_COUNT];
+  CM_TRY(post_hook(ctx, N, K, stim, lam, y, nullptr, mu, beta, shape_prior, rate_prior, 0, &o, nullptr, sc));
+  *shape = sc[CM_S_SHAPE]; *rate = sc[CM_S_RATE];
+  return CM_OK;
+}
+
+extern "C" int cm_k_spont(cm_ctx* ctx, int32_t N, int32_t K, const double* stim, const double* lam, const double* y, const uint8_t* mask,
+                          const double* mu, int32_t it, int32_t max_backtrack_iters, double penalty, double scale_factor, double tol,
+                          double spont_orthogonality, double* z, double* spont_rate) {
+  if (!ctx || !stim || !lam || !y || !mask || !mu || !z) { cm_set_error("cm_k_spont: NULL argument"); return CM_ERR_INVALID; }
+  CM_HIP(hipSetDevice(ctx->device));
+  cm_options o;
+  cm_options_default(&o);
+  o.max_backtrack_iters = max_backtrack_iters; o.penalty = penalty; o.scale_factor = scale_factor; o.tol = tol; o.spont_orthogonality = spont_orthogonality;
+  double sc[CM_S_COUNT];
+  CM_TRY(post_hook(ctx, N, K, stim, lam, y, mask, mu, nullptr, 1.0, 1.0, it, &o, z, sc));
+  if (spont_rate) *spont_rate = sc[CM_S_SPONT_RATE];
+  return CM_OK;
+}
+
+// update_lam (caviar.py:190-231): one Gauss-Seidel sweep over the neurons in the order jax.random.choice(key) gives, the
+// Monte-Carlo logit from phi / phi_cov, the isotonic gate; `key` is the carried jax key, replaced by the key update_lam returns
+extern "C" int cm_k_lam_sweep(cm_ctx* ctx, int32_t N, int32_t K, const double* stim, double* lam, const double* y, const uint8_t* mask,
+                              const double* mu, const double* beta, double shape, double rate, const double* phi, const double* phi_cov,
+                              uint32_t* key, int32_t num_mc_samples, double minimum_spike_count, double minimax_spk_prob, int32_t it,
+                              int32_t delay_spont_est) {
+  if (!ctx || !stim || !lam || !y || !mask || !mu || !beta || !phi || !phi_cov || !key || num_mc_samples < 1) { cm_set_error("cm_k_lam_sweep: bad argument"); return CM_ERR_INVALID; }
+  CM_HIP(hipSetDevice(ctx->device));
+  cm_problem* p = nullptr;
+  CM_TRY(problem_from_dense(ctx, N, K, stim, lam, y, &p));
+  hipStream_t st = ctx->stream;
+  const int S = num_mc_samples;
+  double h[CM_S_COUNT] = {0};
+  h[CM_S_SHAPE] = shape; h[CM_S_RATE] = rate;                       // spont_rate = 0: the threshold is minimax_spk_prob itself
+  cm_options o;
+  cm_options_default(&o);
+  o.iters = 1; o.num_mc_samples = S; o.msrmp = minimax_spk_prob; o.minimum_spike_count = minimum_spike_count; o.delay_spont_est = delay_spont_est;
+  std::vector<uint32_t>& keys = p->h_keys;
+  keys.assign((size_t)(N + 3) * 2, 0u);
+  uint32_t chain[2] = {key[0], key[1]};
+  cm_host_key_schedule_range(chain, 0, 1, N, keys.data());
+  uint32_t kout[2] = {key[0], key[1]};                              // the key update_lam returns: the carry after N splits
+  for (int m = 0; m < N; ++m) { uint32_t a0 = 0, a1 = 2, b0 = 1, b1 = 3; cm_threefry2x32(kout[0], kout[1], a0, a1); cm_threefry2x32(kout[0], kout[1], b0, b1); kout[0] = a1; kout[1] = b1; }
+  int rc = CM_OK;
+  if ((rc = dmalloc(&p->keys, keys.size())) || (rc = dmalloc(&p->orders_all, (size_t)N)) || (rc = dmalloc(&p->orders_tmp, (size_t)N)) ||
+      (rc = dmalloc(&p->inv_all, (size_t)N)) || (rc = dmalloc(&p->wtab, (size_t)N * 2 * S))) {
+  } else if (hipMemcpy(p->keys, keys.data(), keys.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+             hipMemcpy(p->scal, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess ||
+             hipMemcpy(p->mu, mu, (size_t)N * 8, hipMemcpyHostToDevice) != hipSuccess ||
+             hipMemcpy(p->beta, beta, (size_t)N * 8, hipMemcpyHostToDevice) != hipSuccess ||
+             hipMemcpy(p->mask, mask, (size_t)K, hipMemcpyHostToDevice) != hipSuccess ||
+             hipMemcpy(p->phi, phi, (size_t)N * 16, hipMemcpyHostToDevice) != hipSuccess ||
+             hipMemcpy(p->phi_cov, phi_cov, (size_t)N * 32, hipMemcpyHostToDevice) != hipSuccess ||
+             hipMemset(p->n_act, 0, 4 * sizeof(int)) != hipSuccess || hipMemset(p->seq_meta, 0, 8 * sizeof(int)) != hipSuccess) {
+    cm_set_error("upload failed"); rc = CM_ERR_HIP;
+  }
+  p->keys_iters = 1; p->orders_cap = 1; p->wtab_cap = (size_t)N * 2 * S;
+  cm_set set;
+  if (!rc) rc = cm_launch_rng(ctx, p, 0, 1, st);
+  if (!rc) rc = cm_launch_ndtri_table(ctx, p, 0, 1, S, CM_RNG_THREEFRY, st);
+  if (!rc) rc = cm_set_single(ctx, p, &set);
+  if (!rc) rc = cm_launch_iter_mid(ctx, set, -1, 1, S, CM_RNG_THREEFRY, &o, 0, 0, 2);   // per-neuron role only: MC logit from phi / phi_cov
+  ctx->mb_n = N;
+  if (!rc) rc = cm_launch_sweep(ctx, set, it, &o, nullptr, 0);
+  double* d_dense = nullptr;
+  if (!rc) rc = dmalloc(&d_dense, (size_t)N * K);
+  if (!rc) rc = cm_launch_expand_lam(ctx, p, p->lam, d_dense);
+  if (!rc && (hipMemcpyAsync(lam, d_dense, (size_t)N * K * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+              hipMemcpyAsync(ctx->h_pinned + 8, p->n_act, 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
+              hipStreamSynchronize(st) != hipSuccess)) { cm_set_error("download failed: %s", hipGetErrorString(hipGetLastError())); rc = CM_ERR_HIP; }
+  if (!rc && ctx->h_pinned[10]) { cm_set_error("sweep ticket wait timed out (internal error)"); rc = CM_ERR_STATE; }
+  if (d_dense) hipFree(d_dense);
+  cm_problem_destroy(p);
+  if (!rc) { key[0] = kout[0]; key[1] = kout[1]; }
   return rc;
 }
 
@@ -746,7 +980,7 @@ extern "C" int cm_k_reconnect(cm_ctx* ctx, int32_t N, int32_t K, const double* s
   std::vector<double> vm(mu, mu + N), vb(beta, beta + N), vz(z, z + K), vl(nnz ? nnz : 1);
   for (int n = 0; n < N; ++n)
     for (int e = p->h_row_ptr[n]; e < p->h_row_ptr[n + 1]; ++e) vl[e] = lam[(size_t)n * K + p->h_col[e]];
-  host_reconnect(p, vm.data(), vb.data(), vl.data(), vz.data(), minimax_spk_prob, minimum_spike_count, 0);
+  cm_host_reconnect(host_rows(p), vm.data(), vb.data(), vl.data(), vz.data(), minimax_spk_prob, minimum_spike_count, 0);
   for (int n = 0; n < N; ++n)
     for (int e = p->h_row_ptr[n]; e < p->h_row_ptr[n + 1]; ++e) lam[(size_t)n * K + p->h_col[e]] = vl[e];
   std::copy(vm.begin(), vm.end(), mu); std::copy(vb.begin(), vb.end(), beta); std::copy(vz.begin(), vz.end(), z);

@@ -37,19 +37,24 @@ __device__ __forceinline__ void cm_col_dot16(int t, int K, const double* __restr
   if (ok && j == 0) { R[k] = s; if (colany) colany[k] = (uint8_t)(any != 0); }
 }
 
-// block-wide sum (1024 threads), result valid in every thread
-__device__ __forceinline__ double block_sum(double v, double* sh) {
+// The single-workgroup phases run on the first CM_POST_THREADS threads of their workgroup, whatever its launch size (the other
+// waves have retired; a retired wave no longer counts at s_barrier): the strided partial sums and their combination order are
+// then the same in every kernel that embeds these bodies, so a batched launch reproduces the single-circuit results bit for bit.
+#define CM_POST_THREADS 256
+
+// sum over the first `nthr` threads of the workgroup, result valid in every one of them
+__device__ __forceinline__ double block_sum(double v, double* sh, int nthr) {
   v = cm_wave_sum(v);
   __syncthreads();
   if (threadIdx.x % CM_WAVE == 0) sh[threadIdx.x / CM_WAVE] = v;
   __syncthreads();
   double t = 0.0;
-  for (int w = 0; w < (int)(blockDim.x / CM_WAVE); ++w) t += sh[w];
+  for (int w = 0; w < nthr / CM_WAVE; ++w) t += sh[w];
   return t;
 }
 
 // ------------------------------------------------------------------------------------------------
-// Everything of an iteration that is a single-workgroup reduction (1024 threads):
+// Everything of an iteration that is a single-workgroup reduction (the first CM_POST_THREADS threads of the workgroup):
 //   1. ordered compaction of the active rows (lam row != 0) for the next block_update_mu, and the size of that set
 //      posted straight into host-mapped pinned memory (mailbox) so the host can size the next solve while 2-3 still run;
 //   2. update_sigma: rate = rate0 + 1/2 ( sum_k (y_k - R_k)^2 - sum_n mu_n^2 sum_k lam_nk^2 + sum_n (mu_n^2 + beta_n^2) sum_k lam_nk )
@@ -69,12 +74,13 @@ __device__ __forceinline__ int post_single_body(const double* __restrict__ y, co
   __shared__ double sh[16];
   __shared__ int wave_cnt[16];
   __shared__ int base;
+  constexpr int nthr_ = CM_POST_THREADS;
   // ---- 1. active set
   if (threadIdx.x == 0) base = 0;
   __syncthreads();
   {
     const int lane = threadIdx.x % CM_WAVE, w = threadIdx.x / CM_WAVE;
-    const int nthr = blockDim.x, nwv = blockDim.x / CM_WAVE;
+    const int nthr = nthr_, nwv = nthr_ / CM_WAVE;
     for (int n0 = 0; n0 < N; n0 += nthr) {
       const int n = n0 + threadIdx.x;
       const bool a = n < N && rs[(size_t)n * 4 + 3] >= 0.0;
@@ -113,14 +119,14 @@ __device__ __forceinline__ int post_single_body(const double* __restrict__ y, co
   if (!do_sigma) return n_active;
   // ---- 2. update_sigma
   double a = 0.0;
-  for (int k = threadIdx.x; k < K; k += blockDim.x) { const double r = y[k] - R[k]; a = fma(r, r, a); }
+  for (int k = threadIdx.x; k < K; k += nthr_) { const double r = y[k] - R[k]; a = fma(r, r, a); }
   double b = 0.0, c = 0.0;
-  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+  for (int n = threadIdx.x; n < N; n += nthr_) {
     const double m = mu[n], be = beta[n];
     b = fma(m * m, rs[(size_t)n * 4 + 1], b);
     c = fma(m * m + be * be, rs[(size_t)n * 4 + 0], c);
   }
-  a = block_sum(a, sh); b = block_sum(b, sh); c = block_sum(c, sh);
+  a = block_sum(a, sh, nthr_); b = block_sum(b, sh, nthr_); c = block_sum(c, sh, nthr_);
   if (threadIdx.x == 0) {
     scal[CM_S_SHAPE] = scal[CM_S_SHAPE_PRIOR] + (double)K / 2.0;
     scal[CM_S_RATE] = scal[CM_S_RATE_PRIOR] + 0.5 * (a - b + c);
@@ -136,7 +142,7 @@ __device__ __forceinline__ int post_single_body(const double* __restrict__ y, co
   double* rl = lds_scratch;
   uint8_t* bl = (uint8_t*)(lds_scratch + K);
   if (staged) {
-    for (int k = threadIdx.x; k < K; k += blockDim.x) { rl[k] = y[k] - R[k]; bl[k] = (uint8_t)(colany[k] || !mask[k]); }
+    for (int k = threadIdx.x; k < K; k += nthr_) { rl[k] = y[k] - R[k]; bl[k] = (uint8_t)(colany[k] || !mask[k]); }
     __syncthreads();
   }
   // z itself is only needed from the LAST pass: the passes accumulate the error norm, and z is written once afterwards with the
@@ -145,7 +151,7 @@ __device__ __forceinline__ int post_single_body(const double* __restrict__ y, co
   double last_pen = pen;
   while (itc < max_iters && err > tol) {
     double e = 0.0;
-    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    for (int k = threadIdx.x; k < K; k += nthr_) {
       const double resid = staged ? rl[k] : y[k] - R[k];
       const bool blocked = staged ? (bl[k] != 0) : (colany[k] || !mask[k]);
       double zz = resid < pen ? 0.0 : resid - pen;                       // :154
@@ -154,7 +160,7 @@ __device__ __forceinline__ int post_single_body(const double* __restrict__ y, co
       const double d = resid - zz;
       e = fma(d, d, e);                                                  // :158
     }
-    err = block_sum(e, sh) / ysq;
+    err = block_sum(e, sh, nthr_) / ysq;
     ++itc;
     last_pen = pen;
     ran = true;
@@ -162,7 +168,7 @@ __device__ __forceinline__ int post_single_body(const double* __restrict__ y, co
   }
   double cnt = 0.0;
   if (ran) {
-    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    for (int k = threadIdx.x; k < K; k += nthr_) {
       const double resid = staged ? rl[k] : y[k] - R[k];
       const bool blocked = staged ? (bl[k] != 0) : (colany[k] || !mask[k]);
       double zz = resid < last_pen ? 0.0 : resid - last_pen;
@@ -172,9 +178,9 @@ __device__ __forceinline__ int post_single_body(const double* __restrict__ y, co
       cnt += (zz != 0.0) ? 1.0 : 0.0;
     }
   } else {
-    for (int k = threadIdx.x; k < K; k += blockDim.x) cnt += (z[k] != 0.0) ? 1.0 : 0.0;   // z is frozen (caviar.py:86-87 with it >= 20)
+    for (int k = threadIdx.x; k < K; k += nthr_) cnt += (z[k] != 0.0) ? 1.0 : 0.0;   // z is frozen (caviar.py:86-87 with it >= 20)
   }
-  cnt = block_sum(cnt, sh);
+  cnt = block_sum(cnt, sh, nthr_);
   if (threadIdx.x == 0) scal[CM_S_SPONT_RATE] = cnt / (double)K;
   return n_active;
 }
@@ -343,13 +349,12 @@ __device__ __forceinline__ void phi_body(int n, int lane, const double* __restri
 //   barriers each; pivots of an SPD matrix are positive, no pivoting needed);  4. mu = A^-1 rhs, beta = diag(A^-1).
 // n == 0 only fills the priors.
 // ------------------------------------------------------------------------------------------------
-#define CM_SMALL_MAX 128
 __device__ __forceinline__ void solve_small_body(double* sm, const double* __restrict__ lam, const int* __restrict__ row_ptr,
                                                  const int* __restrict__ col, const int* __restrict__ act_idx,
                                                  const double* __restrict__ rs, const double* __restrict__ scal,
                                                  const double* __restrict__ mu_prior, const double* __restrict__ beta_prior,
                                                  int n, int N, int tot_cap, double* __restrict__ mu, double* __restrict__ beta,
-                                                 int* __restrict__ flag) {
+                                                 int* __restrict__ flag, int nthr) {
   const int ldA = n + 1;
   double* A = sm;                              // [n][n+1]
   double* rowk = A + (size_t)n * ldA;          // [CM_SMALL_MAX]
@@ -362,7 +367,7 @@ __device__ __forceinline__ void solve_small_body(double* sm, const double* __res
   __shared__ int bad;
   const int tid = threadIdx.x;
   // inactive rows: mu = mu0, beta = beta0^2 exactly (their rows of the precision matrix are diagonal)
-  for (int i = tid; i < N; i += blockDim.x) { mu[i] = mu_prior[i]; const double b0 = beta_prior[i]; beta[i] = b0 * b0; }
+  for (int i = tid; i < N; i += nthr) { mu[i] = mu_prior[i]; const double b0 = beta_prior[i]; beta[i] = b0 * b0; }
   if (tid == 0) bad = 0;
   // ---- 1. stage
   if (tid < n) { const int nn = act_idx[tid]; nidx[tid] = nn; rp[tid + 1] = row_ptr[nn + 1] - row_ptr[nn]; }
@@ -375,7 +380,7 @@ __device__ __forceinline__ void solve_small_body(double* sm, const double* __res
     if (tid < n && tid >= o) rp[tid + 1] += v;
     __syncthreads();
   }
-  const int wave = tid / CM_WAVE, lane = tid % CM_WAVE, nw = blockDim.x / CM_WAVE;
+  const int wave = tid / CM_WAVE, lane = tid % CM_WAVE, nw = nthr / CM_WAVE;
   for (int a = wave; a < n; a += nw) {
     const int g0 = row_ptr[nidx[a]], len = rp[a + 1] - rp[a], o0 = rp[a];
     for (int e = lane; e < len; e += CM_WAVE) { cols[o0 + e] = col[g0 + e]; lams[o0 + e] = lam[g0 + e]; }
@@ -384,7 +389,7 @@ __device__ __forceinline__ void solve_small_body(double* sm, const double* __res
   // ---- 2. build (lower triangle pairs, mirrored)
   const double sig = scal[CM_S_SHAPE] / scal[CM_S_RATE];
   const int npairs = n * (n + 1) / 2;
-  for (int q = tid; q < npairs; q += blockDim.x) {
+  for (int q = tid; q < npairs; q += nthr) {
     int a = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
     while ((a + 1) * (a + 2) / 2 <= q) ++a;
     while (a * (a + 1) / 2 > q) --a;
@@ -415,7 +420,7 @@ __device__ __forceinline__ void solve_small_body(double* sm, const double* __res
     if (tid == 0 && !(d > 0.0)) bad = 1;
     if (tid < n) { rowk[tid] = A[k * ldA + tid] * inv; colk[tid] = A[tid * ldA + k]; }
     __syncthreads();
-    for (int idx = tid; idx < n * n; idx += blockDim.x) {
+    for (int idx = tid; idx < n * n; idx += nthr) {
       const int i = idx / n, j = idx % n;
       double v;
       if (i == k) v = (j == k) ? inv : rowk[j];
@@ -489,6 +494,3 @@ __device__ __forceinline__ void mc_logit_body(int n, int m, int lane, double mea
 }
 
 
-static inline size_t small_lds_bytes(int n, int tot_cap) {
-  return ((size_t)n * (n + 1) + 3 * CM_SMALL_MAX + tot_cap) * sizeof(double) + ((size_t)tot_cap + 2 * CM_SMALL_MAX + 1) * sizeof(int);
-}

@@ -6,11 +6,14 @@
 #include <vector>
 
 #include "../../include/caviar_hip.h"
+#include "cm_host.h"
 
 #define CM_WAVE 64
 #define CM_TILE 32          // tile edge of the blocked SPD solve
 #define CM_EV_PER_IT 10
-#define CM_MAILBOX_WORDS 64  // int32 words of host-mapped pinned memory per context: [0..1] mailbox, [8..11] scratch
+#define CM_MAX_BATCH 1024      // circuits in one lock-step group
+#define CM_MAILBOX_BATCH0 32   // 64-bit word index of the first per-circuit mailbox of a batch
+#define CM_MAILBOX_WORDS (2 * (CM_MAILBOX_BATCH0 + CM_MAX_BATCH))  // int32 words of host-mapped pinned memory per context: [0..1] single-circuit mailbox, [8..11] scratch, then one 64-bit word per circuit of a batch
 
 void cm_set_error(const char* fmt, ...);
 
@@ -43,7 +46,10 @@ struct cm_ctx {
   int num_cus = 256;
   void* h_stage = nullptr;        // pinned staging buffer (priors upload, fn_scan round trip), grown on demand
   size_t h_stage_bytes = 0;
-  size_t lds_attr[40] = {};       // dynamic-LDS caps already raised for this context's device, by kernel slot (cm_raise_lds)
+  size_t lds_attr[48] = {};       // dynamic-LDS caps already raised for this context's device, by kernel slot (cm_raise_lds)
+  void* d_pdev = nullptr;         // descriptors of the current batch (device) and their pinned source
+  void* h_pdev = nullptr;
+  size_t pdev_cap = 0;
   std::vector<hipEvent_t> pool;   // per-iteration events (CM_EV_PER_IT per iteration): phase stamps + cross-stream edges
 };
 
@@ -128,6 +134,93 @@ enum {
   CM_S_SHAPE = 0, CM_S_RATE = 1, CM_S_SPONT_RATE = 2, CM_S_SHAPE_PRIOR = 3, CM_S_RATE_PRIOR = 4, CM_S_ERR = 5,
   CM_S_COUNT = 16
 };
+
+// ------------------------------------------------------------------------------------------------
+// Device view of one circuit: every pointer and size the per-iteration kernels need.  A kernel receives it either BY VALUE in its
+// arguments (one circuit: nothing sits between the launch and the first load, as before) or as an ARRAY in HBM indexed by
+// blockIdx.y (a lock-step batch of circuits: the circuit is the outer grid dimension of every launch).  Quantities that change
+// from iteration to iteration travel as ordinary kernel arguments and are common to all circuits of a batch.
+// ------------------------------------------------------------------------------------------------
+struct cm_pdev {
+  int N, K, V, small_cap, max_row_len, ld_alloc;
+  long long nnz;
+  const double *y, *ss, *sum_y, *vals;
+  const int *row_ptr, *col;
+  const uint8_t* grp;
+  const int *rowcnt, *col_ptr, *csc_row, *csc_pos;
+  uint8_t *mask, *colany;
+  double *lam, *mu, *beta, *phi, *phi_cov, *scal, *R, *z, *mcE, *rs;
+  const double *pslab, *mu_prior, *beta_prior, *phi_prior, *phi_cov_prior;
+  int *act_idx, *act_inv, *n_act, *seq_n, *seq_off, *seq_pos, *chunk_first, *seq_meta;
+  void* packed;
+  double *A, *X, *Lf, *Dinv, *rhs;
+  int* mailbox;                  // this circuit's 64-bit word in host-mapped pinned memory (nullptr: no mailbox)
+  // random tables: data independent, shared by all circuits of a batch (same seed, N, S -> same streams)
+  const int *orders_all, *inv_all;
+  const double *wtab, *uexp;
+  const uint32_t* keys;
+};
+
+#ifdef __HIPCC__
+template <bool BATCH> struct cm_parg;
+template <> struct cm_parg<false> {
+  cm_pdev d;
+  __device__ __forceinline__ const cm_pdev& get() const { return d; }
+};
+template <> struct cm_parg<true> {
+  const cm_pdev* __restrict__ arr;
+  __device__ __forceinline__ const cm_pdev& get() const { return arr[blockIdx.y]; }
+};
+#endif
+
+// LDS footprint of the one-workgroup solver (solve_small_body, cm_bodies.h) for n active rows with tot_cap staged entries
+#define CM_SMALL_MAX 128
+__host__ __device__ static inline size_t small_lds_bytes(int n, int tot_cap) {
+  return ((size_t)n * (n + 1) + 3 * CM_SMALL_MAX + tot_cap) * sizeof(double) + ((size_t)tot_cap + 2 * CM_SMALL_MAX + 1) * sizeof(int);
+}
+
+// Which solver handles block_update_mu for an active set of `na` rows (host and device agree by construction):
+//   0  nothing to do here: na <= skip_le, the fused mid-iteration kernel has already solved it in LDS
+//   1  the one-workgroup LDS solver (k_solve_small)
+//   2  the tiled factorisation (na == 0: only its prior fill)
+__host__ __device__ static inline int cm_solve_kind(int na, int skip_le, int max_row_len) {
+  if (na <= skip_le) return 0;
+  if (na > 0 && na <= CM_SMALL_MAX && small_lds_bytes(na, na * max_row_len) <= 150 * 1024) return 1;
+  return 2;
+}
+
+// The circuits one launch serves: a single problem, or a lock-step group with identical launch configuration.
+struct cm_set {
+  int B = 1;
+  cm_problem* lead = nullptr;            // sizes and random tables (identical over the group)
+  std::vector<cm_problem*> ps;
+  cm_pdev h0;                            // B == 1: the descriptor, passed by value
+  const cm_pdev* d_arr = nullptr;        // B > 1: descriptors in HBM
+  int small_cap_max = 0, max_row_len_max = 0, max_col_len_max = 0;
+  size_t small_lds_max = 0;              // largest LDS need of the fused in-LDS solve over the circuits of the set
+  long long nnz_max = 0, nnz_min = 0;
+  long long fact_launches = 0, fact_tile_updates = 0;   // counters of the tiled solves (cm_timings)
+  bool last_fact = false;                // the last cm_solve_launch ran a factorisation (and recorded its event pair)
+  std::vector<int> na;                   // last active-set sizes read from the mailboxes
+  int na_max = 0;
+};
+void cm_fill_pdev(const cm_problem* p, const cm_problem* rng_owner, int* mailbox, cm_pdev* d);
+int cm_set_single(cm_ctx* ctx, cm_problem* p, cm_set* s);
+bool cm_same_launch_config(const cm_problem* a, const cm_problem* b);
+
+// launch helpers: KERN is a kernel template whose FIRST template argument is BATCH; CM_LAUNCH_SET_T passes further template
+// arguments in parentheses, e.g. CM_LAUNCH_SET_T(k_iter_mid, (4, true), set, ...)
+#define CM_UNPAREN(...) __VA_ARGS__
+#define CM_LAUNCH_SET(KERN, set, gridx, block, lds, st, ...)                                                                               \
+  do {                                                                                                                                    \
+    if ((set).B == 1) hipLaunchKernelGGL((KERN<false>), dim3(gridx), dim3(block), lds, st, cm_parg<false>{(set).h0}, ##__VA_ARGS__);       \
+    else hipLaunchKernelGGL((KERN<true>), dim3(gridx, (set).B), dim3(block), lds, st, cm_parg<true>{(set).d_arr}, ##__VA_ARGS__);          \
+  } while (0)
+#define CM_LAUNCH_SET_T(KERN, TARGS, set, gridx, block, lds, st, ...)                                                                      \
+  do {                                                                                                                                    \
+    if ((set).B == 1) hipLaunchKernelGGL((KERN<false, CM_UNPAREN TARGS>), dim3(gridx), dim3(block), lds, st, cm_parg<false>{(set).h0}, ##__VA_ARGS__); \
+    else hipLaunchKernelGGL((KERN<true, CM_UNPAREN TARGS>), dim3(gridx, (set).B), dim3(block), lds, st, cm_parg<true>{(set).d_arr}, ##__VA_ARGS__);    \
+  } while (0)
 
 // ------------------------------------------------------------------------------------------------
 // device helpers
@@ -226,7 +319,8 @@ inline void cm_threefry2x32(uint32_t k0, uint32_t k1, uint32_t& x0, uint32_t& x1
 // in ONE process-wide table keyed (device, kernel) under a mutex and is only ever raised; the per-context array is a cache of
 // lower bounds of that table (valid because the table never decreases), so the common launch pays no lock and no runtime call.
 enum cm_lds_slot { CM_LDS_ITER = 0 /* 7 x 2 x 2 template variants */, CM_LDS_SOLVE_SMALL = 28, CM_LDS_SWEEP_PAR, CM_LDS_SWEEP_PAR2, CM_LDS_SWEEP_SEQ,
-                   CM_LDS_NWD, CM_LDS_SIM_SORT, CM_LDS_BUILD_PREC, CM_LDS_SLOTS = 40 };
+                   CM_LDS_NWD, CM_LDS_SIM_SORT, CM_LDS_BUILD_PREC, CM_LDS_SWEEP_PAR_B, CM_LDS_SWEEP_PAR2_B, CM_LDS_SWEEP_SEQ_B,
+                   CM_LDS_SOLVE_SMALL_B, CM_LDS_BUILD_PREC_B, CM_LDS_SLOTS = 48 };
 // table update: returns the value hipFuncSetAttribute has to be called with (0 = the value in force already covers `bytes`)
 size_t cm_lds_table_request(int device, const void* fn, size_t bytes, size_t floor_bytes);
 inline int cm_raise_lds(cm_ctx* ctx, int slot, const void* fn, size_t bytes, size_t floor_bytes) {
@@ -242,25 +336,21 @@ inline int cm_raise_lds(cm_ctx* ctx, int slot, const void* fn, size_t bytes, siz
 // ------------------------------------------------------------------------------------------------
 int cm_launch_psc_prologue(cm_ctx* ctx, int K, int T, const double* d_psc, double* d_y, double* d_ss);
 int cm_encode_stim(cm_ctx* ctx, cm_problem* p, const double* d_stim);               // syncs (sizes nnz)
-int cm_launch_init_state(cm_ctx* ctx, cm_problem* p, double y_xcorr_thresh);
+int cm_launch_init_state(cm_ctx* ctx, cm_set& s, double y_xcorr_thresh);             // state from the uploaded priors, lam0, mask, z, counters
 int cm_launch_scatter_dense_lam(cm_ctx* ctx, cm_problem* p, const double* d_lam_dense);
 int cm_launch_expand_lam(cm_ctx* ctx, cm_problem* p, const double* d_lam_sparse, double* d_dense);
 
-int cm_solve_mu(cm_ctx* ctx, cm_problem* p, int* n_active_out);                      // syncs once (active-set size)
-int cm_solve_launch(cm_ctx* ctx, cm_problem* p, int na);
+int cm_solve_mu(cm_ctx* ctx, cm_set& s, int* n_active_out);                          // syncs once (active-set size)
+int cm_solve_launch(cm_ctx* ctx, cm_set& s, int skip_mode, hipEvent_t fact_begin = nullptr, hipEvent_t fact_end = nullptr);                          // sizes from s.na; skip_mode 0: circuits the fused kernel solved are left alone, -1: solve all
 int cm_small_cap(const cm_problem* p);
-int cm_launch_iter_mid(cm_ctx* ctx, cm_problem* p, int it, int iters, int S, int rng_mode, const cm_options* o, int do_sigma, int do_phi);
+int cm_launch_iter_mid(cm_ctx* ctx, cm_set& s, int it, int iters, int S, int rng_mode, const cm_options* o, int do_sigma, int do_phi, int roles = 3);
 int cm_launch_ndtri_table(cm_ctx* ctx, cm_problem* p, int it0, int n_it, int S, int rng_mode, hipStream_t st);
-void cm_host_key_schedule_range(uint32_t key[2], int it0, int n_it, int N, uint32_t* keys);
 int cm_launch_rng(cm_ctx* ctx, cm_problem* p, int it0, int n_it, hipStream_t st);
-int cm_launch_mc_logit(cm_ctx* ctx, cm_problem* p, int it, int S, int rng_mode, hipStream_t st);
-int cm_launch_sweep(cm_ctx* ctx, cm_problem* p, int it, const cm_options* o, hipEvent_t mid);
-int cm_launch_stats(cm_ctx* ctx, cm_problem* p, double spont_orthogonality);
-int cm_launch_post_single(cm_ctx* ctx, cm_problem* p, int it, const cm_options* o, int do_sigma);
-int cm_wait_active(cm_ctx* ctx, cm_problem* p);
-int cm_launch_update_phi(cm_ctx* ctx, cm_problem* p, hipStream_t st);
-int cm_launch_col_stats(cm_ctx* ctx, cm_problem* p, double spont_orthogonality);
+int cm_launch_sweep(cm_ctx* ctx, cm_set& s, int it, const cm_options* o, hipEvent_t mid, int table_it = -1);   // table_it: iteration whose sweep order is used (default: it)
+int cm_launch_sum_y(cm_ctx* ctx, cm_set& s);
+int cm_sweep_variant(const cm_set& s, int rows_hint);
+int cm_launch_stats(cm_ctx* ctx, cm_set& s, double spont_orthogonality);
+int cm_launch_post_single(cm_ctx* ctx, cm_set& s, int it, const cm_options* o, int do_sigma);
+int cm_wait_active(cm_ctx* ctx, cm_set& s);
+int cm_launch_update_phi(cm_ctx* ctx, cm_set& s, hipStream_t st);
 
-void cm_host_key_schedule(uint64_t seed, int iters, int N, std::vector<uint32_t>& keys);
-int cm_perm_rounds(int N);
-double cm_host_pava_last(const double* y, int n);

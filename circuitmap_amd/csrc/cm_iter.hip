@@ -1,6 +1,6 @@
-// The middle of a CAVIaR iteration as ONE launch on ONE stream (256-thread workgroups, two roles):
+// The middle of a CAVIaR iteration as ONE launch on ONE stream, two roles:
 //
-//   block 0       everything that is a single-workgroup reduction, back to back:
+//   block 0       everything that is a single-workgroup reduction, back to back (on its first CM_POST_THREADS threads):
 //                 active-set compaction -> size posted to the host mailbox -> update_sigma (caviar.py:238-244) ->
 //                 soft threshold + spont_rate (:147-163, :88) -> block_update_mu of the NEXT iteration (:166-172) when the
 //                 active set fits the in-LDS solver (otherwise the host, which has the size from the mailbox, launches
@@ -10,57 +10,56 @@
 //
 // Neither role reads what the other writes (sigma/z/mu/beta vs phi/mcE), so they overlap inside the launch without
 // streams or events; the launch is as long as its longer role (~phi + MC logit).
+//
+// One circuit: 256-thread workgroups (4 waves = one per SIMD; the blocks spread one per CU: shortest latency).  A batch of circuits
+// (blockIdx.y): 1024-thread workgroups, so that the dynamic LDS block 0 needs (up to 56 KB, allocated by every workgroup of the
+// launch) still leaves the CU fully occupied by the per-neuron waves -- the batch is a throughput problem, not a latency one.
 #include <stdlib.h>
 
 #include "cm_bodies.h"
 
-#define CM_ITER_THREADS 256                     // 4 waves = one per SIMD; with <= ~50 KB of LDS the blocks spread one per CU
-#define CM_ITER_WAVES (CM_ITER_THREADS / CM_WAVE)
+#define CM_ITER_THREADS 256
+#define CM_ITER_THREADS_BATCH 1024
 
-struct IterArgs {
-  // block 0: post
-  const double* y; const double* R; const uint8_t* colany; const uint8_t* mask; const double* rs; const double* sum_y;
-  int N, K, it, max_iters; double penalty, scale_factor, tol; int do_sigma, seq;
-  int* act_idx; int* act_inv; int* n_act; int* mailbox; double* z; double* scal;
-  // block 0: next block_update_mu
-  const double* lam; const int* row_ptr; const int* col; const double* mu_prior; const double* beta_prior;
-  int small_cap, max_row_len, do_solve, stage_ok; double* mu; double* beta;
-  // blocks 1..: update_phi + next MC logit
-  const uint8_t* grp; const int* rowcnt; const double* vals; int V; const double* phi_prior; const double* phi_cov_prior;
-  double* phi; double* phi_cov; int do_phi, do_mc, S, roles;
-  const uint32_t* keys_next; const double* uexp_next; const double* wtab_next; const int* inv_next; double* mcE;
+struct IterDyn {     // what changes from iteration to iteration (common to all circuits of a batch)
+  int it, max_iters; double penalty, scale_factor, tol; int do_sigma, seq, do_solve, stage_ok, do_phi, do_mc, S, roles, nx, explicit_rng;
 };
 
-template <int SEG, bool FULLMC>
-__global__ __launch_bounds__(CM_ITER_THREADS) void k_iter_mid(IterArgs a) {
+template <bool BATCH, int SEG, bool FULLMC>
+__global__ __launch_bounds__(BATCH ? CM_ITER_THREADS_BATCH : CM_ITER_THREADS) void k_iter_mid(cm_parg<BATCH> pa, IterDyn a) {
   extern __shared__ double sm[];
+  const cm_pdev& p = pa.get();
   if (blockIdx.x == 0) {
     if (!(a.roles & 1)) return;
-    const int n = post_single_body(a.y, a.R, a.colany, a.mask, a.mu, a.beta, a.rs, a.sum_y, a.N, a.K, a.it, a.max_iters, a.penalty,
-                                   a.scale_factor, a.tol, a.do_sigma, a.seq, a.act_idx, a.act_inv, a.n_act, a.mailbox, a.z, a.scal,
+    if (threadIdx.x >= CM_POST_THREADS) return;
+    const int n = post_single_body(p.y, p.R, p.colany, p.mask, p.mu, p.beta, p.rs, p.sum_y, p.N, p.K, a.it, a.max_iters, a.penalty,
+                                   a.scale_factor, a.tol, a.do_sigma, a.seq, p.act_idx, p.act_inv, p.n_act, p.mailbox, p.z, p.scal,
                                    a.stage_ok ? sm : nullptr);
-    if (a.do_solve && n <= a.small_cap) {
+    if (a.do_solve && n <= p.small_cap) {
       __syncthreads();
-      solve_small_body(sm, a.lam, a.row_ptr, a.col, a.act_idx, a.rs, a.scal, a.mu_prior, a.beta_prior, n, a.N, n * a.max_row_len, a.mu,
-                       a.beta, a.n_act + 1);
+      solve_small_body(sm, p.lam, p.row_ptr, p.col, p.act_idx, p.rs, p.scal, p.mu_prior, p.beta_prior, n, p.N, n * p.max_row_len, p.mu,
+                       p.beta, p.n_act + 1, CM_POST_THREADS);
     }
     return;
   }
   if (!(a.roles & 2)) return;
   const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE;
-  const int n = ((int)blockIdx.x - 1) * CM_ITER_WAVES + wave;
-  if (n >= a.N) return;
+  const int n = ((int)blockIdx.x - 1) * (int)(blockDim.x / CM_WAVE) + wave;
+  const int N = p.N;
+  if (n >= N) return;
   double pc[4];
   if (a.do_phi) {
-    phi_body<SEG>(n, lane, a.lam, a.row_ptr, a.grp, a.rowcnt, a.vals, a.V, a.phi_prior, a.phi_cov_prior, a.phi, a.phi_cov, pc);
+    phi_body<SEG>(n, lane, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, pc);
   } else {
-    pc[0] = a.phi[2 * n]; pc[1] = a.phi[2 * n + 1]; pc[2] = a.phi_cov[4 * n]; pc[3] = a.phi_cov[4 * n + 3];
+    pc[0] = p.phi[2 * n]; pc[1] = p.phi[2 * n + 1]; pc[2] = p.phi_cov[4 * n]; pc[3] = p.phi_cov[4 * n + 3];
   }
   if (a.do_mc) {
-    const int m = a.inv_next[n];
-    const size_t off = (size_t)m * 2 * a.S;
-    mc_logit_body<FULLMC>(n, m, lane, pc[0], pc[1], pc[2], pc[3], a.keys_next, a.uexp_next ? a.uexp_next + off : nullptr, a.wtab_next + off,
-                  a.vals, a.V, a.S, sm + (size_t)wave * 2 * a.S, a.mcE);
+    // random tables of iteration nx (the next one)
+    const int m = p.inv_all[(size_t)a.nx * N + n];
+    const size_t off = ((size_t)a.nx * N + m) * 2 * a.S;
+    const uint32_t* keys_next = a.explicit_rng ? nullptr : p.keys + (size_t)a.nx * (N + 3) * 2;
+    mc_logit_body<FULLMC>(n, m, lane, pc[0], pc[1], pc[2], pc[3], keys_next, a.explicit_rng ? p.uexp + off : nullptr, p.wtab + off,
+                          p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE);
   }
 }
 
@@ -73,54 +72,51 @@ int cm_small_cap(const cm_problem* p) {
 }
 
 template <int SEG, bool FULLMC>
-static int launch_iter2(cm_ctx* ctx, const IterArgs& a, size_t lds, int blocks) {
-  const int slot = CM_LDS_ITER + 2 * (31 - __builtin_clz((unsigned)SEG)) + (FULLMC ? 1 : 0);          // SEG = 1, 2, 4 .. 64
-  CM_TRY(cm_raise_lds(ctx, slot, reinterpret_cast<const void*>(k_iter_mid<SEG, FULLMC>), lds, 48 * 1024));
-  hipLaunchKernelGGL((k_iter_mid<SEG, FULLMC>), dim3(blocks), dim3(CM_ITER_THREADS), lds, ctx->stream, a);
+static int launch_iter2(cm_ctx* ctx, cm_set& s, const IterDyn& a, size_t lds, int blocks) {
+  const int slot = CM_LDS_ITER + 4 * (31 - __builtin_clz((unsigned)SEG)) + (FULLMC ? 1 : 0) + (s.B > 1 ? 2 : 0);          // SEG = 1, 2, 4 .. 64
+  if (s.B == 1) CM_TRY(cm_raise_lds(ctx, slot, reinterpret_cast<const void*>(k_iter_mid<false, SEG, FULLMC>), lds, 48 * 1024));
+  else CM_TRY(cm_raise_lds(ctx, slot, reinterpret_cast<const void*>(k_iter_mid<true, SEG, FULLMC>), lds, 48 * 1024));
+  CM_LAUNCH_SET_T(k_iter_mid, (SEG, FULLMC), s, blocks, (s.B == 1 ? CM_ITER_THREADS : CM_ITER_THREADS_BATCH), lds, ctx->stream, a);
   CM_HIP(hipGetLastError());
   return CM_OK;
 }
 template <int SEG>
-static int launch_iter(cm_ctx* ctx, const IterArgs& a, size_t lds, int blocks) {
-  return a.it < 0 ? launch_iter2<SEG, true>(ctx, a, lds, blocks) : launch_iter2<SEG, false>(ctx, a, lds, blocks);
+static int launch_iter(cm_ctx* ctx, cm_set& s, const IterDyn& a, size_t lds, int blocks) {
+  return a.it < 0 ? launch_iter2<SEG, true>(ctx, s, a, lds, blocks) : launch_iter2<SEG, false>(ctx, s, a, lds, blocks);
 }
 
 // it = -1: state init (no sigma / phi; MC logit and solve for iteration 0).  Otherwise the middle of iteration `it`.
-int cm_launch_iter_mid(cm_ctx* ctx, cm_problem* p, int it, int iters, int S, int rng_mode, const cm_options* o, int do_sigma, int do_phi) {
-  IterArgs a;
+// roles: 1 = the single-workgroup role, 2 = the per-neuron role, 3 = both.
+int cm_launch_iter_mid(cm_ctx* ctx, cm_set& s, int it, int iters, int S, int rng_mode, const cm_options* o, int do_sigma, int do_phi, int roles) {
+  IterDyn a;
+  const cm_problem* p = s.lead;
   const int N = p->N, nxt = it + 1;
-  a.y = p->y; a.R = p->R; a.colany = p->colany; a.mask = p->mask; a.rs = p->rs; a.sum_y = p->sum_y;
-  a.N = N; a.K = p->K; a.it = it; a.max_iters = o->max_backtrack_iters; a.penalty = o->penalty; a.scale_factor = o->scale_factor;
+  a.it = it; a.max_iters = o->max_backtrack_iters; a.penalty = o->penalty; a.scale_factor = o->scale_factor;
   a.tol = o->tol; a.do_sigma = do_sigma; a.seq = ++ctx->mail_seq;
-  a.act_idx = p->act_idx; a.act_inv = p->act_inv; a.n_act = p->n_act; a.mailbox = ctx->d_mailbox; a.z = p->z; a.scal = p->scal;
-  a.lam = p->lam; a.row_ptr = p->row_ptr; a.col = p->col; a.mu_prior = p->mu_prior; a.beta_prior = p->beta_prior;
-  a.small_cap = p->small_cap; a.max_row_len = p->max_row_len; a.do_solve = nxt < iters; a.mu = p->mu; a.beta = p->beta;
-  a.grp = p->grp; a.rowcnt = p->rowcnt; a.vals = p->vals; a.V = p->V; a.phi_prior = p->phi_prior; a.phi_cov_prior = p->phi_cov_prior;
-  a.phi = p->phi; a.phi_cov = p->phi_cov; a.do_phi = do_phi; a.do_mc = nxt < iters; a.S = S;
-  const int nx = a.do_mc ? nxt : 0;
-  a.keys_next = (rng_mode == CM_RNG_EXPLICIT) ? nullptr : p->keys + (size_t)nx * (N + 3) * 2;
-  a.uexp_next = (rng_mode == CM_RNG_EXPLICIT) ? p->uexp + (size_t)nx * N * 2 * S : nullptr;
-  a.wtab_next = p->wtab + (size_t)nx * N * 2 * S;
-  a.inv_next = p->inv_all + (size_t)nx * N;
-  a.mcE = p->mcE;
-  size_t lds = (size_t)CM_ITER_WAVES * 2 * S * sizeof(double);
-  if (p->small_cap > 0) lds = std::max(lds, small_lds_bytes(p->small_cap, p->small_cap * p->max_row_len));
+  a.do_solve = nxt < iters;
+  a.do_phi = do_phi; a.do_mc = nxt < iters; a.S = S;
+  a.nx = a.do_mc ? nxt : 0;
+  a.explicit_rng = rng_mode == CM_RNG_EXPLICIT;
+  const int threads = s.B == 1 ? CM_ITER_THREADS : CM_ITER_THREADS_BATCH;
+  const int waves = threads / CM_WAVE;
+  size_t lds = (size_t)waves * 2 * S * sizeof(double);
+  lds = std::max(lds, s.small_lds_max);
   a.stage_ok = 0;
   if ((size_t)p->K * 9 + 16 <= 56 * 1024) { lds = std::max(lds, (size_t)p->K * 9 + 16); a.stage_ok = 1; }   // residual + flag per trial
-  const int blocks = 1 + ((do_phi || a.do_mc) ? (N + CM_ITER_WAVES - 1) / CM_ITER_WAVES : 0);
+  const int blocks = 1 + ((do_phi || a.do_mc) ? (N + waves - 1) / waves : 0);
   const int V = p->V;
   static const bool split = getenv("CAVIAR_HIP_SPLIT_ITER") != nullptr;         // diagnostic: one launch per role (profiling only)
-  a.roles = 3;
-  if (split && it >= 0) {
+  a.roles = roles;
+  if (split && it >= 0 && roles == 3) {
     a.roles = 2;
-    if (V <= 4) { CM_TRY(launch_iter<4>(ctx, a, lds, blocks)); } else { CM_TRY(launch_iter<64>(ctx, a, lds, blocks)); }
+    if (V <= 4) { CM_TRY(launch_iter<4>(ctx, s, a, lds, blocks)); } else { CM_TRY(launch_iter<64>(ctx, s, a, lds, blocks)); }
     a.roles = 1;
   }
-  if (V <= 1) return launch_iter<1>(ctx, a, lds, blocks);
-  if (V <= 2) return launch_iter<2>(ctx, a, lds, blocks);
-  if (V <= 4) return launch_iter<4>(ctx, a, lds, blocks);
-  if (V <= 8) return launch_iter<8>(ctx, a, lds, blocks);
-  if (V <= 16) return launch_iter<16>(ctx, a, lds, blocks);
-  if (V <= 32) return launch_iter<32>(ctx, a, lds, blocks);
-  return launch_iter<64>(ctx, a, lds, blocks);
+  if (V <= 1) return launch_iter<1>(ctx, s, a, lds, blocks);
+  if (V <= 2) return launch_iter<2>(ctx, s, a, lds, blocks);
+  if (V <= 4) return launch_iter<4>(ctx, s, a, lds, blocks);
+  if (V <= 8) return launch_iter<8>(ctx, s, a, lds, blocks);
+  if (V <= 16) return launch_iter<16>(ctx, s, a, lds, blocks);
+  if (V <= 32) return launch_iter<32>(ctx, s, a, lds, blocks);
+  return launch_iter<64>(ctx, s, a, lds, blocks);
 }

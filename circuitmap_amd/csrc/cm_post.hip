@@ -2,6 +2,8 @@
 //   update_sigma                      reference circuitmap/optimise/caviar.py:238-244
 //   update_phi / _laplace_approx      caviar.py:246-316
 //   estimate_spont_act_soft_thresh    caviar.py:147-163  (+ spont_rate, caviar.py:88)
+#include <algorithm>
+
 #include "cm_bodies.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -10,14 +12,17 @@
 //   blocks [nbR, ..): 16 lanes per trial -> R_k = sum_n mu_n lam_nk (= lam.T @ mu),
 //                     colany_k = any_n lam_nk >= spont_orthogonality
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_stats(const double* __restrict__ lam, const int* __restrict__ row_ptr, const int* __restrict__ col,
-                                                const double* __restrict__ y, const double* __restrict__ mu, const int* __restrict__ col_ptr,
-                                                const int* __restrict__ csc_row, const int* __restrict__ csc_pos, int N, int K, int nbR,
-                                                double orth, double* __restrict__ rs, double* __restrict__ R, uint8_t* __restrict__ colany) {
+template <bool BATCH>
+__global__ __launch_bounds__(256) void k_stats(cm_parg<BATCH> pa, int nbR, double orth) {
+  const cm_pdev& p = pa.get();
+  const double* __restrict__ lam = p.lam;
   if ((int)blockIdx.x < nbR) {
     const int n = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE;
     const int lane = threadIdx.x % CM_WAVE;
-    if (n >= N) return;
+    if (n >= p.N) return;
+    const int* __restrict__ row_ptr = p.row_ptr;
+    const int* __restrict__ col = p.col;
+    const double* __restrict__ y = p.y;
     double s1 = 0.0, s2 = 0.0, sy = 0.0, d = 0.0;
     int any = 0;
     for (int e = row_ptr[n] + lane; e < row_ptr[n + 1]; e += CM_WAVE) {
@@ -31,109 +36,108 @@ __global__ __launch_bounds__(256) void k_stats(const double* __restrict__ lam, c
     s1 = cm_wave_sum(s1); s2 = cm_wave_sum(s2); sy = cm_wave_sum(sy); d = cm_wave_sum(d);
     any = __any(any);
     if (lane == 0) {
+      double* __restrict__ rs = p.rs;
       rs[(size_t)n * 4 + 0] = s1;
       rs[(size_t)n * 4 + 1] = s2;
       rs[(size_t)n * 4 + 2] = sy;
       rs[(size_t)n * 4 + 3] = any ? d : -1.0;   // sum lam(1-lam) for active rows, -1 marks an all-zero row
     }
   } else {
-    cm_col_dot16(((int)blockIdx.x - nbR) * blockDim.x + threadIdx.x, K, mu, lam, col_ptr, csc_row, csc_pos, orth, R, colany);
+    cm_col_dot16(((int)blockIdx.x - nbR) * blockDim.x + threadIdx.x, p.K, p.mu, lam, p.col_ptr, p.csc_row, p.csc_pos, orth, p.R, p.colany);
   }
 }
 
-__global__ __launch_bounds__(1024) void k_post_single(const double* __restrict__ y, const double* __restrict__ R,
-                                                       const uint8_t* __restrict__ colany, const uint8_t* __restrict__ mask,
-                                                       const double* __restrict__ mu, const double* __restrict__ beta,
-                                                       const double* __restrict__ rs, const double* __restrict__ sum_y, int N, int K,
-                                                       int it, int max_iters, double penalty, double scale_factor, double tol,
-                                                       int do_sigma, int seq, int* __restrict__ act_idx, int* __restrict__ act_inv,
-                                                       int* __restrict__ n_act, int* mailbox, double* __restrict__ z,
-                                                       double* __restrict__ scal) {
-  post_single_body(y, R, colany, mask, mu, beta, rs, sum_y, N, K, it, max_iters, penalty, scale_factor, tol, do_sigma, seq, act_idx,
-                   act_inv, n_act, mailbox, z, scal);
+// stand-alone single-workgroup phases (per-phase test hooks): 256 threads like block 0 of the fused kernel -> the same sums, bit for bit
+__global__ __launch_bounds__(CM_POST_THREADS) void k_post_single(cm_parg<false> pa, int it, int max_iters, double penalty, double scale_factor,
+                                                                  double tol, int do_sigma, int seq) {
+  const cm_pdev& p = pa.get();
+  post_single_body(p.y, p.R, p.colany, p.mask, p.mu, p.beta, p.rs, p.sum_y, p.N, p.K, it, max_iters, penalty, scale_factor, tol, do_sigma, seq,
+                   p.act_idx, p.act_inv, p.n_act, p.mailbox, p.z, p.scal);
 }
 
-// Row + column statistics of the current lam.  The caller follows with cm_launch_post_single().
-int cm_launch_stats(cm_ctx* ctx, cm_problem* p, double spont_orthogonality) {
+// Row + column statistics of the current lam.
+int cm_launch_stats(cm_ctx* ctx, cm_set& s, double spont_orthogonality) {
+  const cm_problem* p = s.lead;
   const int nbR = (p->N + 3) / 4, nbC = (p->K * 16 + 255) / 256;     // one wave per row; 16 lanes per trial column
-  hipLaunchKernelGGL(k_stats, dim3(nbR + nbC), dim3(256), 0, ctx->stream, p->lam, p->row_ptr, p->col, p->y, p->mu, p->col_ptr, p->csc_row,
-                     p->csc_pos, p->N, p->K, nbR, spont_orthogonality, p->rs, p->R, p->colany);
+  CM_LAUNCH_SET(k_stats, s, nbR + nbC, 256, 0, ctx->stream, nbR, spont_orthogonality);
   CM_HIP(hipGetLastError());
   return CM_OK;
 }
 
-// Compaction (+ mailbox post) and, if do_sigma, update_sigma / z / spont_rate.  `it` < 0 means "state init".
-int cm_launch_post_single(cm_ctx* ctx, cm_problem* p, int it, const cm_options* o, int do_sigma) {
+// Compaction (+ mailbox post) and, if do_sigma, update_sigma / z / spont_rate.  `it` < 0 means "state init".  Single circuit only.
+int cm_launch_post_single(cm_ctx* ctx, cm_set& s, int it, const cm_options* o, int do_sigma) {
   hipStream_t st = ctx->stream;
   const int seq = ++ctx->mail_seq;
-  hipLaunchKernelGGL(k_post_single, dim3(1), dim3(1024), 0, st, p->y, p->R, p->colany, p->mask, p->mu, p->beta, p->rs, p->sum_y, p->N, p->K,
-                     it, o ? o->max_backtrack_iters : 0, o ? o->penalty : 0.0, o ? o->scale_factor : 0.0, o ? o->tol : 0.0, do_sigma, seq,
-                     p->act_idx, p->act_inv, p->n_act, ctx->use_mailbox ? ctx->d_mailbox : (int*)nullptr, p->z, p->scal);
+  hipLaunchKernelGGL(k_post_single, dim3(1), dim3(CM_POST_THREADS), 0, st, cm_parg<false>{s.h0}, it, o ? o->max_backtrack_iters : 0,
+                     o ? o->penalty : 0.0, o ? o->scale_factor : 0.0, o ? o->tol : 0.0, do_sigma, seq);
   CM_HIP(hipGetLastError());
   if (!ctx->use_mailbox) {
-    CM_HIP(hipMemcpyAsync(ctx->h_pinned + 8, p->n_act, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+    CM_HIP(hipMemcpyAsync(ctx->h_pinned + 8, s.lead->n_act, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
     CM_HIP(hipEventRecord(ctx->ev[7], st));
   }
   return CM_OK;
 }
 
-// Host side of the mailbox: wait until the kernel launched by the last post has published the active-set size; the decoded
-// values land in ctx->mb_n / ctx->mb_flag.
-int cm_wait_active(cm_ctx* ctx, cm_problem* p) {
-  (void)p;
-  if (!ctx->use_mailbox) {
+// Host side of the mailboxes: wait until the kernel launched by the last post has published the active-set size of every circuit
+// of the set; the decoded values land in s.na / s.na_max (and ctx->mb_n / ctx->mb_flag: largest size, OR of the not-SPD flags).
+int cm_wait_active(cm_ctx* ctx, cm_set& s) {
+  s.na.resize(s.B);
+  if (!ctx->use_mailbox) {                             // single circuit only (cm_set_single refuses batches without mailbox)
     CM_HIP(hipEventSynchronize(ctx->ev[7]));
     ctx->mb_n = ctx->h_pinned[8]; ctx->mb_flag = ctx->h_pinned[9];
+    s.na[0] = s.na_max = ctx->mb_n;
     return CM_OK;
   }
-  volatile unsigned long long* mb = (volatile unsigned long long*)ctx->h_pinned;
   const unsigned seq = (unsigned)ctx->mail_seq;
-  unsigned long long spins = 0, w;
-  while ((unsigned)((w = __atomic_load_n(mb, __ATOMIC_ACQUIRE)) >> 32) != seq) {
-    if ((++spins & 0xFFFFull) == 0) {                      // every 64k polls make sure the stream is still alive
-      hipError_t q = hipStreamQuery(ctx->stream);
-      if (q != hipErrorNotReady && q != hipSuccess) { cm_set_error("stream failed while waiting for the active set: %s", hipGetErrorString(q)); return CM_ERR_HIP; }
-      if (q == hipSuccess && (unsigned)(__atomic_load_n(mb, __ATOMIC_ACQUIRE) >> 32) != seq) {
-        cm_set_error("active-set mailbox was not posted (seq %u)", seq);
-        return CM_ERR_STATE;
+  int nmax = 0, flag = 0;
+  for (int c = 0; c < s.B; ++c) {
+    volatile unsigned long long* mb = (volatile unsigned long long*)ctx->h_pinned + (s.B == 1 ? 0 : CM_MAILBOX_BATCH0 + c);
+    unsigned long long spins = 0, w;
+    while ((unsigned)((w = __atomic_load_n(mb, __ATOMIC_ACQUIRE)) >> 32) != seq) {
+      if ((++spins & 0xFFFFull) == 0) {                      // every 64k polls make sure the stream is still alive
+        hipError_t q = hipStreamQuery(ctx->stream);
+        if (q != hipErrorNotReady && q != hipSuccess) { cm_set_error("stream failed while waiting for the active set: %s", hipGetErrorString(q)); return CM_ERR_HIP; }
+        if (q == hipSuccess && (unsigned)(__atomic_load_n(mb, __ATOMIC_ACQUIRE) >> 32) != seq) {
+          cm_set_error("active-set mailbox of circuit %d was not posted (seq %u)", c, seq);
+          return CM_ERR_STATE;
+        }
       }
     }
+    s.na[c] = (int)(w & 0x7FFFFFFFull);
+    nmax = std::max(nmax, s.na[c]);
+    flag |= (int)((w >> 31) & 1ull);
   }
-  ctx->mb_n = (int)(w & 0x7FFFFFFFull);
-  ctx->mb_flag = (int)((w >> 31) & 1ull);
+  s.na_max = nmax;
+  ctx->mb_n = nmax;
+  ctx->mb_flag = flag;
   return CM_OK;
 }
 
 // update_phi stand-alone (final update after the false-negative scan, and the per-phase test hook): one wave per neuron
-template <int SEG>
-__global__ __launch_bounds__(256) void k_update_phi(const double* __restrict__ lam, const int* __restrict__ row_ptr,
-                                                     const uint8_t* __restrict__ grp, const int* __restrict__ rowcnt,
-                                                     const double* __restrict__ vals, int V, int N,
-                                                     const double* __restrict__ phi_prior, const double* __restrict__ phi_cov_prior,
-                                                     double* __restrict__ phi, double* __restrict__ phi_cov) {
+template <bool BATCH, int SEG>
+__global__ __launch_bounds__(256) void k_update_phi(cm_parg<BATCH> pa) {
+  const cm_pdev& p = pa.get();
   const int n = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE;
-  if (n >= N) return;
+  if (n >= p.N) return;
   double out[4];
-  phi_body<SEG>(n, threadIdx.x % CM_WAVE, lam, row_ptr, grp, rowcnt, vals, V, phi_prior, phi_cov_prior, phi, phi_cov, out);
+  phi_body<SEG>(n, threadIdx.x % CM_WAVE, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, out);
 }
 
 template <int SEG>
-static void launch_phi(cm_problem* p, hipStream_t st) {
-  hipLaunchKernelGGL(k_update_phi<SEG>, dim3((unsigned)((p->N + 3) / 4)), dim3(256), 0, st, p->lam, p->row_ptr, p->grp,
-                     p->rowcnt, p->vals, p->V, p->N, p->phi_prior, p->phi_cov_prior, p->phi, p->phi_cov);
+static void launch_phi(cm_set& s, hipStream_t st) {
+  CM_LAUNCH_SET_T(k_update_phi, (SEG), s, (unsigned)((s.lead->N + 3) / 4), 256, 0, st);
 }
 
-int cm_launch_update_phi(cm_ctx* ctx, cm_problem* p, hipStream_t st) {
+int cm_launch_update_phi(cm_ctx* ctx, cm_set& s, hipStream_t st) {
   (void)ctx;
-  const int V = p->V;
-  if (V <= 1) launch_phi<1>(p, st);
-  else if (V <= 2) launch_phi<2>(p, st);
-  else if (V <= 4) launch_phi<4>(p, st);
-  else if (V <= 8) launch_phi<8>(p, st);
-  else if (V <= 16) launch_phi<16>(p, st);
-  else if (V <= 32) launch_phi<32>(p, st);
-  else launch_phi<64>(p, st);
+  const int V = s.lead->V;                                  // the group shares the lane-segment class of V
+  if (V <= 1) launch_phi<1>(s, st);
+  else if (V <= 2) launch_phi<2>(s, st);
+  else if (V <= 4) launch_phi<4>(s, st);
+  else if (V <= 8) launch_phi<8>(s, st);
+  else if (V <= 16) launch_phi<16>(s, st);
+  else if (V <= 32) launch_phi<32>(s, st);
+  else launch_phi<64>(s, st);
   CM_HIP(hipGetLastError());
   return CM_OK;
 }
-

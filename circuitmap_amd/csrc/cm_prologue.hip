@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void k_psc_prologue(const double* __restrict__
   if (lane == 0) { y[wave] = tz; ss[wave] = sq; }
 }
 
-__global__ __launch_bounds__(1024) void k_sum_y(const double* __restrict__ y, int K, double* __restrict__ out) {
+__device__ __forceinline__ void sum_y_body(const double* __restrict__ y, int K, double* __restrict__ out) {
   __shared__ double s0[16], s1[16];
   double a = 0.0, b = 0.0;
   for (int k = threadIdx.x; k < K; k += blockDim.x) { a += y[k]; b = fma(y[k], y[k], b); }
@@ -291,25 +291,42 @@ int cm_encode_stim(cm_ctx* ctx, cm_problem* p, const double* d_stim) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// state init: lam_mask = ss > thresh; lam0 = 0.95 * [I > 0] * mask (caviar.py:30-34); z = 0 (caviar.py:50)
+// state init, one launch for everything that is elementwise: lam_mask = ss > thresh; lam0 = 0.95 * [I > 0] * mask
+// (caviar.py:30-34); z = 0 (caviar.py:50); mu, beta, phi, phi_cov from the uploaded priors (caviar.py:44-49); counters zeroed.
+// sum(y), sum(y^2) keep their own single-workgroup launch (fixed summation order).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_init_mask(const double* __restrict__ ss, int K, double thresh, uint8_t* __restrict__ mask,
-                                                    double* __restrict__ z) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < K) { mask[k] = ss[k] > thresh; z[k] = 0.0; }
+template <bool BATCH>
+__global__ __launch_bounds__(256) void k_init_state(cm_parg<BATCH> pa, double thresh) {
+  const cm_pdev& p = pa.get();
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int N = p.N, K = p.K;
+  if (i < K) { p.mask[i] = p.ss[i] > thresh; p.z[i] = 0.0; }
+  if (i < p.nnz) p.lam[i] = 0.95 * (double)(p.ss[p.col[i]] > thresh);
+  const double* __restrict__ pslab = p.pslab;              // mu_prior | beta_prior | phi_prior | phi_cov_prior | scalars
+  if (i < N) { p.mu[i] = pslab[i]; p.beta[i] = pslab[N + i]; }
+  if (i < 2 * (long long)N) p.phi[i] = pslab[2 * (size_t)N + i];
+  if (i < 4 * (long long)N) p.phi_cov[i] = pslab[4 * (size_t)N + i];
+  if (i < 4) p.n_act[i] = 0;
+  if (i < 8) p.seq_meta[i] = 0;
 }
-__global__ __launch_bounds__(256) void k_init_lam(const int* __restrict__ col, const uint8_t* __restrict__ mask, long long nnz,
-                                                   double* __restrict__ lam) {
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < nnz) lam[e] = 0.95 * (double)mask[col[e]];
+template <bool BATCH>
+__global__ __launch_bounds__(1024) void k_sum_y_set(cm_parg<BATCH> pa) {
+  const cm_pdev& p = pa.get();
+  sum_y_body(p.y, p.K, const_cast<double*>(p.sum_y));
 }
 
-int cm_launch_init_state(cm_ctx* ctx, cm_problem* p, double y_xcorr_thresh) {
+int cm_launch_sum_y(cm_ctx* ctx, cm_set& s) {
+  CM_LAUNCH_SET(k_sum_y_set, s, 1, 1024, 0, ctx->stream);
+  CM_HIP(hipGetLastError());
+  return CM_OK;
+}
+
+int cm_launch_init_state(cm_ctx* ctx, cm_set& s, double y_xcorr_thresh) {
   hipStream_t st = ctx->stream;
-  hipLaunchKernelGGL(k_init_mask, dim3((p->K + 255) / 256), dim3(256), 0, st, p->ss, p->K, y_xcorr_thresh, p->mask, p->z);
-  if (p->nnz > 0)
-    hipLaunchKernelGGL(k_init_lam, dim3((unsigned)((p->nnz + 255) / 256)), dim3(256), 0, st, p->col, p->mask, (long long)p->nnz, p->lam);
-  hipLaunchKernelGGL(k_sum_y, dim3(1), dim3(1024), 0, st, p->y, p->K, p->sum_y);
+  const cm_problem* p = s.lead;
+  const long long n = std::max<long long>(std::max<long long>(4LL * p->N, p->K), std::max<long long>(s.nnz_max, 8));
+  CM_LAUNCH_SET(k_init_state, s, (unsigned)((n + 255) / 256), 256, 0, st, y_xcorr_thresh);
+  CM_LAUNCH_SET(k_sum_y_set, s, 1, 1024, 0, st);
   CM_HIP(hipGetLastError());
   return CM_OK;
 }

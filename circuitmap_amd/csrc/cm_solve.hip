@@ -12,19 +12,44 @@
 #include "cm_bodies.h"
 
 #define TS CM_TILE
+
+// Every kernel of the tiled solve serves one circuit (descriptor by value, active-set size `na_arg` known to the host) or a lock-step
+// batch (blockIdx.y = circuit): then each circuit reads its own active-set size from HBM, derives its own tile count and leading
+// dimension, and leaves at once if the tiled solve is not the solver of that size (cm_solve_kind) or if the block lies outside
+// its (smaller) matrix -- the grid is sized for the largest matrix of the batch.
+#define CM_SOLVE_PROLOGUE(KIND)                                                   \
+  const cm_pdev& p = pa.get();                                                    \
+  const int na = BATCH ? p.n_act[0] : na_arg;                                     \
+  if (BATCH && cm_solve_kind(na, skip_own ? p.small_cap : -1, p.max_row_len) != (KIND)) return;       \
+  const int nblk = (na + TS - 1) / TS, ld = nblk * TS;                            \
+  (void)nblk; (void)ld;
+#define CM_LARGE_TILES 48     // more tile rows than this: panel solve + lean trailing-update kernels (bandwidth-bound regime)
+
 #define CM_LINV_THREADS 1024  // threads that run the diagonal-tile elimination (256 was measured slower: 4 elements per thread)
 #define TP (CM_TILE + 1)   // padded LDS row (doubles)
 
 // ------------------------------------------------------------------------------------------------
 // precision matrix over the active set; one wave per (padded) row, accumulator row in LDS
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_build_precision(const double* __restrict__ lam, const int* __restrict__ row_ptr,
-                                                         const int* __restrict__ col, const int* __restrict__ col_ptr,
-                                                         const int* __restrict__ csc_row, const int* __restrict__ csc_pos,
-                                                         const int* __restrict__ act_idx, const int* __restrict__ act_inv,
-                                                         const double* __restrict__ rs, const double* __restrict__ scal,
-                                                         const double* __restrict__ mu_prior, const double* __restrict__ beta_prior,
-                                                         int n_act, int ld, double* __restrict__ A, double* __restrict__ rhs) {
+template <bool BATCH>
+__global__ __launch_bounds__(64) void k_build_precision(cm_parg<BATCH> pa, int na_arg, int skip_own) {
+  CM_SOLVE_PROLOGUE(2)
+  const int n_act = na;
+  if ((int)blockIdx.x >= ld) return;
+  const double* __restrict__ lam = p.lam;
+  const int* __restrict__ row_ptr = p.row_ptr;
+  const int* __restrict__ col = p.col;
+  const int* __restrict__ col_ptr = p.col_ptr;
+  const int* __restrict__ csc_row = p.csc_row;
+  const int* __restrict__ csc_pos = p.csc_pos;
+  const int* __restrict__ act_idx = p.act_idx;
+  const int* __restrict__ act_inv = p.act_inv;
+  const double* __restrict__ rs = p.rs;
+  const double* __restrict__ scal = p.scal;
+  const double* __restrict__ mu_prior = p.mu_prior;
+  const double* __restrict__ beta_prior = p.beta_prior;
+  double* __restrict__ A = p.A;
+  double* __restrict__ rhs = p.rhs;
   extern __shared__ double acc[];   // [ld]
   const int a = blockIdx.x;
   const int lane = threadIdx.x;
@@ -280,7 +305,13 @@ __device__ __forceinline__ void tile_linv_reg2(const double (*C)[TP], double (*L
 }
 
 // factor the first diagonal tile
-__global__ __launch_bounds__(256) void k_chol_first(double* __restrict__ A, int ld, double* __restrict__ Dinv, int* __restrict__ flag) {
+template <bool BATCH>
+__global__ __launch_bounds__(256) void k_chol_first(cm_parg<BATCH> pa, int na_arg, int skip_own) {
+  CM_SOLVE_PROLOGUE(2)
+  if (na == 0) return;
+  double* __restrict__ A = p.A;
+  double* __restrict__ Dinv = p.Dinv;
+  int* __restrict__ flag = p.n_act + 1;
   __shared__ double C[TS][TP], Li[TS][TP];
   tile_load(C, A, ld);
   __syncthreads();
@@ -289,8 +320,13 @@ __global__ __launch_bounds__(256) void k_chol_first(double* __restrict__ A, int 
 }
 
 // panel solve for large matrices: Lf[i][j] = A[i][j] * L_jj^-T for i > j   (one 256-thread workgroup per tile row)
-__global__ __launch_bounds__(256) void k_chol_trsm(const double* __restrict__ A, double* __restrict__ Lf, int ld,
-                                                    const double* __restrict__ Dinv, int j) {
+template <bool BATCH>
+__global__ __launch_bounds__(256) void k_chol_trsm(cm_parg<BATCH> pa, int na_arg, int skip_own, int j) {
+  CM_SOLVE_PROLOGUE(2)
+  if (nblk <= CM_LARGE_TILES || j + 1 + (int)blockIdx.x >= nblk) return;
+  const double* __restrict__ A = p.A;
+  double* __restrict__ Lf = p.Lf;
+  const double* __restrict__ Dinv = p.Dinv;
   __shared__ double P[TS][TP], Li[TS][TP];
   const int i = j + 1 + blockIdx.x;
   tile_load(P, A + (size_t)i * TS * ld + (size_t)j * TS, ld);
@@ -308,8 +344,17 @@ __global__ __launch_bounds__(256) void k_chol_trsm(const double* __restrict__ A,
 // whole trailing matrix -- so it gets its own lean kernel: 256-thread workgroups, two LDS tiles (the solved panel tiles X_i,
 // X_l from Lf), one 16x16 output block per wave on the matrix cores, output tile prefetched into registers.  Many workgroups
 // per CU keep enough bytes in flight; block 0 owns the diagonal tile (j+1, j+1) and factors it in place.
-__global__ __launch_bounds__(256) void k_chol_bulk(double* __restrict__ A, const double* __restrict__ Lf, int ld, int j,
-                                                   double* __restrict__ Dinv, int* __restrict__ flag) {
+template <bool BATCH>
+__global__ __launch_bounds__(256) void k_chol_bulk(cm_parg<BATCH> pa, int na_arg, int skip_own, int j) {
+  CM_SOLVE_PROLOGUE(2)
+  {
+    const int tr = nblk - j - 1;
+    if (nblk <= CM_LARGE_TILES || tr <= 0 || (int)blockIdx.x >= tr * (tr + 1) / 2) return;
+  }
+  double* __restrict__ A = p.A;
+  const double* __restrict__ Lf = p.Lf;
+  double* __restrict__ Dinv = p.Dinv;
+  int* __restrict__ flag = p.n_act + 1;
   __shared__ double Sm[3][TS][TP];
   double (*Xi)[TP] = Sm[0], (*Xl)[TP] = Sm[1];
   // linear block id -> (i, l), 0 <= l' <= i' in the trailing tile rows; id 0 is the diagonal tile (j+1, j+1)
@@ -351,9 +396,17 @@ __global__ __launch_bounds__(256) void k_chol_bulk(double* __restrict__ A, const
 // The 32x32x32 tile products use the first 256 threads (2x2 register patches); the diagonal elimination uses all 1024.
 // SOLVED = true: the panel tiles A[.][j] were already solved (k_chol_trsm wrote X into Lf), so the workgroup only does the
 // trailing update -- used for large matrices where recomputing the panel solve per tile pair would triple the flops.
-template <bool SOLVED>
-__global__ __launch_bounds__(1024) void k_chol_panel(double* __restrict__ A, double* __restrict__ Lf, int ld, double* __restrict__ Dinv,
-                                                      int j, int nblk, int* __restrict__ flag) {
+template <bool BATCH, bool SOLVED>
+__global__ __launch_bounds__(1024) void k_chol_panel(cm_parg<BATCH> pa, int na_arg, int skip_own, int j) {
+  CM_SOLVE_PROLOGUE(2)
+  {
+    const int tr = nblk - j - 1;
+    if (nblk > CM_LARGE_TILES || tr <= 0 || (int)blockIdx.x >= tr * (tr + 1) / 2) return;
+  }
+  double* __restrict__ A = p.A;
+  double* __restrict__ Lf = p.Lf;
+  double* __restrict__ Dinv = p.Dinv;
+  int* __restrict__ flag = p.n_act + 1;
   __shared__ double Pi[TS][TP], Pl[TS][TP], Li[TS][TP], Xi[TS][TP], Xl[TS][TP];
   const int t = blockIdx.x;
   int ip = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
@@ -428,7 +481,12 @@ __device__ __forceinline__ void tile_put(double (*dst)[TP], const double r[4]) {
 //    T   = L21 * X11        (stored in the unused strictly-upper tile (c, j2) of A)
 //    X21 = -X22 * T
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_inv_seed(const double* __restrict__ Dinv, double* __restrict__ X, int ld) {
+template <bool BATCH>
+__global__ __launch_bounds__(256) void k_inv_seed(cm_parg<BATCH> pa, int na_arg, int skip_own) {
+  CM_SOLVE_PROLOGUE(2)
+  if ((int)blockIdx.x >= nblk) return;
+  const double* __restrict__ Dinv = p.Dinv;
+  double* __restrict__ X = p.X;
   __shared__ double Tm[TS][TP];
   const int d = blockIdx.x;
   tile_load(Tm, Dinv + (size_t)d * TS * TS, TS);
@@ -436,7 +494,12 @@ __global__ __launch_bounds__(256) void k_inv_seed(const double* __restrict__ Din
   tile_store(X + (size_t)d * TS * ld + (size_t)d * TS, ld, Tm);
 }
 
-__global__ __launch_bounds__(256) void k_inv_T(double* __restrict__ A, const double* __restrict__ Lf, const double* __restrict__ X, int ld, int b, int nblk) {
+template <bool BATCH>
+__global__ __launch_bounds__(256) void k_inv_T(cm_parg<BATCH> pa, int na_arg, int skip_own, int b) {
+  CM_SOLVE_PROLOGUE(2)
+  double* __restrict__ A = p.A;
+  const double* __restrict__ Lf = p.Lf;
+  const double* __restrict__ X = p.X;
   __shared__ double Lt[TS][TP], Xt[TS][TP];
   const int per = b * b;
   const int q = blockIdx.x / per, rem = blockIdx.x % per;
@@ -465,7 +528,11 @@ __global__ __launch_bounds__(256) void k_inv_T(double* __restrict__ A, const dou
   for (int reg = 0; reg < 4; ++reg) out[(size_t)BLK_ROW(rb, lane, reg) * ld + BLK_COL(cb, lane)] = acc[reg];
 }
 
-__global__ __launch_bounds__(256) void k_inv_X21(const double* __restrict__ A, double* __restrict__ X, int ld, int b, int nblk) {
+template <bool BATCH>
+__global__ __launch_bounds__(256) void k_inv_X21(cm_parg<BATCH> pa, int na_arg, int skip_own, int b) {
+  CM_SOLVE_PROLOGUE(2)
+  const double* __restrict__ A = p.A;
+  double* __restrict__ X = p.X;
   __shared__ double Xa[TS][TP], Tt[TS][TP];
   const int per = b * b;
   const int q = blockIdx.x / per, rem = blockIdx.x % per;
@@ -497,8 +564,13 @@ __global__ __launch_bounds__(256) void k_inv_X21(const double* __restrict__ A, d
 // ------------------------------------------------------------------------------------------------
 // w = X rhs (rows), then mu_c = sum_r X[r][c] w_r, beta_c = sum_r X[r][c]^2 (columns, two stages, fixed order)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_tri_matvec(const double* __restrict__ X, int ld, int n, const double* __restrict__ rhs,
-                                                     double* __restrict__ w) {
+template <bool BATCH>
+__global__ __launch_bounds__(256) void k_tri_matvec(cm_parg<BATCH> pa, int na_arg, int skip_own) {
+  CM_SOLVE_PROLOGUE(2)
+  const double* __restrict__ X = p.X;
+  const double* __restrict__ rhs = p.rhs;
+  double* __restrict__ w = p.rhs + p.ld_alloc;
+  const int n = na;
   const int r = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE;
   const int lane = threadIdx.x % CM_WAVE;
   if (r >= n) return;
@@ -509,11 +581,18 @@ __global__ __launch_bounds__(256) void k_tri_matvec(const double* __restrict__ X
 }
 
 #define CM_COLCHUNK 64
-__global__ __launch_bounds__(64) void k_colsum_partial(const double* __restrict__ X, int ld, int n, const double* __restrict__ w,
-                                                        double* __restrict__ part) {
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  const int chunk = blockIdx.y;
+// grid.x = nbx * nchunks (largest matrix of the set): block -> (column block, row chunk)
+template <bool BATCH>
+__global__ __launch_bounds__(64) void k_colsum_partial(cm_parg<BATCH> pa, int na_arg, int skip_own, int nbx) {
+  CM_SOLVE_PROLOGUE(2)
+  const double* __restrict__ X = p.X;
+  const double* __restrict__ w = p.rhs + p.ld_alloc;
+  double* __restrict__ part = p.A;               // the factor is no longer needed: its storage takes the partial column sums
+  const int n = na;
+  const int c = ((int)blockIdx.x % nbx) * 64 + threadIdx.x;
+  const int chunk = (int)blockIdx.x / nbx;
   const int rbeg = chunk * CM_COLCHUNK, rend = min(n, rbeg + CM_COLCHUNK);
+  if (rbeg >= n || ((int)blockIdx.x % nbx) * 64 >= ld) return;
   double sm = 0.0, sb = 0.0;
   if (c < n) {
     // 8 independent loads in flight, then the 8 accumulations in row order (the summation order is part of the result)
@@ -535,8 +614,11 @@ __global__ __launch_bounds__(64) void k_colsum_partial(const double* __restrict_
     part[((size_t)chunk * 2 + 1) * ld + c] = sb;
   }
 }
-__global__ __launch_bounds__(256) void k_colsum_final(const double* __restrict__ part, int ld, int n, int nchunks,
-                                                       const int* __restrict__ act_idx, double* __restrict__ mu, double* __restrict__ beta) {
+template <bool BATCH>
+__global__ __launch_bounds__(256) void k_colsum_final(cm_parg<BATCH> pa, int na_arg, int skip_own) {
+  CM_SOLVE_PROLOGUE(2)
+  const double* __restrict__ part = p.A;
+  const int n = na, nchunks = (na + CM_COLCHUNK - 1) / CM_COLCHUNK;
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n) return;
   double sm = 0.0, sb = 0.0;
@@ -544,86 +626,108 @@ __global__ __launch_bounds__(256) void k_colsum_final(const double* __restrict__
     sm += part[((size_t)ch * 2 + 0) * ld + c];
     sb += part[((size_t)ch * 2 + 1) * ld + c];
   }
-  const int nn = act_idx[c];
-  mu[nn] = sm;
-  beta[nn] = sb;
+  const int nn = p.act_idx[c];
+  p.mu[nn] = sm;
+  p.beta[nn] = sb;
 }
 
-__global__ __launch_bounds__(256) void k_fill_prior(const double* __restrict__ mu_prior, const double* __restrict__ beta_prior, int N,
-                                                     double* __restrict__ mu, double* __restrict__ beta) {
+template <bool BATCH>
+__global__ __launch_bounds__(256) void k_fill_prior(cm_parg<BATCH> pa, int na_arg, int skip_own) {
+  CM_SOLVE_PROLOGUE(2)
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n < N) { mu[n] = mu_prior[n]; beta[n] = beta_prior[n] * beta_prior[n]; }
+  if (n < p.N) { p.mu[n] = p.mu_prior[n]; const double b0 = p.beta_prior[n]; p.beta[n] = b0 * b0; }
 }
 
 // stand-alone launch of the small solve (per-phase test hook, and active sets between the fused kernel's cap and 128)
-__global__ __launch_bounds__(1024) void k_solve_small(const double* __restrict__ lam, const int* __restrict__ row_ptr,
-                                                       const int* __restrict__ col, const int* __restrict__ act_idx,
-                                                       const double* __restrict__ rs, const double* __restrict__ scal,
-                                                       const double* __restrict__ mu_prior, const double* __restrict__ beta_prior,
-                                                       int n, int N, int tot_cap, double* __restrict__ mu, double* __restrict__ beta,
-                                                       int* __restrict__ flag) {
+template <bool BATCH>
+__global__ __launch_bounds__(1024) void k_solve_small(cm_parg<BATCH> pa, int na_arg, int skip_own) {
   extern __shared__ double sm[];
-  solve_small_body(sm, lam, row_ptr, col, act_idx, rs, scal, mu_prior, beta_prior, n, N, tot_cap, mu, beta, flag);
+  CM_SOLVE_PROLOGUE(1)
+  solve_small_body(sm, p.lam, p.row_ptr, p.col, p.act_idx, p.rs, p.scal, p.mu_prior, p.beta_prior, na, p.N, na * p.max_row_len, p.mu, p.beta,
+                   p.n_act + 1, (int)blockDim.x);
 }
 
-// Expects cm_launch_row_stats() to have been enqueued after the last change of lam.
-int cm_solve_mu(cm_ctx* ctx, cm_problem* p, int* n_active_out) {
-  CM_TRY(cm_wait_active(ctx, p));                   // the only host wait of an iteration: size of the active set
-  const int na = ctx->mb_n;
-  if (n_active_out) *n_active_out = na;
-  return cm_solve_launch(ctx, p, na);
+// Expects cm_launch_stats() + a compaction (k_post_single or k_iter_mid) to have been enqueued after the last change of lam.
+int cm_solve_mu(cm_ctx* ctx, cm_set& s, int* n_active_out) {
+  CM_TRY(cm_wait_active(ctx, s));                   // the only host wait of an iteration: size of the active set
+  if (n_active_out) *n_active_out = s.na_max;
+  return cm_solve_launch(ctx, s, -1);
 }
 
-// block_update_mu for an active set of known size: small sets in one workgroup, larger ones by the tiled factorisation
-int cm_solve_launch(cm_ctx* ctx, cm_problem* p, int na) {
+// block_update_mu for active sets of known sizes (s.na): small sets in one workgroup each, larger ones by the tiled factorisation.
+// skip_le: circuits whose active set is no larger than this were already solved (by the fused mid-iteration kernel) and are left
+// alone; -1 = solve every circuit of the set.  In a batch each circuit reads its own size on the device; the host only sizes the
+// grids for the largest one.
+int cm_solve_launch(cm_ctx* ctx, cm_set& s, int skip_mode, hipEvent_t fact_begin, hipEvent_t fact_end) {
   hipStream_t st = ctx->stream;
-  if (na > 0 && na <= CM_SMALL_MAX) {
-    const int tot_cap = na * p->max_row_len;
-    const size_t lds = small_lds_bytes(na, tot_cap);
-    if (lds <= 150 * 1024) {
-      CM_TRY(cm_raise_lds(ctx, CM_LDS_SOLVE_SMALL, reinterpret_cast<const void*>(k_solve_small), lds, 48 * 1024));
-      hipLaunchKernelGGL(k_solve_small, dim3(1), dim3(1024), lds, st, p->lam, p->row_ptr, p->col, p->act_idx, p->rs, p->scal, p->mu_prior,
-                         p->beta_prior, na, p->N, tot_cap, p->mu, p->beta, p->n_act + 1);
-      CM_HIP(hipGetLastError());
-      return CM_OK;
+  s.last_fact = false;
+  // what the set needs
+  bool any_small = false, any_tiled = false, any_panel = false, any_large = false;
+  int na_small = 0, nblk_max = 0, nblk_panel = 0, na_tiled = 0;
+  size_t lds_small = 0;
+  for (int c = 0; c < s.B; ++c) {
+    const cm_problem* q = s.ps[c];
+    const int na = s.na[c];
+    const int kind = cm_solve_kind(na, skip_mode < 0 ? -1 : q->small_cap, q->max_row_len);
+    if (kind == 1) { any_small = true; na_small = std::max(na_small, na); lds_small = std::max(lds_small, small_lds_bytes(na, na * q->max_row_len)); }
+    if (kind == 2) {
+      any_tiled = true;
+      const int nb = (na + TS - 1) / TS;
+      nblk_max = std::max(nblk_max, nb); na_tiled = std::max(na_tiled, na);
+      if (nb > CM_LARGE_TILES) any_large = true; else { any_panel = true; nblk_panel = std::max(nblk_panel, nb); }
     }
   }
-  hipLaunchKernelGGL(k_fill_prior, dim3((p->N + 255) / 256), dim3(256), 0, st, p->mu_prior, p->beta_prior, p->N, p->mu, p->beta);
-  if (na == 0) { CM_HIP(hipGetLastError()); return CM_OK; }
-  const int nblk = (na + TS - 1) / TS;
+  const int skip_le = skip_mode < 0 ? 0 : 1;                   // device side: 1 = leave circuits at or below their own small_cap alone
+  const int na1 = s.B == 1 ? s.na[0] : 0;
+  const int N = s.lead->N;
+  if (any_small) {
+    if (s.B == 1) CM_TRY(cm_raise_lds(ctx, CM_LDS_SOLVE_SMALL, reinterpret_cast<const void*>(k_solve_small<false>), lds_small, 48 * 1024));
+    else CM_TRY(cm_raise_lds(ctx, CM_LDS_SOLVE_SMALL_B, reinterpret_cast<const void*>(k_solve_small<true>), lds_small, 48 * 1024));
+    CM_LAUNCH_SET(k_solve_small, s, 1, 1024, lds_small, st, na1, skip_le);
+  }
+  if (!any_tiled) { CM_HIP(hipGetLastError()); return CM_OK; }
+  CM_LAUNCH_SET(k_fill_prior, s, (N + 255) / 256, 256, 0, st, na1, skip_le);
+  if (nblk_max == 0) { CM_HIP(hipGetLastError()); return CM_OK; }
+  const int nblk = nblk_max;
   const int ld = nblk * TS;
-  double* A = p->A;
-  double* X = p->X;
-  if ((size_t)ld * sizeof(double) > 150 * 1024) { cm_set_error("active set of %d neurons exceeds the LDS row accumulator", na); return CM_ERR_INVALID; }
-  CM_TRY(cm_raise_lds(ctx, CM_LDS_BUILD_PREC, reinterpret_cast<const void*>(k_build_precision), (size_t)ld * sizeof(double), 48 * 1024));
-  hipLaunchKernelGGL(k_build_precision, dim3(ld), dim3(64), (size_t)ld * sizeof(double), st, p->lam, p->row_ptr, p->col, p->col_ptr,
-                     p->csc_row, p->csc_pos, p->act_idx, p->act_inv, p->rs, p->scal, p->mu_prior, p->beta_prior, na, ld, A, p->rhs);
+  if ((size_t)ld * sizeof(double) > 150 * 1024) { cm_set_error("active set of %d neurons exceeds the LDS row accumulator", na_tiled); return CM_ERR_INVALID; }
+  if (s.B == 1) CM_TRY(cm_raise_lds(ctx, CM_LDS_BUILD_PREC, reinterpret_cast<const void*>(k_build_precision<false>), (size_t)ld * sizeof(double), 48 * 1024));
+  else CM_TRY(cm_raise_lds(ctx, CM_LDS_BUILD_PREC_B, reinterpret_cast<const void*>(k_build_precision<true>), (size_t)ld * sizeof(double), 48 * 1024));
+  CM_LAUNCH_SET(k_build_precision, s, ld, 64, (size_t)ld * sizeof(double), st, na1, skip_le);
   // Cholesky
-  hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(256), 0, st, A, ld, p->Dinv, p->n_act + 1);
+  if (fact_begin) CM_HIP(hipEventRecord(fact_begin, st));
+  s.last_fact = true;
+  for (int c = 0; c < s.B; ++c) {                  // bookkeeping for cm_timings: launches and tiles of the trailing updates
+    const int nb = (s.na[c] + TS - 1) / TS;
+    if (cm_solve_kind(s.na[c], skip_mode < 0 ? -1 : s.ps[c]->small_cap, s.ps[c]->max_row_len) != 2) continue;
+    for (int j = 0; j + 1 < nb; ++j) { const long long t = nb - j - 1; s.fact_tile_updates += t * (t + 1) / 2; }
+  }
+  s.fact_launches += std::max(0, nblk - 1);
+  CM_LAUNCH_SET(k_chol_first, s, 1, 256, 0, st, na1, skip_le);
   for (int j = 0; j + 1 < nblk; ++j) {
     const int t = nblk - j - 1;
-    if (nblk > 48) {                                 // large: solve the panel once, then the bandwidth-lean trailing update (block 0 factors the next diagonal tile)
-      hipLaunchKernelGGL(k_chol_trsm, dim3(t), dim3(256), 0, st, A, p->Lf, ld, p->Dinv, j);
-      hipLaunchKernelGGL(k_chol_bulk, dim3(t * (t + 1) / 2), dim3(256), 0, st, A, p->Lf, ld, j, p->Dinv, p->n_act + 1);
-    } else {                                         // small / medium: one launch per panel
-      hipLaunchKernelGGL(k_chol_panel<false>, dim3(t * (t + 1) / 2), dim3(1024), 0, st, A, p->Lf, ld, p->Dinv, j, nblk, p->n_act + 1);
+    if (any_large) {                                 // large: solve the panel once, then the bandwidth-lean trailing update (block 0 factors the next diagonal tile)
+      CM_LAUNCH_SET(k_chol_trsm, s, t, 256, 0, st, na1, skip_le, j);
+      CM_LAUNCH_SET(k_chol_bulk, s, t * (t + 1) / 2, 256, 0, st, na1, skip_le, j);
+    }
+    if (any_panel && j + 1 < nblk_panel) {           // small / medium: one launch per panel
+      const int tp = nblk_panel - j - 1;
+      CM_LAUNCH_SET_T(k_chol_panel, (false), s, tp * (tp + 1) / 2, 1024, 0, st, na1, skip_le, j);
     }
   }
-  // inverse of the factor
-  CM_HIP(hipMemsetAsync(X, 0, (size_t)ld * ld * sizeof(double), st));
-  hipLaunchKernelGGL(k_inv_seed, dim3(nblk), dim3(256), 0, st, p->Dinv, X, ld);
+  if (fact_end) CM_HIP(hipEventRecord(fact_end, st));
+  // inverse of the factor (strictly-upper tiles of X are never read: no clearing needed)
+  CM_LAUNCH_SET(k_inv_seed, s, nblk, 256, 0, st, na1, skip_le);
   for (int b = 1; b < nblk; b *= 2) {
     const int npairs = (nblk + 2 * b - 1) / (2 * b);
-    hipLaunchKernelGGL(k_inv_T, dim3(npairs * b * b), dim3(256), 0, st, A, p->Lf, X, ld, b, nblk);
-    hipLaunchKernelGGL(k_inv_X21, dim3(npairs * b * b), dim3(256), 0, st, A, X, ld, b, nblk);
+    CM_LAUNCH_SET(k_inv_T, s, npairs * b * b, 256, 0, st, na1, skip_le, b);
+    CM_LAUNCH_SET(k_inv_X21, s, npairs * b * b, 256, 0, st, na1, skip_le, b);
   }
   // mu, beta
-  double* w = p->rhs + ld;
-  hipLaunchKernelGGL(k_tri_matvec, dim3((na + 3) / 4), dim3(256), 0, st, X, ld, na, p->rhs, w);
-  const int nchunks = (na + CM_COLCHUNK - 1) / CM_COLCHUNK;
-  double* part = A;   // the factor is no longer needed: reuse its storage for the partial column sums
-  hipLaunchKernelGGL(k_colsum_partial, dim3((ld + 63) / 64, nchunks), dim3(64), 0, st, X, ld, na, w, part);
-  hipLaunchKernelGGL(k_colsum_final, dim3((na + 255) / 256), dim3(256), 0, st, part, ld, na, nchunks, p->act_idx, p->mu, p->beta);
+  CM_LAUNCH_SET(k_tri_matvec, s, (na_tiled + 3) / 4, 256, 0, st, na1, skip_le);
+  const int nchunks = (na_tiled + CM_COLCHUNK - 1) / CM_COLCHUNK, nbx = (ld + 63) / 64;
+  CM_LAUNCH_SET(k_colsum_partial, s, nbx * nchunks, 64, 0, st, na1, skip_le, nbx);
+  CM_LAUNCH_SET(k_colsum_final, s, (na_tiled + 255) / 256, 256, 0, st, na1, skip_le);
   CM_HIP(hipGetLastError());
   return CM_OK;
 }

@@ -21,51 +21,6 @@
 // RNG.  Key schedule (host, cm_host_key_schedule): per iteration (3 + N) threefry keys:
 //   [0..2]  sort-key subkeys of the permutation rounds (jax _shuffle), [3 + m] the uniform key of sweep step m.
 // ------------------------------------------------------------------------------------------------
-int cm_perm_rounds(int N) {
-  const double r = 3.0 * log((double)(N > 1 ? N : 1)) / log(4294967295.0);
-  int k = (int)ceil(r);
-  return k < 0 ? 0 : k;
-}
-
-static void host_split(const uint32_t key[2], uint32_t out0[2], uint32_t out1[2]) {
-  uint32_t a0 = 0, a1 = 2, b0 = 1, b1 = 3;
-  cm_threefry2x32(key[0], key[1], a0, a1);
-  cm_threefry2x32(key[0], key[1], b0, b1);
-  out0[0] = a0; out0[1] = b0;
-  out1[0] = a1; out1[1] = b1;
-}
-
-// jax key handling of caviar(): see oracle/threefry.py JaxLikeStream (caviar.py:76,196,209-210,227,251,304)
-// Resumable: `key` is the carried jax key (PRNGKey(seed) before iteration 0), updated in place; writes the (3 + N) keys of
-// iterations [it0, it0 + n_it) at their place in `keys` (which holds all iterations).
-void cm_host_key_schedule_range(uint32_t key[2], int it0, int n_it, int N, uint32_t* keys) {
-  const size_t per = (size_t)(N + 3) * 2;
-  const int rounds = cm_perm_rounds(N);
-  for (int it = it0; it < it0 + n_it; ++it) {
-    uint32_t* out = keys + per * it;
-    uint32_t k[2] = {key[0], key[1]}, s0[2], s1[2];
-    for (int r = 0; r < rounds && r < 3; ++r) {       // key, subkey = split(key)
-      host_split(k, s0, s1);
-      out[2 * r] = s1[0]; out[2 * r + 1] = s1[1];
-      k[0] = s0[0]; k[1] = s0[1];
-    }
-    k[0] = key[0]; k[1] = key[1];
-    for (int m = 0; m < N; ++m) {                      // key, key_next = split(key); uniform(key); carry key_next
-      host_split(k, s0, s1);
-      out[2 * (3 + m)] = s0[0]; out[2 * (3 + m) + 1] = s0[1];
-      k[0] = s1[0]; k[1] = s1[1];
-    }
-    host_split(k, s0, s1);                             // update_phi returns split(key)[1]
-    key[0] = s1[0]; key[1] = s1[1];
-  }
-}
-
-void cm_host_key_schedule(uint64_t seed, int iters, int N, std::vector<uint32_t>& keys) {
-  keys.assign((size_t)(N + 3) * 2 * iters, 0u);
-  uint32_t key[2] = {(uint32_t)(seed >> 32), (uint32_t)(seed & 0xFFFFFFFFull)};
-  cm_host_key_schedule_range(key, 0, iters, N, keys.data());
-}
-
 // 32-bit sort keys: jax threefry_2x32(key, iota(n)) layout (odd n padded with one zero counter)
 __device__ __forceinline__ uint32_t cm_bits32(uint32_t k0, uint32_t k1, int i, int n) {
   const int odd = n & 1, half = (n + odd) >> 1;
@@ -156,6 +111,14 @@ struct SweepArgs {
   int V, gated;
   double msrmp, min_count;
 };
+
+__device__ __forceinline__ SweepArgs sweep_args(const cm_pdev& p, int gated, double msrmp, double min_count) {
+  SweepArgs a;
+  a.row_ptr = p.row_ptr; a.col = p.col; a.grp = p.grp; a.rowcnt = p.rowcnt;
+  a.y = p.y; a.mask = p.mask; a.mu = p.mu; a.beta = p.beta; a.mcE = p.mcE; a.scal = p.scal;
+  a.lam = p.lam; a.V = p.V; a.gated = gated; a.msrmp = msrmp; a.min_count = min_count;
+  return a;
+}
 
 // pava.py:9-88 with gamma = 1, last element only; literal pool walk (strict '>' merge test, pava.py:42)
 __device__ __forceinline__ double cm_pava_last_dev(const double* y, int n, double* v, double* w) {
@@ -399,14 +362,15 @@ __device__ __forceinline__ void seq_scan_body(const int* __restrict__ order, con
 //   blocks [nbI, nbI+nbC)  R_k = sum_n mu_n lam_nk per trial (= lam.T @ mu), 16 lanes per trial.  Rows handled by the
 //                          first role have mu == 0, so whichever of their old/new lam is read contributes exactly 0.
 //   last block             ordered compaction of the mu != 0 rows + record offsets + chunk table of the chain
-__global__ __launch_bounds__(1024) void k_presweep(SweepArgs a, int N, int K, int nbI, int nbC, int roles, const int* __restrict__ order,
-                                                    const int* __restrict__ col_ptr, const int* __restrict__ csc_row,
-                                                    const int* __restrict__ csc_pos, double* __restrict__ R, int* __restrict__ seq_n,
-                                                    int* __restrict__ seq_off, int* __restrict__ chunk_first, int* __restrict__ meta,
-                                                    int* __restrict__ seq_pos, int gran) {
+template <bool BATCH>
+__global__ __launch_bounds__(1024) void k_presweep(cm_parg<BATCH> pa, int it, int gated, double msrmp, double min_count, int nbI, int nbC,
+                                                    int roles, int gran) {
   __shared__ double scr_all[16][3 * CM_MAX_VALS];
   __shared__ int wsum[2][16];
   __shared__ int carry[2];
+  const cm_pdev& p = pa.get();
+  const SweepArgs a = sweep_args(p, gated, msrmp, min_count);
+  const int N = p.N;
   const int b = blockIdx.x;
   if (b < nbI) {
     if (!(roles & 1)) return;
@@ -414,22 +378,28 @@ __global__ __launch_bounds__(1024) void k_presweep(SweepArgs a, int N, int K, in
     if (n < N) sweep_indep_row(a, n, threadIdx.x % CM_WAVE, scr_all[threadIdx.x / CM_WAVE]);
   } else if (b < nbI + nbC) {
     if (!(roles & 2)) return;
-    cm_col_dot16((b - nbI) * 1024 + threadIdx.x, K, a.mu, a.lam, col_ptr, csc_row, csc_pos, 0.0, R, nullptr);
+    cm_col_dot16((b - nbI) * 1024 + threadIdx.x, p.K, a.mu, a.lam, p.col_ptr, p.csc_row, p.csc_pos, 0.0, p.R, nullptr);
   } else {
     if (!(roles & 4)) return;
-    seq_scan_body(order, a.mu, a.row_ptr, N, seq_n, seq_off, chunk_first, meta, seq_pos, gran, wsum, carry);
+    seq_scan_body(p.orders_all + (size_t)it * N, a.mu, a.row_ptr, N, p.seq_n, p.seq_off, p.chunk_first, p.seq_meta, p.seq_pos, gran, wsum, carry);
   }
 }
 
 // `turns` != 0: also store in bits 24..31 of the slot word how many EARLIER chain rows touch the entry's trial (its ticket
 // in the multi-wave chain kernel); requires nnz < 2^24 and at most 255 targeted neurons per trial.
-__global__ __launch_bounds__(256) void k_seq_pack(SweepArgs a, const int* __restrict__ seq_n, const int* __restrict__ seq_off,
-                                                   const int* __restrict__ meta, SeqRec* __restrict__ packed, int turns,
-                                                   const int* __restrict__ seq_pos, const int* __restrict__ col_ptr,
-                                                   const int* __restrict__ csc_row) {
+template <bool BATCH>
+__global__ __launch_bounds__(256) void k_seq_pack(cm_parg<BATCH> pa, int gated, double msrmp, double min_count, int turns) {
+  const cm_pdev& p = pa.get();
+  const SweepArgs a = sweep_args(p, gated, msrmp, min_count);
+  const int* __restrict__ seq_n = p.seq_n;
+  const int* __restrict__ seq_off = p.seq_off;
+  const int* __restrict__ seq_pos = p.seq_pos;
+  const int* __restrict__ col_ptr = p.col_ptr;
+  const int* __restrict__ csc_row = p.csc_row;
+  SeqRec* __restrict__ packed = (SeqRec*)p.packed;
   const int j = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE;
   const int lane = threadIdx.x % CM_WAVE;
-  if (j >= meta[0]) return;
+  if (j >= p.seq_meta[0]) return;
   const int n = seq_n[j], off = seq_off[j];
   const int beg = a.row_ptr[n], len = a.row_ptr[n + 1] - beg;
   const double sig = a.scal[CM_S_SHAPE] / a.scal[CM_S_RATE];
@@ -455,12 +425,16 @@ __global__ __launch_bounds__(256) void k_seq_pack(SweepArgs a, const int* __rest
   }
 }
 
-template <bool R_IN_LDS>
-__global__ __launch_bounds__(1024) void k_sweep_seq(SweepArgs a, const SeqRec* __restrict__ packed, int packed_cap, int nchunks_cap,
-                                                     const int* __restrict__ seq_off,
-                                                     const int* __restrict__ chunk_first, const int* __restrict__ meta, int K,
-                                                     const int* __restrict__ col_ptr, const int* __restrict__ csc_row,
-                                                     const int* __restrict__ csc_pos, double* __restrict__ Rg) {
+template <bool BATCH, bool R_IN_LDS>
+__global__ __launch_bounds__(1024) void k_sweep_seq(cm_parg<BATCH> pa, int gated, double msrmp, double min_count, int packed_cap, int nchunks_cap) {
+  const cm_pdev& p = pa.get();
+  const SweepArgs a = sweep_args(p, gated, msrmp, min_count);
+  const SeqRec* __restrict__ packed = (const SeqRec*)p.packed;
+  const int* __restrict__ seq_off = p.seq_off;
+  const int* __restrict__ chunk_first = p.chunk_first;
+  const int* __restrict__ meta = p.seq_meta;
+  const int K = p.K;
+  double* __restrict__ Rg = p.R;
   __shared__ SeqRec buf[2][CM_SEQ_CAP];
   __shared__ int cfo[CM_SEQ_LDS_CHUNKS][2];      // per chunk: first row, first record offset
   __shared__ double scr[3 * CM_MAX_VALS];
@@ -557,11 +531,17 @@ __global__ __launch_bounds__(1024) void k_sweep_seq(SweepArgs a, const SeqRec* _
 #define CM_PAR_MIN_ROWS 0    // measured: the multi-wave kernel also wins for the ~30-row steady-state chains
 #endif
 // CAP = records per LDS buffer, TK = ticket type: (1024, int) for K up to ~5600 trials, (512, uint8_t) up to ~10900.
-template <int CAP, typename TK>
-__global__ __launch_bounds__(1024) void k_sweep_par(SweepArgs a, const SeqRec* __restrict__ packed, int packed_cap, int nchunks_cap,
-                                                     const int* __restrict__ seq_off, const int* __restrict__ chunk_first,
-                                                     const int* __restrict__ meta, int K, const double* __restrict__ Rg,
-                                                     int* __restrict__ err_flag) {
+template <bool BATCH, int CAP, typename TK>
+__global__ __launch_bounds__(1024) void k_sweep_par(cm_parg<BATCH> pa, int gated, double msrmp, double min_count, int packed_cap, int nchunks_cap) {
+  const cm_pdev& p = pa.get();
+  const SweepArgs a = sweep_args(p, gated, msrmp, min_count);
+  const SeqRec* __restrict__ packed = (const SeqRec*)p.packed;
+  const int* __restrict__ seq_off = p.seq_off;
+  const int* __restrict__ chunk_first = p.chunk_first;
+  const int* __restrict__ meta = p.seq_meta;
+  const int K = p.K;
+  const double* __restrict__ Rg = p.R;
+  int* __restrict__ err_flag = p.n_act + 2;
   __shared__ SeqRec buf[2][CAP];
   __shared__ int cfo[CM_SEQ_LDS_CHUNKS][2];
   __shared__ int roff[2][CAP + 1];            // record offset of every row of the chunk, relative to the chunk start
@@ -693,54 +673,57 @@ int cm_k_rng_streams_impl(cm_ctx* ctx, cm_problem* p, int it, int S, double* d_u
   return CM_OK;
 }
 
-int cm_launch_sweep(cm_ctx* ctx, cm_problem* p, int it, const cm_options* o, hipEvent_t mid) {
-  SweepArgs a;
-  a.row_ptr = p->row_ptr; a.col = p->col; a.grp = p->grp; a.rowcnt = p->rowcnt;
-  a.y = p->y; a.mask = p->mask; a.mu = p->mu; a.beta = p->beta; a.mcE = p->mcE; a.scal = p->scal;
-  a.lam = p->lam; a.V = p->V;
-  a.gated = it > o->delay_spont_est;
-  a.msrmp = o->msrmp; a.min_count = o->minimum_spike_count;
+int cm_launch_sweep(cm_ctx* ctx, cm_set& s, int it, const cm_options* o, hipEvent_t mid, int table_it) {
+  const cm_problem* p = s.lead;
+  const int gated = it > o->delay_spont_est;
+  const double msrmp = o->msrmp, min_count = o->minimum_spike_count;
   hipStream_t st = ctx->stream;
   const int N = p->N;
   const int nbI = (N + 15) / 16, nbC = (p->K * 16 + 1023) / 1024;    // 16 rows per block; 16 lanes per trial column
   // multi-wave chain when the ticket encoding fits (see k_sweep_par): variant 1 = 1024-record buffers + 32-bit tickets,
-  // variant 2 = 512-record buffers + 8-bit tickets (larger K); 0 = single-consumer kernel
-  static const bool no_par = getenv("CAVIAR_HIP_NO_PAR_SWEEP") != nullptr;
-  int par = 0;
-  if (!no_par && ctx->mb_n > CM_PAR_MIN_ROWS && p->max_row_len <= CM_WAVE && p->max_col_len <= 255 && p->nnz < (1 << 24)) {
-    if ((size_t)p->K * 12 <= 68 * 1024) par = 1;
-    else if ((size_t)p->K * 9 + 16 <= 96 * 1024) par = 2;
-  }
+  // variant 2 = 512-record buffers + 8-bit tickets (larger K); 0 = single-consumer kernel.  Whichever kernel walks the chain,
+  // every R_k sees its updates in sweep order: the variants give bit-identical results.
+  const int par = cm_sweep_variant(s, s.B > 1 ? 1 : ctx->mb_n);
   const int cap = (par == 2) ? 512 : CM_SEQ_CAP;
   const int gran = cap - CM_WAVE - 1;                              // chunking granule: a chunk spans < gran + 65 <= cap records
   const size_t lds_par = (par == 2) ? (size_t)p->K * 9 + 16 : (size_t)p->K * 12;
   static const bool split = getenv("CAVIAR_HIP_SPLIT_PRESWEEP") != nullptr;     // diagnostic: one launch per role (profiling only)
   for (int pass = 0; pass < (split ? 3 : 1); ++pass)
-    hipLaunchKernelGGL(k_presweep, dim3(nbI + nbC + 1), dim3(1024), 0, st, a, N, p->K, nbI, nbC, split ? (1 << pass) : 7, p->order,
-                       p->col_ptr, p->csc_row, p->csc_pos, p->R, p->seq_n, p->seq_off, p->chunk_first, p->seq_meta, p->seq_pos, gran);
-  hipLaunchKernelGGL(k_seq_pack, dim3((N + 3) / 4), dim3(256), 0, st, a, p->seq_n, p->seq_off, p->seq_meta, (SeqRec*)p->packed,
-                     par ? 1 : 0, p->seq_pos, p->col_ptr, p->csc_row);
+    CM_LAUNCH_SET(k_presweep, s, nbI + nbC + 1, 1024, 0, st, (table_it < 0 ? it : table_it), gated, msrmp, min_count, nbI, nbC, split ? (1 << pass) : 7, gran);
+  CM_LAUNCH_SET(k_seq_pack, s, (N + 3) / 4, 256, 0, st, gated, msrmp, min_count, par ? 1 : 0);
   if (mid) CM_HIP(hipEventRecord(mid, st));
   const size_t lds = (size_t)p->K * sizeof(double);
-  const long long nrec = (long long)p->N + p->nnz;             // allocation of `packed` (records) and of the chunk table
+  const long long nrec = (long long)p->N + s.nnz_min;          // smallest allocation of `packed` (records) and of the chunk table in the set
   const int packed_cap = (int)std::min<long long>(cap, nrec);
   const int nchunks_cap = (int)std::min<long long>(CM_SEQ_LDS_CHUNKS - 1, nrec / 256 + 7);
   if (par == 1) {
-    CM_TRY(cm_raise_lds(ctx, CM_LDS_SWEEP_PAR, reinterpret_cast<const void*>(k_sweep_par<CM_SEQ_CAP, int>), lds_par, 0));
-    hipLaunchKernelGGL((k_sweep_par<CM_SEQ_CAP, int>), dim3(1), dim3(1024), lds_par, st, a, (const SeqRec*)p->packed, packed_cap, nchunks_cap,
-                       p->seq_off, p->chunk_first, p->seq_meta, p->K, p->R, p->n_act + 2);
+    if (s.B == 1) CM_TRY(cm_raise_lds(ctx, CM_LDS_SWEEP_PAR, reinterpret_cast<const void*>(k_sweep_par<false, CM_SEQ_CAP, int>), lds_par, 0));
+    else CM_TRY(cm_raise_lds(ctx, CM_LDS_SWEEP_PAR_B, reinterpret_cast<const void*>(k_sweep_par<true, CM_SEQ_CAP, int>), lds_par, 0));
+    CM_LAUNCH_SET_T(k_sweep_par, (CM_SEQ_CAP, int), s, 1, 1024, lds_par, st, gated, msrmp, min_count, packed_cap, nchunks_cap);
   } else if (par == 2) {
-    CM_TRY(cm_raise_lds(ctx, CM_LDS_SWEEP_PAR2, reinterpret_cast<const void*>(k_sweep_par<512, uint8_t>), lds_par, 0));
-    hipLaunchKernelGGL((k_sweep_par<512, uint8_t>), dim3(1), dim3(1024), lds_par, st, a, (const SeqRec*)p->packed, packed_cap, nchunks_cap,
-                       p->seq_off, p->chunk_first, p->seq_meta, p->K, p->R, p->n_act + 2);
+    if (s.B == 1) CM_TRY(cm_raise_lds(ctx, CM_LDS_SWEEP_PAR2, reinterpret_cast<const void*>(k_sweep_par<false, 512, uint8_t>), lds_par, 0));
+    else CM_TRY(cm_raise_lds(ctx, CM_LDS_SWEEP_PAR2_B, reinterpret_cast<const void*>(k_sweep_par<true, 512, uint8_t>), lds_par, 0));
+    CM_LAUNCH_SET_T(k_sweep_par, (512, uint8_t), s, 1, 1024, lds_par, st, gated, msrmp, min_count, packed_cap, nchunks_cap);
   } else if (lds <= 88 * 1024) {     // 64 KiB of record buffers + R must fit the CU's 160 KiB
-    CM_TRY(cm_raise_lds(ctx, CM_LDS_SWEEP_SEQ, reinterpret_cast<const void*>(k_sweep_seq<true>), lds, 0));   // only when it has to grow
-    hipLaunchKernelGGL(k_sweep_seq<true>, dim3(1), dim3(1024), lds, st, a, (const SeqRec*)p->packed, packed_cap, nchunks_cap, p->seq_off, p->chunk_first,
-                       p->seq_meta, p->K, p->col_ptr, p->csc_row, p->csc_pos, p->R);
+    if (s.B == 1) CM_TRY(cm_raise_lds(ctx, CM_LDS_SWEEP_SEQ, reinterpret_cast<const void*>(k_sweep_seq<false, true>), lds, 0));
+    else CM_TRY(cm_raise_lds(ctx, CM_LDS_SWEEP_SEQ_B, reinterpret_cast<const void*>(k_sweep_seq<true, true>), lds, 0));
+    CM_LAUNCH_SET_T(k_sweep_seq, (true), s, 1, 1024, lds, st, gated, msrmp, min_count, packed_cap, nchunks_cap);
   } else {
-    hipLaunchKernelGGL(k_sweep_seq<false>, dim3(1), dim3(1024), 0, st, a, (const SeqRec*)p->packed, packed_cap, nchunks_cap, p->seq_off, p->chunk_first,
-                       p->seq_meta, p->K, p->col_ptr, p->csc_row, p->csc_pos, p->R);
+    CM_LAUNCH_SET_T(k_sweep_seq, (false), s, 1, 1024, 0, st, gated, msrmp, min_count, packed_cap, nchunks_cap);
   }
   CM_HIP(hipGetLastError());
   return CM_OK;
+}
+
+// which kernel walks the chain: 1 / 2 = multi-wave (32-bit / 8-bit tickets), 0 = single consumer.  `rows_hint` = 0 (empty active
+// set) keeps the single-consumer kernel for one circuit, as before.
+int cm_sweep_variant(const cm_set& s, int rows_hint) {
+  static const bool no_par = getenv("CAVIAR_HIP_NO_PAR_SWEEP") != nullptr;
+  const cm_problem* p = s.lead;
+  int par = 0;
+  if (!no_par && rows_hint > CM_PAR_MIN_ROWS && s.max_row_len_max <= CM_WAVE && s.max_col_len_max <= 255 && s.nnz_max < (1 << 24)) {
+    if ((size_t)p->K * 12 <= 68 * 1024) par = 1;
+    else if ((size_t)p->K * 9 + 16 <= 96 * 1024) par = 2;
+  }
+  return par;
 }

@@ -123,6 +123,39 @@ class Problem:
             pass
 
 
+def _priors_struct(N, mu_prior, beta_prior, shape_prior, rate_prior, phi_prior, phi_cov_prior, keep):
+    arrs = [_lib.f64(mu_prior, (N,)), _lib.f64(beta_prior, (N,)), _lib.f64(phi_prior, (N, 2)), _lib.f64(phi_cov_prior, (N, 2, 2))]
+    keep += arrs
+    return _lib.CmPriors(_lib.dptr(arrs[0]), _lib.dptr(arrs[1]), float(shape_prior), float(rate_prior), _lib.dptr(arrs[2]), _lib.dptr(arrs[3]))
+
+
+def run_batch(problems, priors, verbose=0, timing=0, **fit_options):
+    """cm_caviar_run_batch: fit several `Problem`s of ONE context in lock-step (the circuit is the outer grid dimension of every
+    launch).  `priors`: one dict (shared) or a list of dicts with keys mu, beta, shape, rate, phi, phi_cov.  Results stay in HBM
+    (`Problem.fetch`), each bit-identical to the circuit's own `Problem.run`.  Returns the list of device timings."""
+    if not problems:
+        return []
+    ctx = problems[0].ctx
+    if any(q.ctx is not ctx for q in problems):
+        raise ValueError("run_batch: all problems must live on the same context")
+    unknown = set(fit_options) - set(_OPTION_NAMES)
+    if unknown:
+        raise TypeError("caviar() got an unexpected keyword argument '%s'" % sorted(unknown)[0])
+    o = make_options(ctx.lib, verbose=verbose, timing=timing, **fit_options)
+    n = len(problems)
+    plist = [priors] * n if isinstance(priors, dict) else list(priors)
+    keep = []
+    prs = (_lib.CmPriors * n)(*[_priors_struct(q.N, pr["mu"], pr["beta"], pr["shape"], pr["rate"], pr["phi"], pr["phi_cov"], keep)
+                                for q, pr in zip(problems, plist)])
+    handles = (C.c_void_p * n)(*[q.handle for q in problems])
+    tms = (_lib.CmTimings * n)()
+    with ctx.lock:
+        _lib.check(ctx.lib.cm_caviar_run_batch(ctx.handle, n, handles, prs, C.byref(o), tms))
+    for q in problems:
+        q._last = (o.iters, bool(o.save_histories))
+    return list(tms)
+
+
 def caviar(y_psc, I, mu_prior, beta_prior, shape_prior, rate_prior, phi_prior, phi_cov_prior,
            iters=50, num_mc_samples=100, seed=0, y_xcorr_thresh=1e-2, minimum_spike_count=3,
            delay_spont_est=1, msrmp=0.3, scale_factor=0.75, penalty=5e0, save_histories=False,

@@ -168,7 +168,7 @@ _SIM_KEYS = ("N", "T", "H", "trials", "nreps", "connection_prob", "min_latency",
              "gp_lengthscale", "spont_prob", "max_power_min_spike_rate", "seed")
 
 
-def simulate_device(powers=(45, 55, 65), design="blockwise", device_id=0, keep_on_device=False, full=True, **kw):
+def simulate_device(powers=(45, 55, 65), design="blockwise", device_id=0, keep_on_device=False, full=True, ctx=None, **kw):
     """`simulate` generated ON the MI355X (include/sim_hip.h, circuitmap_amd/csrc/cm_sim.hip): same arguments, defaults and
     returned keys as the reference's ``simulate`` (circuitmap/simulation.py:25-195, both designs), counter-based draws.
 
@@ -195,7 +195,7 @@ def simulate_device(powers=(45, 55, 65), design="blockwise", device_id=0, keep_o
     o.n_powers = len(powers)
     for i, p in enumerate(powers):
         o.powers[i] = p
-    ctx = _lib.default_context(device_id)
+    ctx = ctx if ctx is not None else _lib.default_context(device_id)      # `ctx`: run on the caller's context / stream
     N, K, T = o.N, o.trials, o.T
     res = _lib.CmSimResult()
     ms = C.c_float(0.0)

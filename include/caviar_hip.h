@@ -14,6 +14,9 @@
  * cm_last_error() (thread-local); no exceptions cross the ABI.  One cm_ctx = one GPU + one HIP stream; calls on
  * one ctx must be serialised by the caller, distinct ctxs are independent (one process per GPU, or several ctxs
  * per process).
+ *
+ * Limits (also in INTEGRATION.md): N >= 2; at most CM_MAX_VALS distinct stimulus values; active sets of more than 19 200 neurons
+ * are refused (CM_ERR_INVALID: the row accumulator of the precision build lives in LDS); at most 1024 circuits per lock-step group.
  */
 #ifndef CAVIAR_HIP_H
 #define CAVIAR_HIP_H
@@ -111,17 +114,19 @@ typedef struct cm_timings {
   double iters_ms;       /* the `iters` CAVIaR iterations only                                */
   double fn_scan_ms;     /* reconnect_spont_cells (host) + final update_phi                   */
   double solve_ms;       /* timing >= 2, sum over iterations: host wait + block_update_mu of large active sets (build + Cholesky + inverse) */
-  double mc_ms;          /* unused (kept for layout compatibility)                             */
-  double mc_wait_ms;     /* unused (kept for layout compatibility)                             */
   double sweep_indep_ms; /* timing >= 2, sum: k_presweep + k_seq_pack launches                */
   double sweep_seq_ms;   /* timing >= 1, sum: chain-kernel launches (k_sweep_par / k_sweep_seq: the Gauss-Seidel chain) */
   double mid_ms;         /* timing >= 1, sum: k_iter_mid launches (sigma, z, small solve || phi + next MC logit), each incl. one launch boundary */
   double post_ms;        /* timing >= 2, sum: k_stats + k_iter_mid                            */
+  double fact_ms;        /* timing >= 1, sum over the tiled solves of the run: first to last launch of the Cholesky factorisation (event pair per solve) */
   int32_t iters;
+  int32_t batch;         /* circuits that shared the launches of this run (1 for cm_caviar_run): the *_ms fields are those of the whole set */
   int32_t last_active;   /* size of the active (lam row != 0) set in the last iteration       */
   int64_t sum_active;    /* sum over iterations of the active-set size                        */
   int64_t sum_seq_rows;  /* sum over iterations: rows in the sequential chain (mu != 0)        */
   int64_t sum_seq_records; /* sum over iterations: 32-byte records streamed by k_sweep_seq (rows + their trials) */
+  int64_t fact_launches; /* trailing-update launches (k_chol_panel, or k_chol_trsm + k_chol_bulk pairs) inside fact_ms               */
+  int64_t fact_tile_updates; /* 32 x 32 tiles those launches updated (sum of t (t + 1) / 2 over the panels, times the circuits that took part) */
 } cm_timings;
 
 const char* cm_last_error(void);
@@ -162,6 +167,23 @@ int cm_caviar_fetch(cm_ctx* ctx, cm_problem* p, cm_result* result);
 int cm_caviar_fit(cm_ctx* ctx, int32_t N, int32_t K, int32_t T, const double* psc, const double* stim,
                   const cm_priors* priors, const cm_options* options, cm_result* result, cm_timings* timings);
 
+/* Lock-step batch on ONE GPU: fits `n_circuits` problems (all created on `ctx`, distinct) with the same options.  Circuits with the same
+ * sizes form a group whose every kernel launch carries the circuit as its outer grid dimension (one sweep workgroup per circuit, the
+ * per-neuron phases of all circuits side by side): a single fit is a latency chain that occupies a few percent of an MI355X, a batch
+ * fills it.  Each circuit's results are bit-identical to its own cm_caviar_run (same kernels bodies, same summation orders; the
+ * random streams depend only on (seed, N, num_mc_samples) and are generated once per group).  priors[n_circuits]; timings[n_circuits]
+ * or NULL (device times are those of the circuit's group).  Replaces the reference's only scale-out, one process per circuit
+ * (reference scripts/generate_loho_cv_slurm_scripts.py:8-36).  Results stay in HBM: cm_caviar_fetch per problem. */
+int cm_caviar_run_batch(cm_ctx* ctx, int32_t n_circuits, cm_problem* const* problems, const cm_priors* priors,
+                        const cm_options* options, cm_timings* timings);
+
+/* Convenience over several GPUs of this process: circuit c (host arrays psc[c] = K[c] x T[c], stim[c] = N[c] x K[c]) is created on
+ * device_ids[c % n_devices]; every device runs its circuits as one cm_caviar_run_batch from its own host thread; results[n_circuits]
+ * hold caller-allocated buffers as for cm_caviar_fetch.  device_ids == NULL: device 0. */
+int cm_caviar_fit_batch(int32_t n_circuits, const int32_t* N, const int32_t* K, const int32_t* T, const double* const* psc,
+                        const double* const* stim, const cm_priors* priors, const cm_options* options, const int32_t* device_ids,
+                        int32_t n_devices, cm_result* results, cm_timings* timings);
+
 /* ---- per-phase entry points (parity tests exercise each kernel in isolation; host buffers in/out) ---- */
 
 /* caviar.py:28-30: y[K] = trapz(psc[k,:]), ss[K] = sum_t psc[k,t]^2 */
@@ -175,6 +197,20 @@ int cm_k_block_update_mu(cm_ctx* ctx, int32_t N, int32_t K, const double* stim, 
 /* caviar.py:246-316 on dense lam/stim */
 int cm_k_update_phi(cm_ctx* ctx, int32_t N, int32_t K, const double* stim, const double* lam,
                     const double* phi_prior, const double* phi_cov_prior, double* phi, double* phi_cov);
+/* caviar.py:238-244 update_sigma on dense lam: shape = shape_prior + K/2, rate = rate_prior + (|y - lam^T mu|^2 - ... )/2 */
+int cm_k_sigma(cm_ctx* ctx, int32_t N, int32_t K, const double* stim, const double* lam, const double* y, const double* mu,
+               const double* beta, double shape_prior, double rate_prior, double* shape, double* rate);
+/* caviar.py:147-163 estimate_spont_act_soft_thresh as caviar() calls it at OUTER iteration `it` (:86: loop counter = it, err = sum(y)),
+ * then spont_rate = mean(z != 0) (:88).  mask[K] = lam_mask (bytes); z[K] in: previous z (kept when the loop does not run), out: new z */
+int cm_k_spont(cm_ctx* ctx, int32_t N, int32_t K, const double* stim, const double* lam, const double* y, const uint8_t* mask,
+               const double* mu, int32_t it, int32_t max_backtrack_iters, double penalty, double scale_factor, double tol,
+               double spont_orthogonality, double* z, double* spont_rate);
+/* caviar.py:190-231 update_lam on dense lam[N*K] (in/out).  key[2]: the jax key passed to update_lam, replaced by the key it returns;
+ * minimax_spk_prob = msrmp + spont_rate as at the call site (:81-83); beta = what block_update_mu returned (a variance, quirk 1) */
+int cm_k_lam_sweep(cm_ctx* ctx, int32_t N, int32_t K, const double* stim, double* lam, const double* y, const uint8_t* mask,
+                   const double* mu, const double* beta, double shape, double rate, const double* phi, const double* phi_cov,
+                   uint32_t* key, int32_t num_mc_samples, double minimum_spike_count, double minimax_spk_prob, int32_t it,
+                   int32_t delay_spont_est);
 /* caviar.py:102-144 reconnect_spont_cells on dense lam (in/out: mu, beta, lam[N*K], z are updated in place) */
 int cm_k_reconnect(cm_ctx* ctx, int32_t N, int32_t K, const double* stim, double* lam, double* mu, double* beta, double* z,
                    double minimax_spk_prob, double minimum_spike_count);

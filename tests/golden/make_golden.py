@@ -84,6 +84,25 @@ def case_cfg1(ref):
          update_orders=orders, uniforms_seed=np.int64(0), iters=np.int64(50), **{"out_" + k: v for k, v in res.items()})
 
 
+def case_cfg2(ref):
+    """BASELINE configs[1]: N=300, K=1000, T=900, default options; the first 12 iterations (ungated full-size solves, the gating
+    transition, the shrinking active set) + false-negative scan, with every per-iteration history.  lam (final and history) is
+    stored on the support of the stimulus matrix only (it is identically zero elsewhere, caviar.py:216)."""
+    N, K = 300, 1000
+    sim = simulate(N=N, trials=K, seed=1300)
+    psc, stim = f32_exact(sim["psc"]), sim["stim_matrix"]
+    pri = default_priors(N)
+    opts = dict(iters=12, seed=0, save_histories=True)
+    res = run_caviar(ref, psc, stim, pri, **opts)
+    sup = stim > 0
+    assert not np.any(res["lam"][~sup]) and not np.any(res["hist_lam"][:, ~sup])
+    res["lam"] = res["lam"][sup]
+    res["hist_lam"] = res["hist_lam"][:, sup]
+    res["hist_shape"], res["hist_rate"] = res["hist_shape"][:, 0].copy(), res["hist_rate"][:, 0].copy()   # scalars broadcast to [iters, K]
+    save("caviar_cfg2", psc=psc.astype(np.float32), stim=stim.astype(np.float32), weights=sim["weights"],
+         **{"opt_" + k: np.asarray(v) for k, v in opts.items()}, **{"out_" + k: v for k, v in res.items()})
+
+
 def tiny_problem(seed, N=8, K=48, T=60, H=2, powers=(30.0, 50.0, 70.0)):
     rng = np.random.default_rng(seed)
     stim = np.zeros((N, K))
@@ -182,6 +201,18 @@ def case_units(ref):
         rm, rb, rl, rz = ref.reconnect_spont_cells(jnp.array(y), stim, jnp.array(lam), jnp.array(mu_r), jnp.array(np.asarray(beta)),
                                                    jnp.array(z_r), minimax_spk_prob=0.3, minimum_spike_count=3)
     out.update(rec_mu_in=mu_r, rec_z_in=z_r, rec_mu=np.asarray(rm), rec_beta=np.asarray(rb), rec_lam=np.asarray(rl), rec_z=np.asarray(rz))
+    # update_lam: one Gauss-Seidel sweep, ungated (it <= delay_spont_est) and gated, from the phi posterior above
+    jr = sys.modules["jax.random"]
+    powers = np.unique(stim)[1:]
+    y_s = y * 0.02                                   # residual scale at which the sigmoid posterior is not saturated
+    for tag, it in (("ungated", 0), ("gated", 5)):
+        key = jr.PRNGKey(3)
+        lam_new, key_out = ref.update_lam(jnp.array(y_s), jnp.array(stim), mu * 0.02, beta * 1e-3, jnp.array(lam), 3.0, 0.7, phi, phi_cov,
+                                          jnp.array(mask), key, 7, N, jnp.array(powers), 2.0, 0.35, it, 1)
+        out["ul_lam_" + tag] = np.asarray(lam_new, dtype=np.float64)
+        out["ul_key_" + tag] = np.asarray(key_out)
+    out["ul_key_in"] = np.asarray(jr.PRNGKey(3))
+    out["ul_y"], out["ul_mu"], out["ul_beta"] = y_s, np.asarray(mu) * 0.02, np.asarray(beta) * 1e-3
     save("units", stim=stim, lam=lam, y=y, mask=mask, mu_prior=pri["mu"] + 0.5, **out)
 
 
@@ -191,6 +222,7 @@ def main():
     case_units(ref)
     case_tiny(ref)
     case_cfg1(ref)
+    case_cfg2(ref)
 
 
 if __name__ == "__main__":

@@ -297,17 +297,161 @@ def test_fit_batch_single_gpu_equals_direct():
                 assert np.array_equal(np.asarray(res[i], dtype=float), np.asarray(g[nm], dtype=float), equal_nan=True), nm
 
 
-def test_fit_batch_concurrent_fits_equal_serial():
-    """per_gpu_concurrency: several fits share the GPU from private contexts; every result equals the serial one bit for bit."""
-    from circuitmap_amd.batch import fit_batch
+def _assert_same_fit(a, b, what=""):
+    for i, nm in enumerate(OUT_NAMES):
+        np.testing.assert_array_equal(np.asarray(a[i], dtype=float), np.asarray(b[i], dtype=float), err_msg="%s %s" % (what, nm))
+
+
+def test_run_batch_bit_identical_to_serial(ctx):
+    """cm_caviar_run_batch: circuits of two different shapes in one call (-> two lock-step groups), false-negative scan on, every
+    circuit bit-identical to its own cm_caviar_run; a second batch on the same problem objects reproduces the first; histories."""
+    from circuitmap_amd.optimise.caviar import Problem, run_batch
+    shapes = [(40, 120), (120, 400), (40, 120), (120, 400), (40, 120), (120, 400), (120, 400)]
+    sims = [_sim_case(N, K, 700 + i)[0] for i, (N, K) in enumerate(shapes)]
+    pris = [default_priors(N) for N, _ in shapes]
+    pris[1]["beta"] = 2e1 * np.ones(120)                                  # per-circuit priors are honoured
+    opts = dict(iters=14, seed=2)
+    serial = []
+    for sim, pri in zip(sims, pris):
+        q = Problem(ctx, sim["psc"], sim["stim_matrix"])
+        q.run(*prior_args(pri), **opts)
+        serial.append(q.fetch())
+        q.close()
+    probs = [Problem(ctx, sim["psc"], sim["stim_matrix"]) for sim in sims]
+    tms = run_batch(probs, pris, **opts)
+    assert sorted(t.batch for t in tms) == [3, 3, 3, 4, 4, 4, 4]
+    for q, ref in zip(probs, serial):
+        _assert_same_fit(q.fetch(), ref, "batch")
+    run_batch(probs[::-1], pris[::-1], **opts)                            # again, other order: state fully re-initialised
+    for q, ref in zip(probs, serial):
+        _assert_same_fit(q.fetch(), ref, "second batch")
+    # histories through the batch path
+    hopts = dict(iters=5, seed=1, save_histories=True)
+    run_batch(probs[:3:2], [pris[0], pris[2]], **hopts)
+    for q, sim, pri in [(probs[0], sims[0], pris[0]), (probs[2], sims[2], pris[2])]:
+        q1 = Problem(ctx, sim["psc"], sim["stim_matrix"])
+        q1.run(*prior_args(pri), **hopts)
+        a, b = q.fetch(), q1.fetch()
+        for i in range(8):
+            np.testing.assert_array_equal(a[i], b[i])
+            np.testing.assert_array_equal(a[9 + i], b[9 + i])
+        q1.close()
+    for q in probs:
+        q.close()
+
+
+def test_fit_batch_baseline_config3():
+    """BASELINE configs[3]: the batch of 8 independent N=1000 / K=2000 circuits (seeds 2000..2007), 50 iterations + fn_scan, here
+    all on ONE GPU as one lock-step batch through batch.fit_batch; every circuit bit-identical to its direct caviar() call."""
+    from circuitmap_amd import batch
+    from circuitmap_amd.optimise import caviar
     circuits = []
-    for s_ in range(5):
-        sim, _ = _sim_case(120, 400, 300 + s_)
+    for c in range(8):
+        sim, pri = _sim_case(1000, 2000, 2000 + c)
         circuits.append((sim["psc"], sim["stim_matrix"]))
-    opts = dict(iters=12, seed=0)
-    serial = fit_batch(circuits, fit_options=opts)
-    conc = fit_batch(circuits, fit_options=opts, per_gpu_concurrency=3)
-    assert len(serial) == len(conc) == 5
-    for a, b in zip(serial, conc):
-        for k in ("mu", "beta", "shape", "rate", "phi", "phi_cov", "z"):
-            np.testing.assert_array_equal(np.asarray(a[k]), np.asarray(b[k]))
+    opts = dict(iters=50, seed=0)
+    got = batch.fit_batch(circuits, priors=pri, fit_options=opts)
+    assert len(got) == 8
+    for (psc, stim), g in zip(circuits, got):
+        res = caviar(psc, stim, *prior_args(pri), **opts)
+        for i, nm in enumerate(OUT_NAMES):
+            if nm != "lam":
+                np.testing.assert_array_equal(np.asarray(res[i], dtype=float), np.asarray(g[nm], dtype=float), err_msg=nm)
+        assert np.count_nonzero(res[0]) > 10                              # a real fit: connections were found
+
+
+def test_fit_batch_c_entry_point(ctx):
+    """cm_caviar_fit_batch (host arrays in, host results out, device list) and cm_caviar_fit == caviar()."""
+    from circuitmap_amd import _lib
+    from circuitmap_amd.optimise import caviar
+    from circuitmap_amd.optimise.caviar import make_options, _priors_struct
+    lib = ctx.lib
+    sims = [_sim_case(60, 150, 900 + i)[0] for i in range(3)]
+    pri = default_priors(60)
+    opts = dict(iters=9, seed=4)
+    o = make_options(lib, **opts)
+    keep = []
+    n = len(sims)
+    psc = [_lib.f64(s_["psc"]) for s_ in sims]
+    stim = [_lib.f64(s_["stim_matrix"]) for s_ in sims]
+    prs = (_lib.CmPriors * n)(*[_priors_struct(60, *prior_args(pri), keep) for _ in range(n)])
+    outs, res = [], (_lib.CmResult * n)()
+    for c in range(n):
+        out = dict(mu=np.empty(60), beta=np.empty(60), lam=np.empty((60, 150)), phi=np.empty((60, 2)), phi_cov=np.empty((60, 2, 2)), z=np.empty(150))
+        for k, v in out.items():
+            setattr(res[c], k, _lib.dptr(v))
+        outs.append(out)
+    i32 = lambda v: (C.c_int32 * n)(*v)
+    dpp = lambda arrs: (C.POINTER(C.c_double) * n)(*[_lib.dptr(a) for a in arrs])
+    _lib.check(lib.cm_caviar_fit_batch(n, i32([60] * n), i32([150] * n), i32([900] * n), dpp(psc), dpp(stim), prs, C.byref(o), None, 0, res, None))
+    for c in range(n):
+        ref = caviar(sims[c]["psc"], sims[c]["stim_matrix"], *prior_args(pri), **opts)
+        for i, nm in enumerate(["mu", "beta", "lam"]):
+            np.testing.assert_array_equal(outs[c][nm], ref[i], err_msg=nm)
+        assert res[c].shape == ref[3] and res[c].rate == ref[4]
+    # cm_caviar_fit: create + run + fetch + destroy in one call
+    one = dict(mu=np.empty(60), lam=np.empty((60, 150)), z=np.empty(150))
+    r1 = _lib.CmResult()
+    for k, v in one.items():
+        setattr(r1, k, _lib.dptr(v))
+    tm = _lib.CmTimings()
+    _lib.check(lib.cm_caviar_fit(ctx.handle, 60, 150, 900, _lib.dptr(psc[0]), _lib.dptr(stim[0]), C.byref(prs[0]), C.byref(o), C.byref(r1), C.byref(tm)))
+    ref = caviar(sims[0]["psc"], sims[0]["stim_matrix"], *prior_args(pri), **opts)
+    np.testing.assert_array_equal(one["mu"], ref[0]); np.testing.assert_array_equal(one["lam"], ref[2]); np.testing.assert_array_equal(one["z"], ref[7])
+    assert tm.iters == 9 and tm.batch == 1 and tm.total_ms > 0
+
+
+def test_phase_hooks_vs_golden(ctx):
+    """cm_k_sigma / cm_k_spont / cm_k_lam_sweep against the per-phase vectors recorded from the reference's source (units.npz):
+    update_sigma (caviar.py:238-244), the soft threshold at outer iterations 0, 5, 19, 20 (quirk 4: frozen from 20 on), one
+    update_lam sweep ungated and gated incl. the carried PRNG key (caviar.py:190-231)."""
+    from circuitmap_amd import _lib
+    lib = ctx.lib
+    g = np.load(GOLDEN + "/units.npz")
+    stim, lam, y = g["stim"], g["lam"], g["y"]
+    mask = np.ascontiguousarray(g["mask"].astype(np.uint8))
+    N, K = stim.shape
+    u8 = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint8))
+    mu, beta = np.ascontiguousarray(g["bum_mu"]), np.ascontiguousarray(g["bum_beta"])
+    sh, rt = C.c_double(), C.c_double()
+    _lib.check(lib.cm_k_sigma(ctx.handle, N, K, _lib.dptr(stim), _lib.dptr(lam), _lib.dptr(y), _lib.dptr(mu), _lib.dptr(beta), 1.0, 0.1,
+                              C.byref(sh), C.byref(rt)))
+    assert sh.value == g["sig_shape"] and abs(rt.value - g["sig_rate"]) <= 1e-12 * abs(g["sig_rate"])
+    for it in (0, 5, 19, 20):
+        z = np.zeros(K) + 0.123
+        sr = C.c_double()
+        _lib.check(lib.cm_k_spont(ctx.handle, N, K, _lib.dptr(stim), _lib.dptr(lam), _lib.dptr(y), u8(mask), _lib.dptr(mu), it, 20, 5.0, 0.75, 0.05,
+                                  0.1, _lib.dptr(z), C.byref(sr)))
+        assert rel_err(z, g["z_it%d" % it]) < 1e-12, it
+        assert np.array_equal(z != 0, g["z_it%d" % it] != 0) and sr.value == np.mean(g["z_it%d" % it] != 0)
+    pri = default_priors(N)
+    for tag, it in (("ungated", 0), ("gated", 5)):
+        lam_io = lam.copy()
+        key = np.ascontiguousarray(g["ul_key_in"].astype(np.uint32))
+        _lib.check(lib.cm_k_lam_sweep(ctx.handle, N, K, _lib.dptr(stim), _lib.dptr(lam_io), _lib.dptr(np.ascontiguousarray(g["ul_y"])), u8(mask),
+                                      _lib.dptr(np.ascontiguousarray(g["ul_mu"])), _lib.dptr(np.ascontiguousarray(g["ul_beta"])), 3.0, 0.7,
+                                      _lib.dptr(np.ascontiguousarray(g["phi"])), _lib.dptr(np.ascontiguousarray(g["phi_cov"])),
+                                      key.ctypes.data_as(C.POINTER(C.c_uint32)), 7, 2.0, 0.35, it, 1))
+        assert np.array_equal(key, g["ul_key_" + tag])
+        assert rel_err(lam_io, g["ul_lam_" + tag]) < 1e-10, tag
+        assert np.array_equal(lam_io != 0, g["ul_lam_" + tag] != 0)
+    assert np.any(g["ul_lam_gated"].sum(axis=1) == 0) and np.any(g["ul_lam_gated"] != g["ul_lam_ungated"])   # the gate did close rows
+
+
+def test_caviar_vs_golden_cfg2():
+    """BASELINE configs[1] shape (N=300, K=1000, T=900) against the vectors recorded from the reference's own source: first 12
+    iterations + false-negative scan, all per-iteration histories (lam stored on the support of the stimulus matrix)."""
+    from circuitmap_amd.optimise import caviar
+    g, psc, stim, pri, opts = load_case("caviar_cfg2")
+    res = caviar(psc, stim, *prior_args(pri), **opts)
+    sup = stim > 0
+    for i, nm in enumerate(OUT_NAMES):
+        got, hist = np.asarray(res[i], dtype=float), np.asarray(res[9 + i], dtype=float)
+        if nm == "lam":
+            assert not np.any(got[~sup]) and not np.any(hist[:, ~sup])
+            got, hist = got[sup], hist[:, sup]
+        if nm in ("shape", "rate"):
+            assert np.all(hist == hist[:, :1])
+            hist = hist[:, 0]
+        assert rel_err(got, g["out_" + nm]) < TOL_FINAL * 100, nm             # 12 iterations: still inside the amplified early phase
+        assert rel_err(hist, g["out_hist_" + nm]) < TOL_HIST, "hist " + nm

@@ -38,6 +38,26 @@ def test_fast_oracle_matches(name):
         assert rel_err(res[9 + i], g["out_hist_" + nm]) < 1e-6, "hist " + nm
 
 
+def test_oracle_vs_golden_cfg2():
+    """BASELINE configs[1] shape (N=300, K=1000, T=900; 12 iterations + fn_scan, histories) recorded from the reference's own source:
+    the literal oracle reproduces it bit for bit, the running-residual oracle to parity tolerance."""
+    g, psc, stim, pri, opts = load_case("caviar_cfg2")
+    sup = stim > 0
+    for literal in (True, False):
+        res = co.caviar(psc, stim, *prior_args(pri), literal=literal, **opts)
+        for i, nm in enumerate(OUT_NAMES):
+            got, hist = np.asarray(res[i], dtype=float), np.asarray(res[9 + i], dtype=float)
+            if nm == "lam":
+                assert not np.any(got[~sup]) and not np.any(hist[:, ~sup])
+                got, hist = got[sup], hist[:, sup]
+            if nm in ("shape", "rate"):
+                hist = hist[:, 0]
+            if literal:
+                assert np.array_equal(got, g["out_" + nm], equal_nan=True) and np.array_equal(hist, g["out_hist_" + nm], equal_nan=True), nm
+            else:
+                assert rel_err(got, g["out_" + nm]) < 1e-8 and rel_err(hist, g["out_hist_" + nm]) < 1e-6, nm
+
+
 def test_explicit_streams_reproduce_seeded_run():
     g, psc, stim, pri, opts = load_case("caviar_tiny")
     orders, u = threefry.make_explicit_streams(opts["seed"], opts["iters"], stim.shape[0], opts["num_mc_samples"])
@@ -70,6 +90,18 @@ def test_unit_phases_golden():
         z = co.estimate_spont_act_soft_thresh(y, mu, lam, it, 20, np.zeros(K) + 0.123, 5.0, mask, 0.75, 0.05, 0.1)
         assert np.array_equal(z, g["z_it%d" % it])
     assert np.all(g["z_it20"] == 0.123)          # quirk 4: no penalty step once it >= max_backtrack_iters
+    # update_lam (caviar.py:190-231) incl. the key it hands back: ungated (it <= delay_spont_est) and gated
+    for tag, it in (("ungated", 0), ("gated", 5)):
+        for lit in (True, False):
+            st = threefry.JaxLikeStream(3)
+            assert np.array_equal(st.key, g["ul_key_in"])
+            lam_new, _ = co.update_lam(g["ul_y"], stim, g["ul_mu"], g["ul_beta"], lam, 3.0, 0.7, g["phi"], g["phi_cov"], mask, st, it, 7, powers,
+                                       2.0, 0.35, 1, literal=lit)
+            assert np.array_equal(st.key, g["ul_key_" + tag])
+            if lit:
+                assert np.array_equal(lam_new, g["ul_lam_" + tag])
+            else:
+                assert rel_err(lam_new, g["ul_lam_" + tag]) < 1e-11
     rm, rb, rl, rz = co.reconnect_spont_cells(y, stim, lam, g["rec_mu_in"], beta, g["rec_z_in"], 0.3, 3)
     assert np.array_equal(rm, g["rec_mu"]) and np.array_equal(rb, g["rec_beta"], equal_nan=True)
     assert np.array_equal(rl, g["rec_lam"]) and np.array_equal(rz, g["rec_z"])
