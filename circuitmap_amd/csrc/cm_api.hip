@@ -72,6 +72,7 @@ static int ctx_init(cm_ctx* c, int device_id, void* hip_stream) {
   memset(c->h_pinned, 0, CM_MAILBOX_WORDS * sizeof(int32_t));
   CM_HIP(hipHostGetDevicePointer((void**)&c->d_mailbox, c->h_pinned, 0));
   c->use_mailbox = getenv("CAVIAR_HIP_NO_MAILBOX") == nullptr;
+  if (getenv("CAVIAR_HIP_TRACE_BLOCK0")) { CM_HIP(hipMalloc((void**)&c->dbg_block0, 64 * 8 * sizeof(long long))); CM_HIP(hipMemset(c->dbg_block0, 0, 64 * 8 * sizeof(long long))); }
   hipDeviceProp_t prop;
   CM_HIP(hipGetDeviceProperties(&prop, device_id));
   c->num_cus = prop.multiProcessorCount;
@@ -161,7 +162,7 @@ extern "C" int cm_problem_destroy(cm_problem* p) {
   hipSetDevice(p->ctx->device);
   hipStreamSynchronize(p->ctx->stream);
   void* ptrs[] = {p->y, p->ss, p->sum_y, p->vals, p->row_ptr, p->col, p->grp, p->rowcnt, p->col_ptr, p->csc_row, p->csc_pos,
-                  p->mask, p->slab, p->pslab, p->phi, p->phi_cov,
+                  p->mask, p->slab, p->pslab, p->phi, p->phi_cov, p->phi_dead,
                   p->R, p->colany, p->mcE, p->rs, p->act_idx, p->act_inv, p->n_act, p->orders_all, p->orders_tmp, p->inv_all, p->wtab,
                   p->keys, p->uexp, p->A, p->X, p->Lf, p->Dinv, p->rhs, p->seq_n, p->seq_off, p->seq_pos, p->chunk_first,
                   p->seq_meta, p->packed};
@@ -202,7 +203,7 @@ extern "C" int cm_problem_create(cm_ctx* ctx, int32_t N, int32_t K, int32_t T, c
   const size_t ld = p->ld;
   if ((rc = dmalloc(&p->mask, K)) || (rc = dmalloc(&p->slab, 2 * (size_t)N + K + (size_t)p->nnz)) ||
       (rc = dmalloc(&p->pslab, 8 * (size_t)N + CM_S_COUNT)) || (rc = dmalloc(&p->phi, 2 * (size_t)N)) ||
-      (rc = dmalloc(&p->phi_cov, 4 * (size_t)N)) || (rc = dmalloc(&p->R, K)) ||
+      (rc = dmalloc(&p->phi_cov, 4 * (size_t)N)) || (rc = dmalloc(&p->phi_dead, 6 * (size_t)N)) || (rc = dmalloc(&p->R, K)) ||
       (rc = dmalloc(&p->colany, K)) || (rc = dmalloc(&p->mcE, (size_t)N * CM_MAX_VALS)) ||
       (rc = dmalloc(&p->rs, 4 * (size_t)N)) || (rc = dmalloc(&p->act_idx, N)) || (rc = dmalloc(&p->act_inv, N)) ||
       (rc = dmalloc(&p->n_act, 4)) || (rc = dmalloc(&p->A, ld * ld)) || (rc = dmalloc(&p->X, ld * ld)) || (rc = dmalloc(&p->Lf, ld * ld)) ||
@@ -253,7 +254,7 @@ void cm_fill_pdev(const cm_problem* p, const cm_problem* r, int* mailbox, cm_pde
   d->y = p->y; d->ss = p->ss; d->sum_y = p->sum_y; d->vals = p->vals; d->row_ptr = p->row_ptr; d->col = p->col; d->grp = p->grp;
   d->rowcnt = p->rowcnt; d->col_ptr = p->col_ptr; d->csc_row = p->csc_row; d->csc_pos = p->csc_pos; d->mask = p->mask; d->colany = p->colany;
   d->lam = p->lam; d->mu = p->mu; d->beta = p->beta; d->phi = p->phi; d->phi_cov = p->phi_cov; d->scal = p->scal; d->R = p->R; d->z = p->z;
-  d->mcE = p->mcE; d->rs = p->rs; d->pslab = p->pslab; d->mu_prior = p->mu_prior; d->beta_prior = p->beta_prior; d->phi_prior = p->phi_prior;
+  d->mcE = p->mcE; d->rs = p->rs; d->phi_dead = p->phi_dead; d->phi_cov_dead = p->phi_dead ? p->phi_dead + 2 * (size_t)p->N : nullptr; d->pslab = p->pslab; d->mu_prior = p->mu_prior; d->beta_prior = p->beta_prior; d->phi_prior = p->phi_prior;
   d->phi_cov_prior = p->phi_cov_prior; d->act_idx = p->act_idx; d->act_inv = p->act_inv; d->n_act = p->n_act; d->seq_n = p->seq_n;
   d->seq_off = p->seq_off; d->seq_pos = p->seq_pos; d->chunk_first = p->chunk_first; d->seq_meta = p->seq_meta; d->packed = p->packed;
   d->A = p->A; d->X = p->X; d->Lf = p->Lf; d->Dinv = p->Dinv; d->rhs = p->rhs; d->mailbox = mailbox;
@@ -492,6 +493,14 @@ static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_option
   CM_TRY(set_build(ctx, &s));                        // descriptors (after the table allocations they point to)
   CM_TRY(upload_priors(ctx, s, prs));
   CM_TRY(cm_launch_init_state(ctx, s, o->y_xcorr_thresh));
+  // update_phi of an all-zero row depends only on the neuron's trial counts and priors: a per-run constant, produced once on the side
+  // stream (first needed by the k_iter_mid of iteration 0, half a millisecond from here) and copied by dead rows in every iteration
+  if (iters > 0) {
+    CM_HIP(hipEventRecord(ctx->ev[8], st));                          // priors are uploaded
+    CM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev[8], 0));
+    CM_TRY(cm_launch_phi_dead(ctx, s, ctx->side));
+    CM_HIP(hipEventRecord(ctx->ev[9], ctx->side));
+  }
   bool rng_deferred = false;
   hipEvent_t pending_ev[2] = {nullptr, nullptr};   // long RNG chunks whose event the main stream has not waited on yet
   int pending_from[2] = {0, 0}, n_pending = 0;     // first iteration each of them serves
@@ -574,6 +583,7 @@ static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_option
       if (pending_ev[q] && it + 1 >= pending_from[q]) { CM_HIP(hipStreamWaitEvent(st, pending_ev[q], 0)); pending_ev[q] = nullptr; }
     if (o->save_histories) for (cm_problem* q : s.ps) CM_TRY(record_hist(ctx, q, it, 0));   // mu, beta, lam of this iteration (:90-92)
     // :84-88 update_sigma, update_phi, z, spont_rate; then block_update_mu (small sets) and the MC logit of iteration it + 1
+    if (it == 0) CM_HIP(hipStreamWaitEvent(st, ctx->ev[9], 0));      // the dead-row constants (long done)
     if (timed) CM_HIP(hipEventRecord(EV(it, 8), st));
     CM_TRY(cm_launch_iter_mid(ctx, s, it, iters, S, o->rng_mode, o, 1, 1));
     if (timed) CM_HIP(hipEventRecord(EV(it, 9), st));
@@ -623,6 +633,15 @@ static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_option
       if (ctx->h_pinned[9]) { cm_set_error("weight precision matrix not positive definite (circuit %d of the set)", c); return CM_ERR_NOT_SPD; }
       if (ctx->h_pinned[10]) { cm_set_error("sweep ticket wait timed out (internal error, circuit %d of the set)", c); return CM_ERR_STATE; }
     }
+  }
+  if (ctx->dbg_block0) {
+    long long h[64 * 8];
+    if (hipMemcpy(h, ctx->dbg_block0, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess)
+      for (int it = 0; it < iters && it < 64; ++it) {
+        const long long* d = h + 8 * it;
+        fprintf(stderr, "it %2d: block 0: compaction %6.1f sigma %6.1f solve %6.1f (n = %lld) | block 1: z-loop %6.1f (passes to %lld), ends %+6.1f us after block 0\n",
+                it, (d[1] - d[0]) * 0.01, (d[2] - d[1]) * 0.01, d[4] ? (d[4] - d[2]) * 0.01 : 0.0, d[6], (d[3] - d[7]) * 0.01, d[5], d[4] ? (d[3] - d[4]) * 0.01 : 0.0);
+      }
   }
   if (trace_host)
     for (size_t i = 1; i < host_stamps.size(); ++i)

@@ -41,6 +41,7 @@ __device__ __forceinline__ void cm_col_dot16(int t, int K, const double* __restr
 // waves have retired; a retired wave no longer counts at s_barrier): the strided partial sums and their combination order are
 // then the same in every kernel that embeds these bodies, so a batched launch reproduces the single-circuit results bit for bit.
 #define CM_POST_THREADS 256
+#define CM_Z_SPEC 8            // soft-threshold passes evaluated per barrier pair (post_single_body)
 
 // sum over the first `nthr` threads of the workgroup, result valid in every one of them
 __device__ __forceinline__ double block_sum(double v, double* sh, int nthr) {
@@ -70,12 +71,19 @@ __device__ __forceinline__ int post_single_body(const double* __restrict__ y, co
                                                  int it, int max_iters, double penalty, double scale_factor, double tol,
                                                  int do_sigma, int seq, int* __restrict__ act_idx, int* __restrict__ act_inv,
                                                  int* __restrict__ n_act, int* mailbox, double* __restrict__ z,
-                                                 double* __restrict__ scal, double* lds_scratch = nullptr) {
+                                                 double* __restrict__ scal, double* lds_scratch = nullptr, long long* dbg = nullptr,
+                                                 int parts = 3) {
+  // parts: 1 = the active set and update_sigma, 2 = the soft threshold and spont_rate.  The two halves share no data (rs, mu,
+  // beta vs y - R, colany, mask), so the fused mid-iteration kernel runs them in two workgroups side by side; each half sums in
+  // the same order whether it runs alone or after the other.
   __shared__ double sh[16];
   __shared__ int wave_cnt[16];
   __shared__ int base;
   constexpr int nthr_ = CM_POST_THREADS;
+  int n_active = 0;
+  if (parts & 1) {
   // ---- 1. active set
+  if (dbg && threadIdx.x == 0) dbg[0] = wall_clock64();
   if (threadIdx.x == 0) base = 0;
   __syncthreads();
   {
@@ -115,7 +123,8 @@ __device__ __forceinline__ int post_single_body(const double* __restrict__ y, co
     }
   }
   __syncthreads();
-  const int n_active = base;
+  n_active = base;
+  if (dbg && threadIdx.x == 0) dbg[1] = wall_clock64();
   if (!do_sigma) return n_active;
   // ---- 2. update_sigma
   double a = 0.0;
@@ -131,6 +140,10 @@ __device__ __forceinline__ int post_single_body(const double* __restrict__ y, co
     scal[CM_S_SHAPE] = scal[CM_S_SHAPE_PRIOR] + (double)K / 2.0;
     scal[CM_S_RATE] = scal[CM_S_RATE_PRIOR] + 0.5 * (a - b + c);
   }
+  if (dbg && threadIdx.x == 0) dbg[2] = wall_clock64();
+  }   // parts & 1
+  if (!(parts & 2) || !do_sigma) return n_active;
+  if (dbg && threadIdx.x == 0) dbg[7] = wall_clock64();
   // ---- 3. estimate_spont_act_soft_thresh.  The residual and the "blocked" flag (column has a confident spike, or trial
   // masked out) do not change across the penalty steps: with LDS scratch they are staged once and the up-to-20 steps run
   // out of LDS instead of re-reading four global arrays each.
@@ -147,24 +160,53 @@ __device__ __forceinline__ int post_single_body(const double* __restrict__ y, co
   }
   // z itself is only needed from the LAST pass: the passes accumulate the error norm, and z is written once afterwards with the
   // penalty of that last pass (a store to z in every pass puts a global-store round trip inside each of up to 20 barriers).
+  // The passes form a chain only through the loop test (the penalties pen_j = penalty * scale^j do not depend on the data): up to
+  // CM_Z_SPEC consecutive passes are evaluated together -- every thread keeps one error accumulator per pass over its trials, one
+  // barrier pair reduces them all -- and the sequential loop is then replayed on the results.  Each pass's error is summed
+  // exactly as a pass on its own would sum it (same strided order per thread, same wave and block trees), so z, spont_rate and
+  // the pass count are bit for bit those of the one-pass-at-a-time loop, at 1/8 of its barriers.
   bool ran = false;
   double last_pen = pen;
+  __shared__ double zsh[CM_Z_SPEC][CM_POST_THREADS / CM_WAVE];
   while (itc < max_iters && err > tol) {
-    double e = 0.0;
+    const int np = (max_iters - itc) < CM_Z_SPEC ? (max_iters - itc) : CM_Z_SPEC;
+    double pens[CM_Z_SPEC], e[CM_Z_SPEC];
+    {
+      double pp = pen;
+#pragma unroll
+      for (int j = 0; j < CM_Z_SPEC; ++j) { pens[j] = pp; pp *= scale_factor; e[j] = 0.0; }
+    }
     for (int k = threadIdx.x; k < K; k += nthr_) {
       const double resid = staged ? rl[k] : y[k] - R[k];
       const bool blocked = staged ? (bl[k] != 0) : (colany[k] || !mask[k]);
-      double zz = resid < pen ? 0.0 : resid - pen;                       // :154
-      zz = zz < 0.0 ? 0.0 : zz;                                          // :155
-      zz = blocked ? 0.0 : zz;                                           // :156-157
-      const double d = resid - zz;
-      e = fma(d, d, e);                                                  // :158
+#pragma unroll
+      for (int j = 0; j < CM_Z_SPEC; ++j) {
+        double zz = resid < pens[j] ? 0.0 : resid - pens[j];               // :154
+        zz = zz < 0.0 ? 0.0 : zz;                                          // :155
+        zz = blocked ? 0.0 : zz;                                           // :156-157
+        const double d = resid - zz;
+        e[j] = fma(d, d, e[j]);                                            // :158
+      }
     }
-    err = block_sum(e, sh, nthr_) / ysq;
-    ++itc;
-    last_pen = pen;
-    ran = true;
-    pen *= scale_factor;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < CM_Z_SPEC; ++j) {
+      const double v = cm_wave_sum(e[j]);
+      if (threadIdx.x % CM_WAVE == 0) zsh[j][threadIdx.x / CM_WAVE] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < CM_Z_SPEC; ++j) {
+      if (j < np && (j == 0 || err > tol)) {                               // pass j runs iff the loop test held after pass j - 1
+        double t = 0.0;
+        for (int w = 0; w < nthr_ / CM_WAVE; ++w) t += zsh[j][w];
+        err = t / ysq;
+        ++itc;
+        last_pen = pens[j];
+        ran = true;
+        pen = pens[j] * scale_factor;
+      }
+    }
   }
   double cnt = 0.0;
   if (ran) {
@@ -182,6 +224,7 @@ __device__ __forceinline__ int post_single_body(const double* __restrict__ y, co
   }
   cnt = block_sum(cnt, sh, nthr_);
   if (threadIdx.x == 0) scal[CM_S_SPONT_RATE] = cnt / (double)K;
+  if (dbg && threadIdx.x == 0) { dbg[3] = wall_clock64(); dbg[5] = itc; }
   return n_active;
 }
 
@@ -217,15 +260,29 @@ __device__ __forceinline__ void inv2x2(double h11, double h12, double h21, doubl
   o[1] = (r0 - b * x1) * ra; o[3] = x1;
 }
 
+// negloglik_with_barrier (caviar.py:312-316) on the sufficient statistics of one stimulus value per lane.  Instruction count is
+// what bounds this path (it sits on the 10-step Newton chain of every neuron), so the four logarithms of the literal form
+// are reduced to two, with the per-element nan_to_num classes of the reference kept exact:
+//   * log(s) and log(1 - s), s = sigmoid(x), come from ONE logarithm: for x > 0  ls = log(s), l1s = ls - x; otherwise
+//     l1s = log(1 - s), ls = l1s + x (log(1 - s) = log(s) - x identically; each branch takes the logarithm of the operand that is
+//     not small, so the result is at least as accurate as the literal pair).  s == 1 and s == 0 -- the saturated sigmoid, where
+//     the literal form produces log(0) = -inf and nan_to_num turns the element into -DBL_MAX (quirk 11) -- are restored by hand;
+//   * the barrier's log(phi_0) + log(phi_1) is evaluated by two lanes of the segment in one instruction stream (lane 0: phi_0,
+//     lane 1: phi_1) and enters the segment sum; negative phi gives NaN as in the literal form.
 template <int SEG>
 __device__ __forceinline__ double phi_nll(double p0, double p1, double val, double n0, double n1, double smid, double nmid,
-                                          bool lane_on, double pr0, double pr1, const double prec[4], double t, double* sig_out) {
+                                          bool lane_on, int g, double pr0, double pr1, const double prec[4], double t, double* sig_out) {
   double tot = 0.0;
   *sig_out = 0.0;
   if (lane_on) {
-    const double s = cm_sigmoid(p0 * val - p1);
+    const double x = p0 * val - p1;
+    const double s = cm_sigmoid(x);
     *sig_out = s;
-    const double ls = log(s), l1s = log(1.0 - s);
+    const bool pos = x > 0.0;
+    const double la = log(pos ? s : 1.0 - s);
+    double ls = pos ? la : la + x, l1s = pos ? la - x : la;
+    if (s == 1.0) l1s = -INFINITY;                     // log(1 - s) = log(0)
+    if (s == 0.0) ls = -INFINITY;                      // log(s) = log(0)
     if (n0 > 0.0) tot += n0 * cm_nan_to_num(0.0 * ls + 1.0 * l1s);
     if (n1 > 0.0) tot += n1 * cm_nan_to_num(1.0 * ls + 0.0 * l1s);
     if (nmid > 0.0) {
@@ -233,10 +290,18 @@ __device__ __forceinline__ double phi_nll(double p0, double p1, double val, doub
       else tot += nmid * cm_nan_to_num(0.5 * ls + 0.5 * l1s);
     }
   }
-  tot = cm_seg_sum<SEG>(tot);
+  double barrier;
+  if (SEG >= 2) {
+    tot += log(g == 0 ? p0 : (g == 1 ? p1 : 1.0)) / t;  // lanes 0, 1 of the segment: log(phi_0) / t, log(phi_1) / t; the others add log(1) = 0
+    tot = cm_seg_sum<SEG>(tot);
+    barrier = 0.0;
+  } else {
+    tot = cm_seg_sum<SEG>(tot);
+    barrier = (log(p0) + log(p1)) / t;
+  }
   const double d0 = p0 - pr0, d1 = p1 - pr1;
   const double quad = d0 * (prec[0] * d0 + prec[1] * d1) + d1 * (prec[2] * d0 + prec[3] * d1);
-  return -tot - (log(p0) + log(p1)) / t + 0.5 * quad;
+  return -tot - barrier + 0.5 * quad;
 }
 
 // One wavefront per neuron.  SEG = lanes per evaluation point (power of two >= V; lane g of a segment owns stimulus
@@ -244,7 +309,9 @@ __device__ __forceinline__ double phi_nll(double p0, double p1, double val, doub
 // right-hand side of the Armijo test) while segments 1..E-1 evaluate it at phi + 2^-b v for consecutive b, so the
 // reference's sequential backtracking (caviar.py:259-268: accept the first b whose test passes, at most 40 halvings)
 // collapses into one parallel evaluation per Newton step in the common case.
-template <int SEG>
+// DEAD = true: the row is taken to be identically zero (no scan of lam): the result then depends only on the trial counts and the
+// priors of the neuron, i.e. it is a per-run constant -- computed once (k_phi_dead) and copied by rows that are all zero.
+template <int SEG, bool DEAD = false>
 __device__ __forceinline__ void phi_body(int n, int lane, const double* __restrict__ lam, const int* __restrict__ row_ptr,
                                          const uint8_t* __restrict__ grp, const int* __restrict__ rowcnt,
                                          const double* __restrict__ vals, int V,
@@ -258,7 +325,7 @@ __device__ __forceinline__ void phi_body(int n, int lane, const double* __restri
   const double val = on ? vals[g] : 0.0;
   const double cnt = on ? (double)rowcnt[(size_t)n * CM_MAX_VALS + g] : 0.0;
   double n1 = 0.0, nmid = 0.0, smid = 0.0;
-  if (on && val > 0.0) {                       // untargeted values carry lam == 0 on every trial
+  if (!DEAD && on && val > 0.0) {              // untargeted values carry lam == 0 on every trial
     for (int e = row_ptr[n] + ev; e < row_ptr[n + 1]; e += E) {
       if (grp[e] != g) continue;
       const double l = lam[e];
@@ -310,7 +377,7 @@ __device__ __forceinline__ void phi_body(int n, int lane, const double* __restri
       const double st = is_f0 ? 0.0 : ldexp(1.0, -b);
       const double q0 = is_f0 ? p0 : p0 + st * v0, q1 = is_f0 ? p1 : p1 + st * v1;
       double sg;
-      const double fv = phi_nll<SEG>(q0, q1, val, n0, n1, smid, nmid, on, pr0, pr1, prec, t, &sg);
+      const double fv = phi_nll<SEG>(q0, q1, val, n0, n1, smid, nmid, on, g, pr0, pr1, prec, t, &sg);
       if (first) f0 = cm_readlane_f64(fv, 0);
       const double rhs = f0 + alpha * st * Jv;
       const bool ok = !is_f0 && b <= 39 && !(isnan(fv) || fv > rhs);
@@ -470,11 +537,19 @@ __device__ __forceinline__ void mc_logit_body(int n, int m, int lane, double mea
   for (int j = lane; j < 2 * S; j += CM_WAVE) {
     const bool second = j & 1;
     const double c = second ? c1 : c0, sd = second ? sd1 : sd0, mean = second ? mean1 : mean0;
-    const double u = uexp ? uexp[j] : cm_uniform64(k0, k1, j, S);
-    const double arg = c + u * (1.0 - c);                      // caviar.py:212
     double q;
-    if (FULL) q = normcdfinv(arg);
-    else q = (arg == u) ? wrow[j] : cm_quantile_slow(arg);
+    if (!FULL && c < 0x1p-106) {
+      // c is below half an ulp of every u >= 2^-52, the smallest non-zero uniform: arg = c + u (1 - c) is u bit for bit and
+      // ndtri(arg) is the tabulated w -- without generating u at all (20 threefry rounds per draw).  The one exception, u == 0
+      // (arg = c), is recognisable from the table itself: w = ndtri(0) = -inf.
+      const double w = wrow[j];
+      q = (w == -INFINITY && c != 0.0) ? cm_quantile_slow(c) : w;
+    } else {
+      const double u = uexp ? uexp[j] : cm_uniform64(k0, k1, j, S);
+      const double arg = c + u * (1.0 - c);                      // caviar.py:212
+      if (FULL) q = normcdfinv(arg);
+      else q = (arg == u) ? wrow[j] : cm_quantile_slow(arg);
+    }
     mc[j] = q * sd + mean;
   }
   // same-wave LDS write -> read: the LDS pipe is in order for one wave; the (free) wave barrier keeps the compiler from moving the

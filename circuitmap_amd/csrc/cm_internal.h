@@ -37,7 +37,7 @@ struct cm_ctx {
   hipStream_t stream = nullptr;
   hipStream_t side = nullptr;     // side stream: update_phi(it) -> MC logit(it + 1), overlapped with sigma/z and the next solve
   bool own_stream = false;
-  hipEvent_t ev[8] = {};
+  hipEvent_t ev[10] = {};
   int32_t* h_pinned = nullptr;   // host-mapped pinned memory: words [0..1] = 64-bit mailbox (seq | flag | active-set size); [8..11] scratch for copies
   int32_t* d_mailbox = nullptr;  // device address of h_pinned
   int mail_seq = 0;
@@ -47,6 +47,7 @@ struct cm_ctx {
   void* h_stage = nullptr;        // pinned staging buffer (priors upload, fn_scan round trip), grown on demand
   size_t h_stage_bytes = 0;
   size_t lds_attr[48] = {};       // dynamic-LDS caps already raised for this context's device, by kernel slot (cm_raise_lds)
+  long long* dbg_block0 = nullptr; // diagnostic buffer (CAVIAR_HIP_TRACE_BLOCK0): 64 launches x 8 device-clock stamps
   void* d_pdev = nullptr;         // descriptors of the current batch (device) and their pinned source
   void* h_pdev = nullptr;
   size_t pdev_cap = 0;
@@ -91,6 +92,7 @@ struct cm_problem {
   double* beta_prior = nullptr; // [N]
   double* phi = nullptr;      // [N*2]
   double* phi_cov = nullptr;  // [N*4]
+  double* phi_dead = nullptr; // [N*6] update_phi result of neuron n if its lam row is identically zero: phi [N*2] | phi_cov [N*4]
   double* phi_prior = nullptr;
   double* phi_cov_prior = nullptr;
   double* scal = nullptr;     // [16] device scalars, see CM_S_*
@@ -150,6 +152,7 @@ struct cm_pdev {
   const int *rowcnt, *col_ptr, *csc_row, *csc_pos;
   uint8_t *mask, *colany;
   double *lam, *mu, *beta, *phi, *phi_cov, *scal, *R, *z, *mcE, *rs;
+  double *phi_dead, *phi_cov_dead;   // update_phi of an all-zero row, per neuron: constant over a run (k_phi_dead)
   const double *pslab, *mu_prior, *beta_prior, *phi_prior, *phi_cov_prior;
   int *act_idx, *act_inv, *n_act, *seq_n, *seq_off, *seq_pos, *chunk_first, *seq_meta;
   void* packed;
@@ -353,4 +356,5 @@ int cm_launch_stats(cm_ctx* ctx, cm_set& s, double spont_orthogonality);
 int cm_launch_post_single(cm_ctx* ctx, cm_set& s, int it, const cm_options* o, int do_sigma);
 int cm_wait_active(cm_ctx* ctx, cm_set& s);
 int cm_launch_update_phi(cm_ctx* ctx, cm_set& s, hipStream_t st);
+int cm_launch_phi_dead(cm_ctx* ctx, cm_set& s, hipStream_t st);
 

@@ -1,11 +1,11 @@
 // The middle of a CAVIaR iteration as ONE launch on ONE stream, two roles:
 //
-//   block 0       everything that is a single-workgroup reduction, back to back (on its first CM_POST_THREADS threads):
+//   block 0       single-workgroup reductions, back to back (on its first CM_POST_THREADS threads):
 //                 active-set compaction -> size posted to the host mailbox -> update_sigma (caviar.py:238-244) ->
-//                 soft threshold + spont_rate (:147-163, :88) -> block_update_mu of the NEXT iteration (:166-172) when the
-//                 active set fits the in-LDS solver (otherwise the host, which has the size from the mailbox, launches
-//                 the tiled factorisation after this kernel);
-//   blocks 1..    one wavefront per neuron: update_phi (:246-316) immediately followed by the Monte-Carlo logit of the
+//                 block_update_mu of the NEXT iteration (:166-172) when the active set fits the in-LDS solver (otherwise the
+//                 host, which has the size from the mailbox, launches the tiled factorisation after this kernel);
+//   block 1       soft threshold + spont_rate (:147-163, :88): shares no data with block 0, so it runs beside it;
+//   blocks 2..    one wavefront per neuron: update_phi (:246-316) immediately followed by the Monte-Carlo logit of the
 //                 NEXT iteration for that neuron (:209-215), which needs only that neuron's new phi.
 //
 // Neither role reads what the other writes (sigma/z/mu/beta vs phi/mcE), so they overlap inside the launch without
@@ -23,32 +23,51 @@
 
 struct IterDyn {     // what changes from iteration to iteration (common to all circuits of a batch)
   int it, max_iters; double penalty, scale_factor, tol; int do_sigma, seq, do_solve, stage_ok, do_phi, do_mc, S, roles, nx, explicit_rng;
+  long long* dbg;      // diagnostic (CAVIAR_HIP_TRACE_BLOCK0): device clock at the phase boundaries of block 0, 8 words per launch
 };
 
 template <bool BATCH, int SEG, bool FULLMC>
 __global__ __launch_bounds__(BATCH ? CM_ITER_THREADS_BATCH : CM_ITER_THREADS) void k_iter_mid(cm_parg<BATCH> pa, IterDyn a) {
   extern __shared__ double sm[];
   const cm_pdev& p = pa.get();
-  if (blockIdx.x == 0) {
+  if (blockIdx.x <= 1) {
     if (!(a.roles & 1)) return;
     if (threadIdx.x >= CM_POST_THREADS) return;
+    if (blockIdx.x == 1) {                               // soft threshold + spont_rate: its own workgroup, beside block 0
+      if (a.do_sigma)
+        post_single_body(p.y, p.R, p.colany, p.mask, p.mu, p.beta, p.rs, p.sum_y, p.N, p.K, a.it, a.max_iters, a.penalty, a.scale_factor, a.tol,
+                         a.do_sigma, a.seq, p.act_idx, p.act_inv, p.n_act, p.mailbox, p.z, p.scal, a.stage_ok ? sm : nullptr, a.dbg, 2);
+      return;
+    }
     const int n = post_single_body(p.y, p.R, p.colany, p.mask, p.mu, p.beta, p.rs, p.sum_y, p.N, p.K, a.it, a.max_iters, a.penalty,
                                    a.scale_factor, a.tol, a.do_sigma, a.seq, p.act_idx, p.act_inv, p.n_act, p.mailbox, p.z, p.scal,
-                                   a.stage_ok ? sm : nullptr);
+                                   nullptr, a.dbg, 1);
     if (a.do_solve && n <= p.small_cap) {
       __syncthreads();
       solve_small_body(sm, p.lam, p.row_ptr, p.col, p.act_idx, p.rs, p.scal, p.mu_prior, p.beta_prior, n, p.N, n * p.max_row_len, p.mu,
                        p.beta, p.n_act + 1, CM_POST_THREADS);
     }
+    if (a.dbg && threadIdx.x == 0) { a.dbg[4] = wall_clock64(); a.dbg[6] = n; }
     return;
   }
   if (!(a.roles & 2)) return;
   const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE;
-  const int n = ((int)blockIdx.x - 1) * (int)(blockDim.x / CM_WAVE) + wave;
+  const int n = ((int)blockIdx.x - 2) * (int)(blockDim.x / CM_WAVE) + wave;
   const int N = p.N;
   if (n >= N) return;
   double pc[4];
-  if (a.do_phi) {
+  if (a.do_phi && p.rs[(size_t)n * 4 + 3] < 0.0) {
+    // the row is identically zero (k_stats of this iteration): its update_phi is the per-run constant of this neuron
+    const double* __restrict__ pd = p.phi_dead + 2 * (size_t)n;
+    const double* __restrict__ cd = p.phi_cov_dead + 4 * (size_t)n;
+    pc[0] = pd[0]; pc[1] = pd[1];
+    const double c1 = cd[1], c2 = cd[2];
+    pc[2] = cd[0]; pc[3] = cd[3];
+    if (lane == 0) {
+      p.phi[2 * n] = pc[0]; p.phi[2 * n + 1] = pc[1];
+      p.phi_cov[4 * n] = pc[2]; p.phi_cov[4 * n + 1] = c1; p.phi_cov[4 * n + 2] = c2; p.phi_cov[4 * n + 3] = pc[3];
+    }
+  } else if (a.do_phi) {
     phi_body<SEG>(n, lane, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, pc);
   } else {
     pc[0] = p.phi[2 * n]; pc[1] = p.phi[2 * n + 1]; pc[2] = p.phi_cov[4 * n]; pc[3] = p.phi_cov[4 * n + 3];
@@ -72,17 +91,30 @@ int cm_small_cap(const cm_problem* p) {
 }
 
 template <int SEG, bool FULLMC>
-static int launch_iter2(cm_ctx* ctx, cm_set& s, const IterDyn& a, size_t lds, int blocks) {
+static int launch_iter2(cm_ctx* ctx, cm_set& s, const IterDyn& a0, size_t lds, int blocks, size_t lds_waves) {
   const int slot = CM_LDS_ITER + 4 * (31 - __builtin_clz((unsigned)SEG)) + (FULLMC ? 1 : 0) + (s.B > 1 ? 2 : 0);          // SEG = 1, 2, 4 .. 64
   if (s.B == 1) CM_TRY(cm_raise_lds(ctx, slot, reinterpret_cast<const void*>(k_iter_mid<false, SEG, FULLMC>), lds, 48 * 1024));
   else CM_TRY(cm_raise_lds(ctx, slot, reinterpret_cast<const void*>(k_iter_mid<true, SEG, FULLMC>), lds, 48 * 1024));
-  CM_LAUNCH_SET_T(k_iter_mid, (SEG, FULLMC), s, blocks, (s.B == 1 ? CM_ITER_THREADS : CM_ITER_THREADS_BATCH), lds, ctx->stream, a);
+  static const int batch_split = getenv("CAVIAR_HIP_BATCH_SPLIT") ? atoi(getenv("CAVIAR_HIP_BATCH_SPLIT")) : 0;
+  if (s.B > 1 && batch_split > 0 && a0.roles == 3) {
+    // diagnostic: the two roles of a batch as two launches; the per-neuron role in workgroups of `batch_split` threads with only its own LDS
+    IterDyn a = a0;
+    const int thr = batch_split, waves = thr / CM_WAVE, N = s.lead->N;
+    a.roles = 1;
+    CM_LAUNCH_SET_T(k_iter_mid, (SEG, FULLMC), s, 2, CM_ITER_THREADS_BATCH, lds, ctx->stream, a);
+    a.roles = 2;
+    CM_LAUNCH_SET_T(k_iter_mid, (SEG, FULLMC), s, 2 + (N + waves - 1) / waves, thr, (size_t)waves * lds_waves, ctx->stream, a);
+    CM_HIP(hipGetLastError());
+    return CM_OK;
+  }
+  CM_LAUNCH_SET_T(k_iter_mid, (SEG, FULLMC), s, blocks, (s.B == 1 ? CM_ITER_THREADS : CM_ITER_THREADS_BATCH), lds, ctx->stream, a0);
   CM_HIP(hipGetLastError());
   return CM_OK;
 }
 template <int SEG>
 static int launch_iter(cm_ctx* ctx, cm_set& s, const IterDyn& a, size_t lds, int blocks) {
-  return a.it < 0 ? launch_iter2<SEG, true>(ctx, s, a, lds, blocks) : launch_iter2<SEG, false>(ctx, s, a, lds, blocks);
+  const size_t lw = 2 * (size_t)a.S * sizeof(double);
+  return a.it < 0 ? launch_iter2<SEG, true>(ctx, s, a, lds, blocks, lw) : launch_iter2<SEG, false>(ctx, s, a, lds, blocks, lw);
 }
 
 // it = -1: state init (no sigma / phi; MC logit and solve for iteration 0).  Otherwise the middle of iteration `it`.
@@ -97,13 +129,14 @@ int cm_launch_iter_mid(cm_ctx* ctx, cm_set& s, int it, int iters, int S, int rng
   a.do_phi = do_phi; a.do_mc = nxt < iters; a.S = S;
   a.nx = a.do_mc ? nxt : 0;
   a.explicit_rng = rng_mode == CM_RNG_EXPLICIT;
+  a.dbg = (ctx->dbg_block0 && it >= 0 && it < 64) ? ctx->dbg_block0 + 8 * it : nullptr;
   const int threads = s.B == 1 ? CM_ITER_THREADS : CM_ITER_THREADS_BATCH;
   const int waves = threads / CM_WAVE;
   size_t lds = (size_t)waves * 2 * S * sizeof(double);
   lds = std::max(lds, s.small_lds_max);
   a.stage_ok = 0;
   if ((size_t)p->K * 9 + 16 <= 56 * 1024) { lds = std::max(lds, (size_t)p->K * 9 + 16); a.stage_ok = 1; }   // residual + flag per trial
-  const int blocks = 1 + ((do_phi || a.do_mc) ? (N + waves - 1) / waves : 0);
+  const int blocks = 2 + ((do_phi || a.do_mc) ? (N + waves - 1) / waves : 0);
   const int V = p->V;
   static const bool split = getenv("CAVIAR_HIP_SPLIT_ITER") != nullptr;         // diagnostic: one launch per role (profiling only)
   a.roles = roles;

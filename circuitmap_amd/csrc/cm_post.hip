@@ -123,6 +123,34 @@ __global__ __launch_bounds__(256) void k_update_phi(cm_parg<BATCH> pa) {
   phi_body<SEG>(n, threadIdx.x % CM_WAVE, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, out);
 }
 
+// the per-run constants: update_phi of neuron n for an all-zero lam row -> phi_dead / phi_cov_dead
+template <bool BATCH, int SEG>
+__global__ __launch_bounds__(256) void k_phi_dead(cm_parg<BATCH> pa) {
+  const cm_pdev& p = pa.get();
+  const int n = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE;
+  if (n >= p.N) return;
+  double out[4];
+  phi_body<SEG, true>(n, threadIdx.x % CM_WAVE, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi_dead,
+                      p.phi_cov_dead, out);
+}
+template <int SEG>
+static void launch_phi_dead(cm_set& s, hipStream_t st) {
+  CM_LAUNCH_SET_T(k_phi_dead, (SEG), s, (unsigned)((s.lead->N + 3) / 4), 256, 0, st);
+}
+int cm_launch_phi_dead(cm_ctx* ctx, cm_set& s, hipStream_t st) {
+  (void)ctx;
+  const int V = s.lead->V;
+  if (V <= 1) launch_phi_dead<1>(s, st);
+  else if (V <= 2) launch_phi_dead<2>(s, st);
+  else if (V <= 4) launch_phi_dead<4>(s, st);
+  else if (V <= 8) launch_phi_dead<8>(s, st);
+  else if (V <= 16) launch_phi_dead<16>(s, st);
+  else if (V <= 32) launch_phi_dead<32>(s, st);
+  else launch_phi_dead<64>(s, st);
+  CM_HIP(hipGetLastError());
+  return CM_OK;
+}
+
 template <int SEG>
 static void launch_phi(cm_set& s, hipStream_t st) {
   CM_LAUNCH_SET_T(k_update_phi, (SEG), s, (unsigned)((s.lead->N + 3) / 4), 256, 0, st);
