@@ -183,12 +183,13 @@ __host__ __device__ static inline size_t small_lds_bytes(int n, int tot_cap) {
 }
 
 // Which solver handles block_update_mu for an active set of `na` rows (host and device agree by construction):
-//   0  nothing to do here: na <= skip_le, the fused mid-iteration kernel has already solved it in LDS
-//   1  the one-workgroup LDS solver (k_solve_small)
-//   2  the tiled factorisation (na == 0: only its prior fill)
-__host__ __device__ static inline int cm_solve_kind(int na, int skip_le, int max_row_len) {
-  if (na <= skip_le) return 0;
-  if (na > 0 && na <= CM_SMALL_MAX && small_lds_bytes(na, na * max_row_len) <= 150 * 1024) return 1;
+//   0  nothing to do here: the fused mid-iteration kernel has already solved it in LDS (`skip_solved`)
+//   1  the one-workgroup LDS solver (sweep-operator inverse, ~10 + 2 n microseconds: small sets only)
+//   2  the tiled factorisation (~50 microseconds for one tile, + ~8 per further tile row)
+// `small_cap` is the circuit's largest LDS-solved set (cm_small_cap): the measured crossover of the two, bounded by the LDS budget.
+#define CM_FUSED_SOLVE_MAX 24
+__host__ __device__ static inline int cm_solve_kind(int na, int small_cap, bool skip_solved) {
+  if (na <= small_cap) return skip_solved ? 0 : 1;
   return 2;
 }
 

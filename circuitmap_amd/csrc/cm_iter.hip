@@ -85,7 +85,7 @@ __global__ __launch_bounds__(BATCH ? CM_ITER_THREADS_BATCH : CM_ITER_THREADS) vo
 // largest active set the fused kernel may solve in LDS (0 = never): A (n x (n+1)) + staged rows must fit beside the statics
 int cm_small_cap(const cm_problem* p) {
   int cap = 0;
-  for (int n = 1; n <= 64; ++n)                 // 64: steady-state active sets fit, and the LDS footprint stays ~50 KB per block
+  for (int n = 1; n <= CM_FUSED_SOLVE_MAX; ++n)   // steady-state active sets fit; beyond ~24 rows the tiled solve is faster than n sequential pivots
     if (small_lds_bytes(n, n * p->max_row_len) <= 56 * 1024) cap = n; else break;
   return cap;
 }

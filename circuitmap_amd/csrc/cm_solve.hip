@@ -20,7 +20,7 @@
 #define CM_SOLVE_PROLOGUE(KIND)                                                   \
   const cm_pdev& p = pa.get();                                                    \
   const int na = BATCH ? p.n_act[0] : na_arg;                                     \
-  if (BATCH && cm_solve_kind(na, skip_own ? p.small_cap : -1, p.max_row_len) != (KIND)) return;       \
+  if (BATCH && cm_solve_kind(na, p.small_cap, skip_own != 0) != (KIND)) return;       \
   const int nblk = (na + TS - 1) / TS, ld = nblk * TS;                            \
   (void)nblk; (void)ld;
 #define CM_LARGE_TILES 48     // more tile rows than this: panel solve + lean trailing-update kernels (bandwidth-bound regime)
@@ -321,9 +321,9 @@ __global__ __launch_bounds__(256) void k_chol_first(cm_parg<BATCH> pa, int na_ar
 
 // panel solve for large matrices: Lf[i][j] = A[i][j] * L_jj^-T for i > j   (one 256-thread workgroup per tile row)
 template <bool BATCH>
-__global__ __launch_bounds__(256) void k_chol_trsm(cm_parg<BATCH> pa, int na_arg, int skip_own, int j) {
+__global__ __launch_bounds__(256) void k_chol_trsm(cm_parg<BATCH> pa, int na_arg, int skip_own, int j, int large_min) {
   CM_SOLVE_PROLOGUE(2)
-  if (nblk <= CM_LARGE_TILES || j + 1 + (int)blockIdx.x >= nblk) return;
+  if (nblk <= large_min || j + 1 + (int)blockIdx.x >= nblk) return;
   const double* __restrict__ A = p.A;
   double* __restrict__ Lf = p.Lf;
   const double* __restrict__ Dinv = p.Dinv;
@@ -345,11 +345,11 @@ __global__ __launch_bounds__(256) void k_chol_trsm(cm_parg<BATCH> pa, int na_arg
 // X_l from Lf), one 16x16 output block per wave on the matrix cores, output tile prefetched into registers.  Many workgroups
 // per CU keep enough bytes in flight; block 0 owns the diagonal tile (j+1, j+1) and factors it in place.
 template <bool BATCH>
-__global__ __launch_bounds__(256) void k_chol_bulk(cm_parg<BATCH> pa, int na_arg, int skip_own, int j) {
+__global__ __launch_bounds__(256) void k_chol_bulk(cm_parg<BATCH> pa, int na_arg, int skip_own, int j, int large_min) {
   CM_SOLVE_PROLOGUE(2)
   {
     const int tr = nblk - j - 1;
-    if (nblk <= CM_LARGE_TILES || tr <= 0 || (int)blockIdx.x >= tr * (tr + 1) / 2) return;
+    if (nblk <= large_min || tr <= 0 || (int)blockIdx.x >= tr * (tr + 1) / 2) return;
   }
   double* __restrict__ A = p.A;
   const double* __restrict__ Lf = p.Lf;
@@ -397,11 +397,11 @@ __global__ __launch_bounds__(256) void k_chol_bulk(cm_parg<BATCH> pa, int na_arg
 // SOLVED = true: the panel tiles A[.][j] were already solved (k_chol_trsm wrote X into Lf), so the workgroup only does the
 // trailing update -- used for large matrices where recomputing the panel solve per tile pair would triple the flops.
 template <bool BATCH, bool SOLVED>
-__global__ __launch_bounds__(1024) void k_chol_panel(cm_parg<BATCH> pa, int na_arg, int skip_own, int j) {
+__global__ __launch_bounds__(1024) void k_chol_panel(cm_parg<BATCH> pa, int na_arg, int skip_own, int j, int large_min) {
   CM_SOLVE_PROLOGUE(2)
   {
     const int tr = nblk - j - 1;
-    if (nblk > CM_LARGE_TILES || tr <= 0 || (int)blockIdx.x >= tr * (tr + 1) / 2) return;
+    if (nblk > large_min || tr <= 0 || (int)blockIdx.x >= tr * (tr + 1) / 2) return;
   }
   double* __restrict__ A = p.A;
   double* __restrict__ Lf = p.Lf;
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(256) void k_fill_prior(cm_parg<BATCH> pa, int na_ar
   if (n < p.N) { p.mu[n] = p.mu_prior[n]; const double b0 = p.beta_prior[n]; p.beta[n] = b0 * b0; }
 }
 
-// stand-alone launch of the small solve (per-phase test hook, and active sets between the fused kernel's cap and 128)
+// stand-alone launch of the small solve (per-phase test hook: the same body the fused mid-iteration kernel runs for small sets)
 template <bool BATCH>
 __global__ __launch_bounds__(1024) void k_solve_small(cm_parg<BATCH> pa, int na_arg, int skip_own) {
   extern __shared__ double sm[];
@@ -662,19 +662,23 @@ int cm_solve_launch(cm_ctx* ctx, cm_set& s, int skip_mode, hipEvent_t fact_begin
   hipStream_t st = ctx->stream;
   s.last_fact = false;
   // what the set needs
+  // Two families of trailing-update kernels with bitwise the same results: one launch per panel, every workgroup re-deriving the
+  // panel solve (shortest dependent chain: one circuit, up to CM_LARGE_TILES tile rows), or panel solve once + lean 256-thread
+  // trailing update (least traffic per tile: large matrices, and every batch -- there the launches are throughput-bound).
+  const int large_min = s.B > 1 ? 1 : CM_LARGE_TILES;
   bool any_small = false, any_tiled = false, any_panel = false, any_large = false;
   int na_small = 0, nblk_max = 0, nblk_panel = 0, na_tiled = 0;
   size_t lds_small = 0;
   for (int c = 0; c < s.B; ++c) {
     const cm_problem* q = s.ps[c];
     const int na = s.na[c];
-    const int kind = cm_solve_kind(na, skip_mode < 0 ? -1 : q->small_cap, q->max_row_len);
+    const int kind = cm_solve_kind(na, q->small_cap, skip_mode >= 0);
     if (kind == 1) { any_small = true; na_small = std::max(na_small, na); lds_small = std::max(lds_small, small_lds_bytes(na, na * q->max_row_len)); }
     if (kind == 2) {
       any_tiled = true;
       const int nb = (na + TS - 1) / TS;
       nblk_max = std::max(nblk_max, nb); na_tiled = std::max(na_tiled, na);
-      if (nb > CM_LARGE_TILES) any_large = true; else { any_panel = true; nblk_panel = std::max(nblk_panel, nb); }
+      if (nb > large_min) any_large = true; else { any_panel = true; nblk_panel = std::max(nblk_panel, nb); }
     }
   }
   const int skip_le = skip_mode < 0 ? 0 : 1;                   // device side: 1 = leave circuits at or below their own small_cap alone
@@ -699,7 +703,7 @@ int cm_solve_launch(cm_ctx* ctx, cm_set& s, int skip_mode, hipEvent_t fact_begin
   s.last_fact = true;
   for (int c = 0; c < s.B; ++c) {                  // bookkeeping for cm_timings: launches and tiles of the trailing updates
     const int nb = (s.na[c] + TS - 1) / TS;
-    if (cm_solve_kind(s.na[c], skip_mode < 0 ? -1 : s.ps[c]->small_cap, s.ps[c]->max_row_len) != 2) continue;
+    if (cm_solve_kind(s.na[c], s.ps[c]->small_cap, skip_mode >= 0) != 2) continue;
     for (int j = 0; j + 1 < nb; ++j) { const long long t = nb - j - 1; s.fact_tile_updates += t * (t + 1) / 2; }
   }
   s.fact_launches += std::max(0, nblk - 1);
@@ -707,12 +711,12 @@ int cm_solve_launch(cm_ctx* ctx, cm_set& s, int skip_mode, hipEvent_t fact_begin
   for (int j = 0; j + 1 < nblk; ++j) {
     const int t = nblk - j - 1;
     if (any_large) {                                 // large: solve the panel once, then the bandwidth-lean trailing update (block 0 factors the next diagonal tile)
-      CM_LAUNCH_SET(k_chol_trsm, s, t, 256, 0, st, na1, skip_le, j);
-      CM_LAUNCH_SET(k_chol_bulk, s, t * (t + 1) / 2, 256, 0, st, na1, skip_le, j);
+      CM_LAUNCH_SET(k_chol_trsm, s, t, 256, 0, st, na1, skip_le, j, large_min);
+      CM_LAUNCH_SET(k_chol_bulk, s, t * (t + 1) / 2, 256, 0, st, na1, skip_le, j, large_min);
     }
     if (any_panel && j + 1 < nblk_panel) {           // small / medium: one launch per panel
       const int tp = nblk_panel - j - 1;
-      CM_LAUNCH_SET_T(k_chol_panel, (false), s, tp * (tp + 1) / 2, 1024, 0, st, na1, skip_le, j);
+      CM_LAUNCH_SET_T(k_chol_panel, (false), s, tp * (tp + 1) / 2, 1024, 0, st, na1, skip_le, j, large_min);
     }
   }
   if (fact_end) CM_HIP(hipEventRecord(fact_end, st));
