@@ -203,7 +203,7 @@ extern "C" int cm_problem_create(cm_ctx* ctx, int32_t N, int32_t K, int32_t T, c
   const size_t ld = p->ld;
   if ((rc = dmalloc(&p->mask, K)) || (rc = dmalloc(&p->slab, 2 * (size_t)N + K + (size_t)p->nnz)) ||
       (rc = dmalloc(&p->pslab, 8 * (size_t)N + CM_S_COUNT)) || (rc = dmalloc(&p->phi, 2 * (size_t)N)) ||
-      (rc = dmalloc(&p->phi_cov, 4 * (size_t)N)) || (rc = dmalloc(&p->phi_dead, 6 * (size_t)N)) || (rc = dmalloc(&p->R, K)) ||
+      (rc = dmalloc(&p->phi_cov, 4 * (size_t)N)) || (rc = dmalloc(&p->phi_dead, 8 * (size_t)N)) || (rc = dmalloc(&p->R, K)) ||
       (rc = dmalloc(&p->colany, K)) || (rc = dmalloc(&p->mcE, (size_t)N * CM_MAX_VALS)) ||
       (rc = dmalloc(&p->rs, 4 * (size_t)N)) || (rc = dmalloc(&p->act_idx, N)) || (rc = dmalloc(&p->act_inv, N)) ||
       (rc = dmalloc(&p->n_act, 4)) || (rc = dmalloc(&p->A, ld * ld)) || (rc = dmalloc(&p->X, ld * ld)) || (rc = dmalloc(&p->Lf, ld * ld)) ||
@@ -254,7 +254,7 @@ void cm_fill_pdev(const cm_problem* p, const cm_problem* r, int* mailbox, cm_pde
   d->y = p->y; d->ss = p->ss; d->sum_y = p->sum_y; d->vals = p->vals; d->row_ptr = p->row_ptr; d->col = p->col; d->grp = p->grp;
   d->rowcnt = p->rowcnt; d->col_ptr = p->col_ptr; d->csc_row = p->csc_row; d->csc_pos = p->csc_pos; d->mask = p->mask; d->colany = p->colany;
   d->lam = p->lam; d->mu = p->mu; d->beta = p->beta; d->phi = p->phi; d->phi_cov = p->phi_cov; d->scal = p->scal; d->R = p->R; d->z = p->z;
-  d->mcE = p->mcE; d->rs = p->rs; d->phi_dead = p->phi_dead; d->phi_cov_dead = p->phi_dead ? p->phi_dead + 2 * (size_t)p->N : nullptr; d->pslab = p->pslab; d->mu_prior = p->mu_prior; d->beta_prior = p->beta_prior; d->phi_prior = p->phi_prior;
+  d->mcE = p->mcE; d->rs = p->rs; d->phi_dead = p->phi_dead; d->phi_cov_dead = p->phi_dead ? p->phi_dead + 2 * (size_t)p->N : nullptr; d->phi_c_dead = p->phi_dead ? p->phi_dead + 6 * (size_t)p->N : nullptr; d->pslab = p->pslab; d->mu_prior = p->mu_prior; d->beta_prior = p->beta_prior; d->phi_prior = p->phi_prior;
   d->phi_cov_prior = p->phi_cov_prior; d->act_idx = p->act_idx; d->act_inv = p->act_inv; d->n_act = p->n_act; d->seq_n = p->seq_n;
   d->seq_off = p->seq_off; d->seq_pos = p->seq_pos; d->chunk_first = p->chunk_first; d->seq_meta = p->seq_meta; d->packed = p->packed;
   d->A = p->A; d->X = p->X; d->Lf = p->Lf; d->Dinv = p->Dinv; d->rhs = p->rhs; d->mailbox = mailbox;
@@ -464,11 +464,11 @@ static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_option
     CM_TRY(dmalloc(&p->inv_all, (size_t)iters * N));
     p->orders_cap = iters;
   }
-  if (p->wtab_cap < (size_t)iters * N * S * 2) {
+  if (p->wtab_cap < (size_t)iters * N * S * 4) {           // (ndtri(u), u) for each of the iters x N x S x 2 uniforms
     if (p->wtab) hipFree(p->wtab);
     p->wtab = nullptr; p->wtab_cap = 0;
-    CM_TRY(dmalloc(&p->wtab, (size_t)iters * N * S * 2));
-    p->wtab_cap = (size_t)iters * N * S * 2;
+    CM_TRY(dmalloc(&p->wtab, (size_t)iters * N * S * 4));
+    p->wtab_cap = (size_t)iters * N * S * 4;
   }
   if (o->rng_mode == CM_RNG_EXPLICIT) {
     if (p->uexp) { hipFree(p->uexp); p->uexp = nullptr; }
@@ -958,7 +958,7 @@ extern "C" int cm_k_lam_sweep(cm_ctx* ctx, int32_t N, int32_t K, const double* s
   for (int m = 0; m < N; ++m) { uint32_t a0 = 0, a1 = 2, b0 = 1, b1 = 3; cm_threefry2x32(kout[0], kout[1], a0, a1); cm_threefry2x32(kout[0], kout[1], b0, b1); kout[0] = a1; kout[1] = b1; }
   int rc = CM_OK;
   if ((rc = dmalloc(&p->keys, keys.size())) || (rc = dmalloc(&p->orders_all, (size_t)N)) || (rc = dmalloc(&p->orders_tmp, (size_t)N)) ||
-      (rc = dmalloc(&p->inv_all, (size_t)N)) || (rc = dmalloc(&p->wtab, (size_t)N * 2 * S))) {
+      (rc = dmalloc(&p->inv_all, (size_t)N)) || (rc = dmalloc(&p->wtab, (size_t)N * 4 * S))) {
   } else if (hipMemcpy(p->keys, keys.data(), keys.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
              hipMemcpy(p->scal, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess ||
              hipMemcpy(p->mu, mu, (size_t)N * 8, hipMemcpyHostToDevice) != hipSuccess ||
@@ -969,7 +969,7 @@ extern "C" int cm_k_lam_sweep(cm_ctx* ctx, int32_t N, int32_t K, const double* s
              hipMemset(p->n_act, 0, 4 * sizeof(int)) != hipSuccess || hipMemset(p->seq_meta, 0, 8 * sizeof(int)) != hipSuccess) {
     cm_set_error("upload failed"); rc = CM_ERR_HIP;
   }
-  p->keys_iters = 1; p->orders_cap = 1; p->wtab_cap = (size_t)N * 2 * S;
+  p->keys_iters = 1; p->orders_cap = 1; p->wtab_cap = (size_t)N * 4 * S;
   cm_set set;
   if (!rc) rc = cm_launch_rng(ctx, p, 0, 1, st);
   if (!rc) rc = cm_launch_ndtri_table(ctx, p, 0, 1, S, CM_RNG_THREEFRY, st);

@@ -519,38 +519,62 @@ __device__ __forceinline__ double cm_uniform64(uint32_t k0, uint32_t k1, int j, 
 }
 
 
+// _eval_lam_update_monte_carlo (caviar.py:233-236): log(f / (1 - f)), f = sigmoid(x) -- x itself in exact arithmetic, x plus the
+// rounding of exp, the two divisions and the logarithm as the reference computes it, +-inf once the sigmoid saturates (quirk a5).
+// N x S x P of these per iteration make this the widest transcendental stream of the path, so the final logarithm (~100 fp64
+// instructions) is not taken literally where that is exactly recoverable: with e = exp(-x), f = 1 / (1 + e), r = f / (1 - f) as the
+// reference forms them, log(r) = x + log1p(r e - 1) up to the last-ulp error of e; r e - 1 is the rounding residue of those three
+// operations, a single fma away, and tiny for moderate |x| (|r e - 1| < 2e-7 below |x| = 20), where two terms of log1p are exact to
+// double precision.  Beyond, and for non-finite x, the literal form (with its saturation to +-inf) is evaluated.
+__device__ __forceinline__ double cm_logit_of_sigmoid(double x) {
+  if (fabs(x) < 20.0) {
+    const double e = exp(-x);
+    const double f = cm_rcp(1.0 + e);                  // 1 + e in [1, 5e8]: normal range
+    const double r = f * cm_rcp(1.0 - f);              // 1 - f in [2e-9, 1)
+    const double t = fma(r, e, -1.0);
+    return x + (t - 0.5 * t * t);
+  }
+  const double f = cm_sigmoid(x);
+  return log(f / (1.0 - f));
+}
+
 // rare path of the steady-state kernel, kept out of line so that its registers do not burden the common path
 __device__ __noinline__ double cm_quantile_slow(double arg) { return normcdfinv(arg); }
 
-// one wavefront; mc is the wave's LDS scratch [2*S]; (mean0, mean1, sd0, sd1) = phi[n], diag(phi_cov[n]).
-// arg = c + u (1 - c) equals u bit for bit whenever c is below half an ulp of u (c = ndtr(-mean/sdev) is 0 or ~1e-30 once
-// phi comes from the Laplace step), and then ndtri(arg) is the tabulated ndtri(u).  FULL = true inlines the quantile
-// function (iteration 0, where phi is the prior and c is not small); FULL = false calls it out of line on a miss.
-template <bool FULL>
-__device__ __forceinline__ void mc_logit_body(int n, int m, int lane, double mean0, double mean1, double sd0, double sd1,
-                                              const uint32_t* __restrict__ keys, const double* __restrict__ uexp,
-                                              const double* __restrict__ wrow, const double* __restrict__ vals, int V, int S,
-                                              double* mc, double* __restrict__ mcE) {
-  const double c0 = normcdf(-mean0 / sd0), c1 = normcdf(-mean1 / sd1);
-  uint32_t k0 = 0, k1 = 0;
-  if (!uexp) { k0 = keys[2 * (3 + m)]; k1 = keys[2 * (3 + m) + 1]; }
-  for (int j = lane; j < 2 * S; j += CM_WAVE) {
-    const bool second = j & 1;
-    const double c = second ? c1 : c0, sd = second ? sd1 : sd0, mean = second ? mean1 : mean0;
-    double q;
-    if (!FULL && c < 0x1p-106) {
-      // c is below half an ulp of every u >= 2^-52, the smallest non-zero uniform: arg = c + u (1 - c) is u bit for bit and
-      // ndtri(arg) is the tabulated w -- without generating u at all (20 threefry rounds per draw).  The one exception, u == 0
-      // (arg = c), is recognisable from the table itself: w = ndtri(0) = -inf.
-      const double w = wrow[j];
-      q = (w == -INFINITY && c != 0.0) ? cm_quantile_slow(c) : w;
-    } else {
-      const double u = uexp ? uexp[j] : cm_uniform64(k0, k1, j, S);
-      const double arg = c + u * (1.0 - c);                      // caviar.py:212
-      if (FULL) q = normcdfinv(arg);
-      else q = (arg == u) ? wrow[j] : cm_quantile_slow(arg);
+// one wavefront; mc is the wave's LDS scratch [2*S]; (mean0, mean1, sd0, sd1) = phi[n], diag(phi_cov[n]); wu[2*S] = the (ndtri(u), u)
+// pairs of this sweep step (k_ndtri_table: the uniforms are data independent, so the 20 threefry rounds and the quantile of
+// every draw are taken off the per-iteration path).
+// arg = c + u (1 - c) equals u bit for bit whenever c is below half an ulp of u (c = ndtr(-mean/sdev) underflows once mean/sdev is
+// large), and then ndtri(arg) is the tabulated ndtri(u).  FULL = true inlines the quantile function (iteration 0, where phi is the
+// prior and c is not small); FULL = false calls it out of line on a miss.  The draws are walked component by component (all
+// phi_0 draws, then all phi_1 draws): c is then uniform over the wavefront and the miss path is only entered for a component
+// that needs it (phi_1 of rows whose posterior is wide, e.g. all-zero rows: c ~ 1e-7 there).
+// HAVE_C: c0 / c1 = ndtr(-mean / sdev) are supplied (per-run constants of an all-zero row, k_phi_dead) instead of evaluated here.
+template <bool FULL, bool HAVE_C = false>
+__device__ __forceinline__ void mc_logit_body(int n, int lane, double mean0, double mean1, double sd0, double sd1,
+                                              const double2* __restrict__ wu, const double* __restrict__ vals, int V, int S,
+                                              double* mc, double* __restrict__ mcE, double c0_in = 0.0, double c1_in = 0.0) {
+  const double c0 = HAVE_C ? c0_in : normcdf(-mean0 / sd0), c1 = HAVE_C ? c1_in : normcdf(-mean1 / sd1);
+#pragma unroll
+  for (int comp = 0; comp < 2; ++comp) {
+    const double c = comp ? c1 : c0, sd = comp ? sd1 : sd0, mean = comp ? mean1 : mean0;
+    const bool tiny = !FULL && c < 0x1p-106;           // (wave-uniform)
+    for (int s_ = lane; s_ < S; s_ += CM_WAVE) {
+      const int j = 2 * s_ + comp;                     // u has shape [S, 2] (caviar.py:210)
+      const double2 t = wu[j];
+      double q;
+      if (FULL) {
+        q = normcdfinv(c + t.y * (1.0 - c));           // caviar.py:212
+      } else if (tiny) {
+        // c is below half an ulp of every u >= 2^-52, the smallest non-zero uniform: arg = c + u (1 - c) is u bit for bit and
+        // ndtri(arg) is the tabulated value.  The one exception, u == 0 (arg = c), shows in the table itself: ndtri(0) = -inf.
+        q = (t.x == -INFINITY && c != 0.0) ? cm_quantile_slow(c) : t.x;
+      } else {
+        const double arg = c + t.y * (1.0 - c);
+        q = (arg == t.y) ? t.x : cm_quantile_slow(arg);
+      }
+      mc[j] = q * sd + mean;
     }
-    mc[j] = q * sd + mean;
   }
   // same-wave LDS write -> read: the LDS pipe is in order for one wave; the (free) wave barrier keeps the compiler from moving the
   // reads above the writes of other lanes
@@ -559,10 +583,7 @@ __device__ __forceinline__ void mc_logit_body(int n, int m, int lane, double mea
     const double v = vals[g];
     if (!(v > 0.0)) continue;
     double acc = 0.0;
-    for (int s = lane; s < S; s += CM_WAVE) {
-      const double f = cm_sigmoid(mc[2 * s] * v - mc[2 * s + 1]);
-      acc += log(f / (1.0 - f));
-    }
+    for (int s = lane; s < S; s += CM_WAVE) acc += cm_logit_of_sigmoid(mc[2 * s] * v - mc[2 * s + 1]);
     acc = cm_wave_sum(acc);
     if (lane == 0) mcE[(size_t)n * CM_MAX_VALS + g] = acc / (double)S;
   }

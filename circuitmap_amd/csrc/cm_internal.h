@@ -92,7 +92,7 @@ struct cm_problem {
   double* beta_prior = nullptr; // [N]
   double* phi = nullptr;      // [N*2]
   double* phi_cov = nullptr;  // [N*4]
-  double* phi_dead = nullptr; // [N*6] update_phi result of neuron n if its lam row is identically zero: phi [N*2] | phi_cov [N*4]
+  double* phi_dead = nullptr; // [N*8] update_phi result of neuron n if its lam row is identically zero: phi [N*2] | phi_cov [N*4] | ndtr(-mean/sdev) [N*2]
   double* phi_prior = nullptr;
   double* phi_cov_prior = nullptr;
   double* scal = nullptr;     // [16] device scalars, see CM_S_*
@@ -108,7 +108,7 @@ struct cm_problem {
   int32_t* orders_all = nullptr; // [iters*N] sweep orders of every iteration (device generated, or the explicit stream)
   int32_t* orders_tmp = nullptr; // [iters*N] ping-pong buffer of the shuffle rounds
   int32_t* inv_all = nullptr;    // [iters*N] inverse of every sweep order: position of neuron n in iteration it
-  double* wtab = nullptr;        // [iters*N*2S] ndtri(u) of every uniform of the run (data independent)
+  double* wtab = nullptr;        // [iters*N*2S*2] (ndtri(u), u) for every uniform of the run (data independent)
   size_t wtab_cap = 0;
   int32_t orders_cap = 0;     // iterations the two buffers are sized for
   int32_t* seq_n = nullptr;   // [N]   neurons with mu != 0 in sweep order
@@ -152,7 +152,7 @@ struct cm_pdev {
   const int *rowcnt, *col_ptr, *csc_row, *csc_pos;
   uint8_t *mask, *colany;
   double *lam, *mu, *beta, *phi, *phi_cov, *scal, *R, *z, *mcE, *rs;
-  double *phi_dead, *phi_cov_dead;   // update_phi of an all-zero row, per neuron: constant over a run (k_phi_dead)
+  double *phi_dead, *phi_cov_dead, *phi_c_dead;   // update_phi of an all-zero row, per neuron, and ndtr(-mean / sdev) of it: constants of a run (k_phi_dead)
   const double *pslab, *mu_prior, *beta_prior, *phi_prior, *phi_cov_prior;
   int *act_idx, *act_inv, *n_act, *seq_n, *seq_off, *seq_pos, *chunk_first, *seq_meta;
   void* packed;

@@ -22,9 +22,45 @@
 #define CM_ITER_THREADS_BATCH 1024
 
 struct IterDyn {     // what changes from iteration to iteration (common to all circuits of a batch)
-  int it, max_iters; double penalty, scale_factor, tol; int do_sigma, seq, do_solve, stage_ok, do_phi, do_mc, S, roles, nx, explicit_rng;
+  int it, max_iters; double penalty, scale_factor, tol; int do_sigma, seq, do_solve, stage_ok, do_phi, do_mc, S, roles, nx, explicit_rng, skip_dead;
   long long* dbg;      // diagnostic (CAVIAR_HIP_TRACE_BLOCK0): device clock at the phase boundaries of block 0, 8 words per launch
 };
+
+// an all-zero row takes the per-run constants of its neuron: phi, phi_cov (written by lane 0) and the truncation points c0, c1
+__device__ __forceinline__ void dead_phi_copy(const cm_pdev& p, int n, int lane, double pc[4], double* c0, double* c1) {
+  const double* __restrict__ pd = p.phi_dead + 2 * (size_t)n;
+  const double* __restrict__ cd = p.phi_cov_dead + 4 * (size_t)n;
+  const double* __restrict__ cc = p.phi_c_dead + 2 * (size_t)n;
+  pc[0] = pd[0]; pc[1] = pd[1];
+  const double c01 = cd[1], c10 = cd[2];
+  pc[2] = cd[0]; pc[3] = cd[3];
+  *c0 = cc[0]; *c1 = cc[1];
+  if (lane == 0) {
+    p.phi[2 * n] = pc[0]; p.phi[2 * n + 1] = pc[1];
+    p.phi_cov[4 * n] = pc[2]; p.phi_cov[4 * n + 1] = c01; p.phi_cov[4 * n + 2] = c10; p.phi_cov[4 * n + 3] = pc[3];
+  }
+}
+
+// Batches: the all-zero rows of every circuit (95 % of the rows in the steady state) in a kernel of their own -- copy of the
+// constants + the next Monte-Carlo logit, nothing else: few registers, so twice the wavefronts per SIMD hide the table loads, and
+// no workgroup waits for a Newton iteration.  One wavefront per row; rows with lam != 0 leave at once (k_iter_mid takes them).
+template <bool BATCH>
+__global__ __launch_bounds__(256) void k_mc_dead(cm_parg<BATCH> pa, IterDyn a) {
+  extern __shared__ double sm[];
+  const cm_pdev& p = pa.get();
+  const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE;
+  const int n = (int)blockIdx.x * (int)(blockDim.x / CM_WAVE) + wave;
+  const int N = p.N;
+  if (n >= N || !(p.rs[(size_t)n * 4 + 3] < 0.0)) return;
+  double pc[4], c0, c1;
+  dead_phi_copy(p, n, lane, pc, &c0, &c1);
+  if (a.do_mc) {
+    const int m = p.inv_all[(size_t)a.nx * N + n];
+    const size_t off = ((size_t)a.nx * N + m) * 2 * a.S;
+    mc_logit_body<false, true>(n, lane, pc[0], pc[1], pc[2], pc[3], (const double2*)p.wtab + off, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S,
+                               p.mcE, c0, c1);
+  }
+}
 
 template <bool BATCH, int SEG, bool FULLMC>
 __global__ __launch_bounds__(BATCH ? CM_ITER_THREADS_BATCH : CM_ITER_THREADS) void k_iter_mid(cm_parg<BATCH> pa, IterDyn a) {
@@ -56,17 +92,13 @@ __global__ __launch_bounds__(BATCH ? CM_ITER_THREADS_BATCH : CM_ITER_THREADS) vo
   const int N = p.N;
   if (n >= N) return;
   double pc[4];
+  bool dead_row = false;
+  double dc0 = 0.0, dc1 = 0.0;
   if (a.do_phi && p.rs[(size_t)n * 4 + 3] < 0.0) {
     // the row is identically zero (k_stats of this iteration): its update_phi is the per-run constant of this neuron
-    const double* __restrict__ pd = p.phi_dead + 2 * (size_t)n;
-    const double* __restrict__ cd = p.phi_cov_dead + 4 * (size_t)n;
-    pc[0] = pd[0]; pc[1] = pd[1];
-    const double c1 = cd[1], c2 = cd[2];
-    pc[2] = cd[0]; pc[3] = cd[3];
-    if (lane == 0) {
-      p.phi[2 * n] = pc[0]; p.phi[2 * n + 1] = pc[1];
-      p.phi_cov[4 * n] = pc[2]; p.phi_cov[4 * n + 1] = c1; p.phi_cov[4 * n + 2] = c2; p.phi_cov[4 * n + 3] = pc[3];
-    }
+    if (a.skip_dead) return;                           // batches: these rows belong to the lean kernel k_mc_dead
+    dead_row = true;
+    dead_phi_copy(p, n, lane, pc, &dc0, &dc1);
   } else if (a.do_phi) {
     phi_body<SEG>(n, lane, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, pc);
   } else {
@@ -76,9 +108,11 @@ __global__ __launch_bounds__(BATCH ? CM_ITER_THREADS_BATCH : CM_ITER_THREADS) vo
     // random tables of iteration nx (the next one)
     const int m = p.inv_all[(size_t)a.nx * N + n];
     const size_t off = ((size_t)a.nx * N + m) * 2 * a.S;
-    const uint32_t* keys_next = a.explicit_rng ? nullptr : p.keys + (size_t)a.nx * (N + 3) * 2;
-    mc_logit_body<FULLMC>(n, m, lane, pc[0], pc[1], pc[2], pc[3], keys_next, a.explicit_rng ? p.uexp + off : nullptr, p.wtab + off,
-                          p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE);
+    const double2* wu = (const double2*)p.wtab + off;   // (ndtri(u), u) of that sweep step
+    if (!FULLMC && dead_row)
+      mc_logit_body<false, true>(n, lane, pc[0], pc[1], pc[2], pc[3], wu, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE, dc0, dc1);
+    else
+      mc_logit_body<FULLMC>(n, lane, pc[0], pc[1], pc[2], pc[3], wu, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE);
   }
 }
 
@@ -108,6 +142,8 @@ static int launch_iter2(cm_ctx* ctx, cm_set& s, const IterDyn& a0, size_t lds, i
     return CM_OK;
   }
   CM_LAUNCH_SET_T(k_iter_mid, (SEG, FULLMC), s, blocks, (s.B == 1 ? CM_ITER_THREADS : CM_ITER_THREADS_BATCH), lds, ctx->stream, a0);
+  if (a0.skip_dead)                                  // batches: the all-zero rows, in their lean kernel (after the mailboxes are on their way)
+    CM_LAUNCH_SET(k_mc_dead, s, (s.lead->N + 3) / 4, 256, 4 * lds_waves, ctx->stream, a0);
   CM_HIP(hipGetLastError());
   return CM_OK;
 }
@@ -129,6 +165,7 @@ int cm_launch_iter_mid(cm_ctx* ctx, cm_set& s, int it, int iters, int S, int rng
   a.do_phi = do_phi; a.do_mc = nxt < iters; a.S = S;
   a.nx = a.do_mc ? nxt : 0;
   a.explicit_rng = rng_mode == CM_RNG_EXPLICIT;
+  a.skip_dead = (s.B > 1 && do_phi && it >= 0 && roles == 3) ? 1 : 0;
   a.dbg = (ctx->dbg_block0 && it >= 0 && it < 64) ? ctx->dbg_block0 + 8 * it : nullptr;
   const int threads = s.B == 1 ? CM_ITER_THREADS : CM_ITER_THREADS_BATCH;
   const int waves = threads / CM_WAVE;

@@ -132,6 +132,11 @@ __global__ __launch_bounds__(256) void k_phi_dead(cm_parg<BATCH> pa) {
   double out[4];
   phi_body<SEG, true>(n, threadIdx.x % CM_WAVE, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi_dead,
                       p.phi_cov_dead, out);
+  // the lower truncation points of the Monte-Carlo draws from this phi (caviar.py:212): constants of the run as well
+  if (threadIdx.x % CM_WAVE == 0) {
+    p.phi_c_dead[2 * n] = normcdf(-out[0] / out[2]);
+    p.phi_c_dead[2 * n + 1] = normcdf(-out[1] / out[3]);
+  }
 }
 template <int SEG>
 static void launch_phi_dead(cm_set& s, hipStream_t st) {

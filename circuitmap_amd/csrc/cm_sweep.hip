@@ -96,7 +96,7 @@ __global__ __launch_bounds__(64) void k_ndtri_table(const uint32_t* __restrict__
   if (!uexp_all) { const uint32_t* keys = keys_all + (size_t)it * (N + 3) * 2; k0 = keys[2 * (3 + m)]; k1 = keys[2 * (3 + m) + 1]; }
   for (int j = threadIdx.x; j < 2 * S; j += CM_WAVE) {
     const double u = uexp_all ? uexp_all[base + j] : cm_uniform64(k0, k1, j, S);
-    if (wtab) wtab[base + j] = normcdfinv(u);
+    if (wtab) { wtab[2 * (base + j)] = normcdfinv(u); wtab[2 * (base + j) + 1] = u; }   // (ndtri(u), u) pairs
     if (u_out) u_out[(size_t)m * 2 * S + j] = u;
   }
 }
