@@ -105,6 +105,7 @@ extern "C" int cm_ctx_destroy(cm_ctx* c) {
   for (auto& e : c->pool) hipEventDestroy(e);
   if (c->h_pinned) hipHostFree(c->h_pinned);
   if (c->h_stage) hipHostFree(c->h_stage);
+  delete c->pool_host;
   if (c->h_pdev) hipHostFree(c->h_pdev);
   if (c->d_pdev) hipFree(c->d_pdev);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -340,6 +341,11 @@ static cm_host_rows host_rows(const cm_problem* p) {
   r.row_ptr = p->h_row_ptr.data(); r.col = p->h_col.data(); r.grp = p->h_grp.data();
   r.col_ptr = p->h_col_ptr.data(); r.csc_row = p->h_csc_row.data();
   return r;
+}
+
+__global__ __launch_bounds__(256) void k_set_ones(double* __restrict__ lam, const int32_t* __restrict__ idx, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) lam[idx[i]] = 1.0;
 }
 
 static int alloc_hist(cm_problem* p, int iters) {
@@ -598,32 +604,44 @@ static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_option
   CM_HIP(hipEventRecord(ctx->ev[2], st));
 
   if (o->fn_scan) {                                                  // caviar.py:94-98
-    // mu | beta | z | lam are one device slab per circuit: one pinned copy down, the host scan, one copy back, final update_phi.
-    // The scans of a batch are independent: they run on a few host threads.
+    // mu | beta | z | lam are one device slab per circuit.  The scan reads mu and z and only ever WRITES lam (entries set to 1), so
+    // mu | beta | z travel (one pinned copy down, one back) and lam stays in HBM; the few entries a reconnection sets are sent
+    // as an index list.  The scans of a batch are independent: they run on a few host threads.
     std::vector<size_t> off(B + 1, 0);
-    for (int c = 0; c < B; ++c) off[c + 1] = off[c] + 2 * (size_t)N + s.ps[c]->K + (size_t)s.ps[c]->nnz;
-    CM_TRY(stage_reserve(ctx, off[B] * sizeof(double)));
+    for (int c = 0; c < B; ++c) off[c + 1] = off[c] + 2 * (size_t)N + s.ps[c]->K;
+    size_t nnz_tot = 0;
+    for (int c = 0; c < B; ++c) nnz_tot += (size_t)s.ps[c]->nnz;
+    CM_TRY(stage_reserve(ctx, off[B] * sizeof(double) + nnz_tot * sizeof(int32_t)));     // slabs, then room for the index lists (pinned)
     double* hbase = (double*)ctx->h_stage;
+    int32_t* hidx = (int32_t*)(hbase + off[B]);
     for (int c = 0; c < B; ++c)
       CM_HIP(hipMemcpyAsync(hbase + off[c], s.ps[c]->slab, (off[c + 1] - off[c]) * sizeof(double), hipMemcpyDeviceToHost, st));
     CM_HIP(hipStreamSynchronize(st));
+    std::vector<std::vector<int32_t>> ones(B);
     auto scan = [&](int c) {
       const cm_problem* q = s.ps[c];
       double* h = hbase + off[c];
-      cm_host_reconnect(host_rows(q), h, h + N, h + 2 * (size_t)N + q->K, h + 2 * (size_t)N, o->msrmp, o->minimum_spike_count, o->verbose);
+      cm_host_reconnect(host_rows(q), h, h + N, nullptr, h + 2 * (size_t)N, o->msrmp, o->minimum_spike_count, o->verbose, &ones[c]);
     };
-    const int nthreads = (B > 1 && o->verbose == 0) ? std::min<int>(B, std::max(1u, std::min(8u, std::thread::hardware_concurrency()))) : 1;
-    if (nthreads <= 1) {
-      for (int c = 0; c < B; ++c) scan(c);
+    if (B > 1 && o->verbose == 0) {
+      if (!ctx->pool_host) ctx->pool_host = new cm_host_pool((int)std::max(1u, std::min(7u, std::thread::hardware_concurrency() > 1 ? std::thread::hardware_concurrency() - 1 : 1u)));
+      ctx->pool_host->run(B, scan);
     } else {
-      std::atomic<int> next(0);
-      std::vector<std::thread> pool;
-      for (int t = 0; t < nthreads; ++t) pool.emplace_back([&]() { for (int c; (c = next.fetch_add(1)) < B;) scan(c); });
-      for (auto& t : pool) t.join();
+      for (int c = 0; c < B; ++c) scan(c);
     }
-    for (int c = 0; c < B; ++c)
-      CM_HIP(hipMemcpyAsync(s.ps[c]->slab, hbase + off[c], (off[c + 1] - off[c]) * sizeof(double), hipMemcpyHostToDevice, st));
-    CM_TRY(cm_launch_update_phi(ctx, s, st));
+    for (int c = 0; c < B; ++c) {
+      cm_problem* q = s.ps[c];
+      CM_HIP(hipMemcpyAsync(q->slab, hbase + off[c], (off[c + 1] - off[c]) * sizeof(double), hipMemcpyHostToDevice, st));
+      if (!ones[c].empty()) {                                          // lam[e] = 1 for the reconnected cells' events (:136)
+        const size_t cnt = ones[c].size();
+        memcpy(hidx, ones[c].data(), cnt * sizeof(int32_t));           // pinned: the upload below does not block the host
+        int32_t* d_idx = (int32_t*)q->packed;                          // chain records are dead by now: scratch for the index list
+        CM_HIP(hipMemcpyAsync(d_idx, hidx, cnt * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_set_ones, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, q->lam, d_idx, (int)cnt);
+        hidx += cnt;
+      }
+    }
+    CM_TRY(cm_launch_update_phi(ctx, s, st, iters > 0 ? 1 : 0));     // (iters == 0: the per-run constants were not produced)
   }
   CM_HIP(hipEventRecord(ctx->ev[3], st));
   CM_HIP(hipStreamSynchronize(st));

@@ -316,7 +316,8 @@ __device__ __forceinline__ void phi_body(int n, int lane, const double* __restri
                                          const uint8_t* __restrict__ grp, const int* __restrict__ rowcnt,
                                          const double* __restrict__ vals, int V,
                                          const double* __restrict__ phi_prior, const double* __restrict__ phi_cov_prior,
-                                         double* __restrict__ phi, double* __restrict__ phi_cov, double out[4]) {
+                                         double* __restrict__ phi, double* __restrict__ phi_cov, double out[4],
+                                         const double* __restrict__ dead_phi = nullptr, const double* __restrict__ dead_cov = nullptr) {
   constexpr int E = CM_WAVE / SEG;
   const int g = lane % SEG, ev = lane / SEG;
   // sufficient statistics of value g: segment `ev` scans entries ev, ev + E, ...; partial sums are then combined
@@ -339,6 +340,20 @@ __device__ __forceinline__ void phi_body(int n, int lane, const double* __restri
   }
   const double n0 = cnt - n1 - nmid;
   const double sy = n1 + smid;
+  if (!DEAD && dead_phi != nullptr && __all(n1 == 0.0 && nmid == 0.0)) {
+    // the row turned out to be identically zero: its result is the per-run constant of this neuron (k_phi_dead ran this very
+    // function on those statistics)
+    const double p0c = dead_phi[2 * n], p1c = dead_phi[2 * n + 1];
+    double cv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cv[i] = dead_cov[4 * n + i];
+    if (lane == 0) {
+      phi[2 * n] = p0c; phi[2 * n + 1] = p1c;
+      phi_cov[4 * n] = cv[0]; phi_cov[4 * n + 1] = cv[1]; phi_cov[4 * n + 2] = cv[2]; phi_cov[4 * n + 3] = cv[3];
+    }
+    out[0] = p0c; out[1] = p1c; out[2] = cv[0]; out[3] = cv[3];
+    return;
+  }
 
   const double pr0 = phi_prior[2 * n], pr1 = phi_prior[2 * n + 1];
   double prec[4];

@@ -77,7 +77,7 @@ double cm_host_pava_last(const double* y, int n) {   // pava.py:9-88, gamma = 1,
 
 // reconnect_spont_cells, caviar.py:102-144.  Host C++ on the compressed rows (one-off, after the last iteration).
 void cm_host_reconnect(const cm_host_rows& p, double* mu, double* beta, double* lam, double* z, double minimax_spk_prob,
-                           double minimum_spike_count, int verbose) {
+                       double minimum_spike_count, int verbose, std::vector<int32_t>* ones) {
   const int N = p.N, K = p.K, V = p.V;
   const int P = V - 1;
   std::vector<int> disc;
@@ -141,7 +141,9 @@ void cm_host_reconnect(const cm_host_rows& p, double* mu, double* beta, double* 
       beta[focus] = m > 1 ? sqrt(ssd / (double)(m - 1)) / sqrt((double)m) : NAN;   // :135 scipy.stats.sem, ddof = 1
       for (int e : locs) {                                                     // :136-137
         const int k = p.col[e];
-        lam[e] = 1.0; z[k] = 0.0;
+        if (lam) lam[e] = 1.0;
+        if (ones) ones->push_back(e);
+        z[k] = 0.0;
         for (int ce = p.col_ptr[k]; ce < p.col_ptr[k + 1]; ++ce) { const int mrow = p.csc_row[ce]; if (cnt[mrow] > 0) --cnt[mrow]; }
       }
       nz -= (long)m;

@@ -31,6 +31,8 @@ int cm_perm_rounds(int N);
 void cm_host_key_schedule_range(uint32_t key[2], int it0, int n_it, int N, uint32_t* keys);
 void cm_host_key_schedule(uint64_t seed, int iters, int N, std::vector<uint32_t>& keys);
 double cm_host_pava_last(const double* y, int n);
-// reconnect_spont_cells (caviar.py:102-144) on the compressed rows; mu, beta [N], lam [nnz, CSR order], z [K] are edited in place
+// reconnect_spont_cells (caviar.py:102-144) on the compressed rows; mu, beta [N], z [K] are edited in place.  lam [nnz, CSR order] is
+// only ever WRITTEN (entries set to 1, :136): pass the array, or NULL and collect the entries in `ones` (the driver then leaves lam
+// in HBM and sets them there).
 void cm_host_reconnect(const cm_host_rows& p, double* mu, double* beta, double* lam, double* z, double minimax_spk_prob,
-                       double minimum_spike_count, int verbose);
+                       double minimum_spike_count, int verbose, std::vector<int32_t>* ones = nullptr);

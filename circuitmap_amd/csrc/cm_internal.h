@@ -2,7 +2,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/caviar_hip.h"
@@ -32,6 +36,59 @@ void cm_set_error(const char* fmt, ...);
     if (_s != CM_OK) return _s;   \
   } while (0)
 
+// A few persistent host threads for the per-circuit host work of a batch (the false-negative scans): spawning threads per call
+// costs more than the scans themselves, and their start-up jitter showed in the batch timings.
+class cm_host_pool {
+ public:
+  explicit cm_host_pool(int n) { for (int i = 0; i < n; ++i) th_.emplace_back([this]() { work(); }); }
+  ~cm_host_pool() {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  int size() const { return (int)th_.size(); }
+  // runs fn(0) .. fn(n - 1) on the pool (the caller takes part) and returns when all are done
+  void run(int n, const std::function<void(int)>& fn) {
+    { std::lock_guard<std::mutex> lk(mu_); fn_ = &fn; n_ = n; next_ = 0; done_ = 0; ++gen_; }
+    cv_.notify_all();
+    for (;;) {
+      int i;
+      { std::lock_guard<std::mutex> lk(mu_); if (next_ >= n_) break; i = next_++; }
+      fn(i);
+      { std::lock_guard<std::mutex> lk(mu_); ++done_; }
+    }
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_done_.wait(lk, [this]() { return done_ >= n_; });
+    fn_ = nullptr;
+  }
+
+ private:
+  void work() {
+    unsigned long long seen = 0;
+    for (;;) {
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_.wait(lk, [&]() { return stop_ || (gen_ != seen && fn_ != nullptr && next_ < n_); });
+      if (stop_) return;
+      seen = gen_;
+      while (fn_ != nullptr && next_ < n_) {
+        const int i = next_++;
+        const std::function<void(int)>* f = fn_;
+        lk.unlock();
+        (*f)(i);
+        lk.lock();
+        if (++done_ >= n_) cv_done_.notify_all();
+      }
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex mu_;
+  std::condition_variable cv_, cv_done_;
+  const std::function<void(int)>* fn_ = nullptr;
+  int n_ = 0, next_ = 0, done_ = 0;
+  unsigned long long gen_ = 0;
+  bool stop_ = false;
+};
+
 struct cm_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -48,6 +105,7 @@ struct cm_ctx {
   size_t h_stage_bytes = 0;
   size_t lds_attr[48] = {};       // dynamic-LDS caps already raised for this context's device, by kernel slot (cm_raise_lds)
   long long* dbg_block0 = nullptr; // diagnostic buffer (CAVIAR_HIP_TRACE_BLOCK0): 64 launches x 8 device-clock stamps
+  cm_host_pool* pool_host = nullptr; // host threads for the per-circuit host work of batches (created with the first batch)
   void* d_pdev = nullptr;         // descriptors of the current batch (device) and their pinned source
   void* h_pdev = nullptr;
   size_t pdev_cap = 0;
@@ -356,6 +414,6 @@ int cm_sweep_variant(const cm_set& s, int rows_hint);
 int cm_launch_stats(cm_ctx* ctx, cm_set& s, double spont_orthogonality);
 int cm_launch_post_single(cm_ctx* ctx, cm_set& s, int it, const cm_options* o, int do_sigma);
 int cm_wait_active(cm_ctx* ctx, cm_set& s);
-int cm_launch_update_phi(cm_ctx* ctx, cm_set& s, hipStream_t st);
+int cm_launch_update_phi(cm_ctx* ctx, cm_set& s, hipStream_t st, int use_dead = 0);
 int cm_launch_phi_dead(cm_ctx* ctx, cm_set& s, hipStream_t st);
 

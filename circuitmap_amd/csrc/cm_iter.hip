@@ -62,8 +62,10 @@ __global__ __launch_bounds__(256) void k_mc_dead(cm_parg<BATCH> pa, IterDyn a) {
   }
 }
 
+// (the FULLMC variant -- one launch per run, quantile function inlined -- keeps 256-thread workgroups in batches too: under the
+// 128-register cap of a 1024-thread workgroup it spills)
 template <bool BATCH, int SEG, bool FULLMC>
-__global__ __launch_bounds__(BATCH ? CM_ITER_THREADS_BATCH : CM_ITER_THREADS) void k_iter_mid(cm_parg<BATCH> pa, IterDyn a) {
+__global__ __launch_bounds__((BATCH && !FULLMC) ? CM_ITER_THREADS_BATCH : CM_ITER_THREADS) void k_iter_mid(cm_parg<BATCH> pa, IterDyn a) {
   extern __shared__ double sm[];
   const cm_pdev& p = pa.get();
   if (blockIdx.x <= 1) {
@@ -130,7 +132,7 @@ static int launch_iter2(cm_ctx* ctx, cm_set& s, const IterDyn& a0, size_t lds, i
   if (s.B == 1) CM_TRY(cm_raise_lds(ctx, slot, reinterpret_cast<const void*>(k_iter_mid<false, SEG, FULLMC>), lds, 48 * 1024));
   else CM_TRY(cm_raise_lds(ctx, slot, reinterpret_cast<const void*>(k_iter_mid<true, SEG, FULLMC>), lds, 48 * 1024));
   static const int batch_split = getenv("CAVIAR_HIP_BATCH_SPLIT") ? atoi(getenv("CAVIAR_HIP_BATCH_SPLIT")) : 0;
-  if (s.B > 1 && batch_split > 0 && a0.roles == 3) {
+  if (s.B > 1 && batch_split > 0 && a0.roles == 3 && !FULLMC) {
     // diagnostic: the two roles of a batch as two launches; the per-neuron role in workgroups of `batch_split` threads with only its own LDS
     IterDyn a = a0;
     const int thr = batch_split, waves = thr / CM_WAVE, N = s.lead->N;
@@ -141,7 +143,7 @@ static int launch_iter2(cm_ctx* ctx, cm_set& s, const IterDyn& a0, size_t lds, i
     CM_HIP(hipGetLastError());
     return CM_OK;
   }
-  CM_LAUNCH_SET_T(k_iter_mid, (SEG, FULLMC), s, blocks, (s.B == 1 ? CM_ITER_THREADS : CM_ITER_THREADS_BATCH), lds, ctx->stream, a0);
+  CM_LAUNCH_SET_T(k_iter_mid, (SEG, FULLMC), s, blocks, ((s.B == 1 || FULLMC) ? CM_ITER_THREADS : CM_ITER_THREADS_BATCH), lds, ctx->stream, a0);
   if (a0.skip_dead)                                  // batches: the all-zero rows, in their lean kernel (after the mailboxes are on their way)
     CM_LAUNCH_SET(k_mc_dead, s, (s.lead->N + 3) / 4, 256, 4 * lds_waves, ctx->stream, a0);
   CM_HIP(hipGetLastError());
@@ -167,7 +169,7 @@ int cm_launch_iter_mid(cm_ctx* ctx, cm_set& s, int it, int iters, int S, int rng
   a.explicit_rng = rng_mode == CM_RNG_EXPLICIT;
   a.skip_dead = (s.B > 1 && do_phi && it >= 0 && roles == 3) ? 1 : 0;
   a.dbg = (ctx->dbg_block0 && it >= 0 && it < 64) ? ctx->dbg_block0 + 8 * it : nullptr;
-  const int threads = s.B == 1 ? CM_ITER_THREADS : CM_ITER_THREADS_BATCH;
+  const int threads = (s.B == 1 || it < 0) ? CM_ITER_THREADS : CM_ITER_THREADS_BATCH;     // it < 0: the FULLMC variant
   const int waves = threads / CM_WAVE;
   size_t lds = (size_t)waves * 2 * S * sizeof(double);
   lds = std::max(lds, s.small_lds_max);

@@ -114,13 +114,15 @@ int cm_wait_active(cm_ctx* ctx, cm_set& s) {
 }
 
 // update_phi stand-alone (final update after the false-negative scan, and the per-phase test hook): one wave per neuron
+// use_dead: rows found to be identically zero take the per-run constants (valid once k_phi_dead has run for the current priors)
 template <bool BATCH, int SEG>
-__global__ __launch_bounds__(256) void k_update_phi(cm_parg<BATCH> pa) {
+__global__ __launch_bounds__(256) void k_update_phi(cm_parg<BATCH> pa, int use_dead) {
   const cm_pdev& p = pa.get();
   const int n = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE;
   if (n >= p.N) return;
   double out[4];
-  phi_body<SEG>(n, threadIdx.x % CM_WAVE, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, out);
+  phi_body<SEG>(n, threadIdx.x % CM_WAVE, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, out,
+                use_dead ? p.phi_dead : nullptr, use_dead ? p.phi_cov_dead : nullptr);
 }
 
 // the per-run constants: update_phi of neuron n for an all-zero lam row -> phi_dead / phi_cov_dead
@@ -157,20 +159,20 @@ int cm_launch_phi_dead(cm_ctx* ctx, cm_set& s, hipStream_t st) {
 }
 
 template <int SEG>
-static void launch_phi(cm_set& s, hipStream_t st) {
-  CM_LAUNCH_SET_T(k_update_phi, (SEG), s, (unsigned)((s.lead->N + 3) / 4), 256, 0, st);
+static void launch_phi(cm_set& s, hipStream_t st, int use_dead) {
+  CM_LAUNCH_SET_T(k_update_phi, (SEG), s, (unsigned)((s.lead->N + 3) / 4), 256, 0, st, use_dead);
 }
 
-int cm_launch_update_phi(cm_ctx* ctx, cm_set& s, hipStream_t st) {
+int cm_launch_update_phi(cm_ctx* ctx, cm_set& s, hipStream_t st, int use_dead) {
   (void)ctx;
   const int V = s.lead->V;                                  // the group shares the lane-segment class of V
-  if (V <= 1) launch_phi<1>(s, st);
-  else if (V <= 2) launch_phi<2>(s, st);
-  else if (V <= 4) launch_phi<4>(s, st);
-  else if (V <= 8) launch_phi<8>(s, st);
-  else if (V <= 16) launch_phi<16>(s, st);
-  else if (V <= 32) launch_phi<32>(s, st);
-  else launch_phi<64>(s, st);
+  if (V <= 1) launch_phi<1>(s, st, use_dead);
+  else if (V <= 2) launch_phi<2>(s, st, use_dead);
+  else if (V <= 4) launch_phi<4>(s, st, use_dead);
+  else if (V <= 8) launch_phi<8>(s, st, use_dead);
+  else if (V <= 16) launch_phi<16>(s, st, use_dead);
+  else if (V <= 32) launch_phi<32>(s, st, use_dead);
+  else launch_phi<64>(s, st, use_dead);
   CM_HIP(hipGetLastError());
   return CM_OK;
 }
