@@ -1,20 +1,26 @@
 #!/usr/bin/env python3
 """CAVIaR iterations/s on MI355X (BASELINE.json metric), one process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg5|nwd] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg5|nwd] [--circuits-per-gpu B] [--no-cpu-baseline]
 
 `--workload nwd` benchmarks the upstream NWD demixer forward pass instead (its own metric, traces/s; see bench_nwd).
 
-A "step" is one complete `caviar()` run of one circuit per GPU: `iters` (50) CAVIaR iterations plus the
-false-negative scan and final phi update (reference circuitmap/optimise/caviar.py:79-98), on synthetic data of the
-BASELINE shape (N=1000 neurons, K=2000 trials, T=900 samples; seeded restatement of the reference's `simulate`, generated on the
-GPU by default -- include/sim_hip.h -- or on the host with --host-sim).
+A "step" is one pass of the hot path over one batch of synthetic input: B independent circuits of the BASELINE shape (N=1000
+neurons, K=2000 trials, T=900 samples; default B = 16) fitted per GPU as ONE lock-step batch -- `iters` (50) CAVIaR iterations each plus
+the false-negative scan and final phi update (reference circuitmap/optimise/caviar.py:79-98) -- through the C ABI's
+cm_caviar_run_batch: the circuit is the outer grid dimension of every kernel launch.  A single fit is a latency chain (N sequential
+Gauss-Seidel steps, 31 dependent Cholesky panels, 10 dependent Newton steps) that occupies a few percent of an MI355X; the batch is
+what fills it, and it is the reference's own scale-out unit (independent circuits, one process each:
+scripts/generate_loho_cv_slurm_scripts.py:8-36).  Every circuit of a batch is bit-identical to its own single fit
+(tests/test_gpu_parity.py).  `--circuits-per-gpu 1` measures the latency form (one circuit at a time); on one GPU the default run reports it
+beside the batch (`single_circuit`).  Synthetic data: seeded restatement of the reference's `simulate`, generated on the GPU by
+default (include/sim_hip.h) or on the host with --host-sim.
 Inputs (PSC integrals + encoded stimulus) are resident in HBM before the timed region; results stay in HBM.
-value = (circuits x iterations) / wall time, whole job, max over ranks.  For N > 1 GPUs every rank fits its own
-independent circuit (N circuits, seeds 2000 .. 2000 + N - 1, rotated over the ranks step by step so that every GPU sees the same
-mix): embarrassingly parallel, no data-path collective ("weak" scaling).
+value = (circuits x iterations) / wall time, whole job, max over ranks.  With N > 1 GPUs there are N sets of B circuits (seeds 2000 ...),
+rotated over the ranks step by step so that every GPU sees the same mix: embarrassingly parallel, no data-path collective ("weak"
+scaling).  `python bench.py --gpus N` started as one process launches its own N ranks (torch.distributed.run) before touching a GPU.
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, live HIP-event timing from the library) and
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel by measured total, live HIP-event timing from the library) and
 `cpu_baseline` (the literal float64 oracle timed on this host, N=1 only).
 """
 import argparse
@@ -285,10 +291,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS) + ["nwd"])
     ap.add_argument("--iters", type=int, default=50)
-    ap.add_argument("--circuits-per-gpu", type=int, default=1, help="B > 1: every step fits B independent circuits per GPU as ONE lock-step "
-                    "batch (cm_caviar_run_batch); value counts all of their iterations")
+    ap.add_argument("--circuits-per-gpu", type=int, default=None, help="B: every step fits B independent circuits per GPU as ONE lock-step batch "
+                    "(cm_caviar_run_batch: the circuit is the outer grid dimension of every launch); value counts all of their iterations.  "
+                    "Default 16 (1 for cfg5: one N=5000 circuit already fills the GPU); 1 = one circuit at a time (the latency form)")
     ap.add_argument("--batch-leg", type=int, default=16, help="with --circuits-per-gpu 1 on one GPU: also time a lock-step batch of this many "
                     "circuits after the main measurement and report it under `batch_throughput` (0 = skip)")
+    ap.add_argument("--no-single-leg", action="store_true", help="with B > 1 on one GPU: skip the one-circuit-at-a-time measurement that is "
+                    "otherwise reported beside the batch under `single_circuit`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--phases", action="store_true", help="stamp every phase of every iteration (more host API calls)")
     ap.add_argument("--circuit-seed", type=int, default=2000, help="seed of rank 0's synthetic circuit (rank r uses seed + r)")
@@ -334,6 +343,8 @@ def main():
 
     wl = WORKLOADS[a.workload]
     N, K, T, H = wl["N"], wl["K"], wl["T"], wl["H"]
+    if a.circuits_per_gpu is None:
+        a.circuits_per_gpu = 1 if a.workload == "cfg5" else 16
     B = max(1, a.circuits_per_gpu)
     pri = default_priors(N)
     # `world` sets of B independent circuits (seeds circuit_seed ...); every rank holds all sets in HBM and fits set (rank + step) mod
@@ -484,6 +495,23 @@ def main():
                                        "k_iter_mid_avg_launch_ms": btms[-1]["mid_ms"] / its, "k_sweep_par_avg_launch_ms": btms[-1]["sweep_seq_ms"] / its,
                                        "fact_ms_per_step": btms[-1]["fact_ms"],
                                        "note": "every circuit bit-identical to its single fit (tests/test_gpu_parity.py::test_fit_batch_baseline_config3)"}
+        if world == 1 and B > 1 and not a.no_single_leg:
+            # the same path one circuit at a time: the latency of a fit (what round 1's bench line reported)
+            q = sets[0][0]
+            for _ in range(2):
+                q.run(*run_args, **opts)
+            barrier()
+            t1 = time.perf_counter()
+            stm = [q.run(*run_args, timing=1 if i_ % 4 == 3 else 0, **opts).as_dict() for i_ in range(8)]
+            barrier()
+            sdt = time.perf_counter() - t1
+            sk = [t for i_, t in enumerate(stm) if i_ % 4 == 3]
+            out["single_circuit"] = {"value": 8 * its / sdt, "unit": "iterations/s", "ms_per_fit": sdt / 8 * 1e3, "steps": 8, "warmup": 2,
+                                     "k_iter_mid_avg_launch_ms": float(np.mean([t["mid_ms"] for t in sk])) / its,
+                                     "k_sweep_par_avg_launch_ms": float(np.mean([t["sweep_seq_ms"] for t in sk])) / its,
+                                     "fact_ms_per_fit": float(np.mean([t["fact_ms"] for t in sk])),
+                                     "batch_x_single": value / (8 * its / sdt),
+                                     "note": "one circuit per step on the same GPU: a latency chain occupying a few percent of the chip"}
         if world == 1 and not a.no_cpu_baseline and sims:
             out["cpu_baseline"] = cpu_baseline(sims[0], pri, wl)
         emit(json.dumps(out))

@@ -343,6 +343,15 @@ static cm_host_rows host_rows(const cm_problem* p) {
   return r;
 }
 
+// end of a run: every circuit's flags and counters into host-mapped pinned memory (read after the final synchronisation: no copies)
+template <bool BATCH>
+__global__ __launch_bounds__(64) void k_collect_status(cm_parg<BATCH> pa, int* __restrict__ out) {
+  const cm_pdev& p = pa.get();
+  const int i = threadIdx.x, c = BATCH ? (int)blockIdx.y : 0;
+  if (i < 4) out[8 * c + i] = p.n_act[i];
+  else if (i < 6) out[8 * c + i] = p.seq_meta[i];
+}
+
 __global__ __launch_bounds__(256) void k_set_ones(double* __restrict__ lam, const int32_t* __restrict__ idx, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) lam[idx[i]] = 1.0;
@@ -644,12 +653,13 @@ static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_option
     CM_TRY(cm_launch_update_phi(ctx, s, st, iters > 0 ? 1 : 0));     // (iters == 0: the per-run constants were not produced)
   }
   CM_HIP(hipEventRecord(ctx->ev[3], st));
+  CM_LAUNCH_SET(k_collect_status, s, 1, 64, 0, st, ctx->d_mailbox + CM_STATUS_OFF);
   CM_HIP(hipStreamSynchronize(st));
+  const int32_t* status = ctx->h_pinned + CM_STATUS_OFF;
   if (iters > 0) {
     for (int c = 0; c < B; ++c) {
-      CM_HIP(hipMemcpy(ctx->h_pinned + 8, s.ps[c]->n_act, 4 * sizeof(int), hipMemcpyDeviceToHost));   // [8..11]: outside the mailbox words
-      if (ctx->h_pinned[9]) { cm_set_error("weight precision matrix not positive definite (circuit %d of the set)", c); return CM_ERR_NOT_SPD; }
-      if (ctx->h_pinned[10]) { cm_set_error("sweep ticket wait timed out (internal error, circuit %d of the set)", c); return CM_ERR_STATE; }
+      if (status[8 * c + 1]) { cm_set_error("weight precision matrix not positive definite (circuit %d of the set)", c); return CM_ERR_NOT_SPD; }
+      if (status[8 * c + 2]) { cm_set_error("sweep ticket wait timed out (internal error, circuit %d of the set)", c); return CM_ERR_STATE; }
     }
   }
   if (ctx->dbg_block0) {
@@ -694,8 +704,7 @@ static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_option
       tm[ci] = t0;
       tm[ci].last_active = last_act[ci];
       tm[ci].sum_active = sum_active[ci];
-      int meta[8] = {0};
-      if (hipMemcpy(meta, s.ps[ci]->seq_meta, sizeof(meta), hipMemcpyDeviceToHost) == hipSuccess) { tm[ci].sum_seq_rows = meta[4]; tm[ci].sum_seq_records = meta[5]; }
+      tm[ci].sum_seq_rows = status[8 * ci + 4]; tm[ci].sum_seq_records = status[8 * ci + 5];
     }
   }
   for (cm_problem* q : s.ps) q->ran = true;

@@ -17,7 +17,8 @@
 #define CM_EV_PER_IT 10
 #define CM_MAX_BATCH 1024      // circuits in one lock-step group
 #define CM_MAILBOX_BATCH0 32   // 64-bit word index of the first per-circuit mailbox of a batch
-#define CM_MAILBOX_WORDS (2 * (CM_MAILBOX_BATCH0 + CM_MAX_BATCH))  // int32 words of host-mapped pinned memory per context: [0..1] single-circuit mailbox, [8..11] scratch, then one 64-bit word per circuit of a batch
+#define CM_STATUS_OFF (2 * (CM_MAILBOX_BATCH0 + CM_MAX_BATCH))   // int32 index of the end-of-run status words: 8 per circuit (n_act[0..3], chain rows, chain records, -, -)
+#define CM_MAILBOX_WORDS (CM_STATUS_OFF + 8 * CM_MAX_BATCH)  // int32 words of host-mapped pinned memory per context: [0..1] single-circuit mailbox, [8..11] scratch, then one 64-bit word per circuit of a batch
 
 void cm_set_error(const char* fmt, ...);
 
