@@ -296,6 +296,9 @@ def main():
                     "Default 16 (1 for cfg5: one N=5000 circuit already fills the GPU); 1 = one circuit at a time (the latency form)")
     ap.add_argument("--batch-leg", type=int, default=16, help="with --circuits-per-gpu 1 on one GPU: also time a lock-step batch of this many "
                     "circuits after the main measurement and report it under `batch_throughput` (0 = skip)")
+    ap.add_argument("--batch-streams", type=int, default=1, help="G > 1: the B circuits of a step run as G lock-step batches of B / G circuits, each on its "
+                    "own context (stream + mailboxes) driven by its own host thread, so that the latency-bound phases of one batch overlap the "
+                    "wide phases of another")
     ap.add_argument("--no-single-leg", action="store_true", help="with B > 1 on one GPU: skip the one-circuit-at-a-time measurement that is "
                     "otherwise reported beside the batch under `single_circuit`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -352,10 +355,13 @@ def main():
     # max-over-ranks time measures the machine, not which rank drew the circuits with the slowest active-set trajectories (fit time
     # varies +-4 % between these seeds).  One GPU: one set.
     gen_ms, sims, sets = None, [], []
-    ctx = _lib.Context(local_rank)
+    G = max(1, min(a.batch_streams, B))
+    ctxs = [_lib.Context(local_rank) for _ in range(G)]
+    ctx = ctxs[0]
     for c in range(world):
         probs = []
         for j in range(B):
+            ctx = ctxs[j % G]                              # circuit j of a set lives on context j mod G
             seed = a.circuit_seed + c * B + j
             if a.host_sim:
                 sim = simulate(N=N, T=T, H=H, trials=K, seed=seed, lite=(N > 2000))
@@ -371,6 +377,11 @@ def main():
                     sims.append({"psc": ctx.download(d["psc_ptr"], np.empty((K, T))), "stim_matrix": ctx.download(d["stim_ptr"], np.empty((N, K)))})
                 ctx.free(d["psc_ptr"]); ctx.free(d["stim_ptr"])
         sets.append(probs)
+    ctx = ctxs[0]
+    pool = None
+    if G > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=G)
     nnz, nvals = sets[0][0].nnz
     run_args = (pri["mu"], pri["beta"], pri["shape"], pri["rate"], pri["phi"], pri["phi_cov"])
     opts = dict(iters=a.iters, seed=0)
@@ -384,23 +395,39 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-        ctx.synchronize()
+        for cx in ctxs:
+            cx.synchronize()
 
     def step_fn(step, timing):
         probs = sets[circuit_for(rank, step, world)]
         if B == 1:
             return probs[0].run(*run_args, timing=timing, **opts).as_dict()
-        return run_batch(probs, pri, timing=timing, **opts)[0].as_dict()
+        if G == 1:
+            return run_batch(probs, pri, timing=timing, **opts)[0].as_dict()
+        futs = [pool.submit(run_batch, probs[g::G], pri, timing=timing, **opts) for g in range(G)]
+        res = [f.result()[0].as_dict() for f in futs]
+        out_ = dict(res[0])
+        for k_ in ("fact_launches", "fact_tile_updates", "sum_seq_rows", "sum_seq_records"):      # counters add up over the groups; times are per group
+            out_[k_] = sum(r_[k_] for r_ in res)
+        return out_
 
     for w in range(max(a.warmup, world)):                  # every set of the rotation has run once before the clock starts
         step_fn(w, 0)
+    import gc
+    gc.collect()
+    gc.disable()                 # a generation-2 collection of this process (torch is loaded) is a 50 ms pause: keep it out of the timed steps
     barrier()
     t0 = time.perf_counter()
-    tms = []
+    tms, step_wall = [], []
     for step in range(a.steps):
+        ts_ = time.perf_counter()
         tms.append(step_fn(step, timing_level if (stamped[step] or a.phases) else 0))
+        step_wall.append((time.perf_counter() - ts_) * 1e3)
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
+    if os.environ.get("CAVIAR_BENCH_TRACE_STEPS"):
+        print("step wall ms:", " ".join("%.2f" % v for v in step_wall), file=sys.stderr)
     n_ranks_seen = 1
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -443,7 +470,7 @@ def main():
             "k_sweep_par": dict(total_ms=seq_ms * its, launches=its, bytes=chain_bytes, note="dependency-bound: Gauss-Seidel chain, one workgroup per circuit"),
         }
         if fl > 0:
-            cands["k_chol_bulk+k_chol_trsm" if N > 48 * 32 else "k_chol_panel"] = dict(
+            cands["k_chol_bulk+k_chol_trsm" if (N > 48 * 32 or B > 1) else "k_chol_panel"] = dict(
                 total_ms=fact_total, launches=fl, bytes=ft * 16384.0 / fl,
                 note="trailing update of the blocked fp64 Cholesky: bandwidth-bound above ~48 tile rows, launch-chain-bound below")
         dom = max(cands, key=lambda k_: cands[k_]["total_ms"])
@@ -464,7 +491,7 @@ def main():
             "dtype": "f64", "data": "synthetic" if gen_ms is None else "synthetic (generated on the GPU in %.2f ms per circuit)" % gen_ms,
             "config": {"workload": "%s: N=%d neurons, K=%d trials, T=%d, H=%d targets/trial, %d iterations + fn_scan per step, "
                                    "%s per GPU and step%s" % (a.workload, N, K, T, H, its,
-                                                              "1 circuit" if B == 1 else "%d circuits as one lock-step batch" % B,
+                                                              "1 circuit" if B == 1 else ("%d circuits as one lock-step batch" % B) if G == 1 else ("%d circuits as %d lock-step batches on %d streams" % (B, G, G)),
                                                               "" if world == 1 else ", %d circuit sets rotated over the ranks" % world),
                        "circuits_per_gpu": B, "nnz_targeted": int(nnz), "distinct_powers": int(nvals) - 1,
                        "mean_active_set": float(np.mean([t["sum_active"] for t in tms])) / max(its, 1)},

@@ -207,7 +207,8 @@ extern "C" int cm_problem_create(cm_ctx* ctx, int32_t N, int32_t K, int32_t T, c
       (rc = dmalloc(&p->phi_cov, 4 * (size_t)N)) || (rc = dmalloc(&p->phi_dead, 8 * (size_t)N)) || (rc = dmalloc(&p->R, K)) ||
       (rc = dmalloc(&p->colany, K)) || (rc = dmalloc(&p->mcE, (size_t)N * CM_MAX_VALS)) ||
       (rc = dmalloc(&p->rs, 4 * (size_t)N)) || (rc = dmalloc(&p->act_idx, N)) || (rc = dmalloc(&p->act_inv, N)) ||
-      (rc = dmalloc(&p->n_act, 4)) || (rc = dmalloc(&p->A, ld * ld)) || (rc = dmalloc(&p->X, ld * ld)) || (rc = dmalloc(&p->Lf, ld * ld)) ||
+      (rc = dmalloc(&p->n_act, 4)) || (rc = dmalloc(&p->A, ld * (ld + CM_LD_PAD))) || (rc = dmalloc(&p->X, ld * (ld + CM_LD_PAD))) ||
+      (rc = dmalloc(&p->Lf, ld * (ld + CM_LD_PAD))) ||
       (rc = dmalloc(&p->Dinv, ld * CM_TILE)) || (rc = dmalloc(&p->rhs, 2 * ld)) || (rc = dmalloc(&p->seq_n, N)) ||
       (rc = dmalloc(&p->seq_off, (size_t)N + 1)) || (rc = dmalloc(&p->seq_pos, N)) || (rc = dmalloc(&p->chunk_first, ((size_t)N + p->nnz) / 256 + 8)) ||
       (rc = dmalloc(&p->seq_meta, 8)) || (rc = dmalloc((char**)&p->packed, ((size_t)N + p->nnz) * 32)))
@@ -460,6 +461,15 @@ bool cm_same_launch_config(const cm_problem* a, const cm_problem* b) {
 
 static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_options* o, cm_timings* tm) {
   hipStream_t st = ctx->stream;
+  static const bool trace_run = getenv("CAVIAR_HIP_TRACE_RUN") != nullptr;      // diagnostic: host wall clock of the phases of a run
+  const auto t_run0 = std::chrono::steady_clock::now();
+  auto t_mark = t_run0;
+  auto lap = [&](const char* what) {
+    if (!trace_run) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[run B=%d] %-12s %8.1f us\n", (int)s.ps.size(), what, std::chrono::duration<double, std::micro>(now - t_mark).count());
+    t_mark = now;
+  };
   cm_problem* p = s.ps[0];                           // the leader: sizes and random tables of the whole set
   const int B = (int)s.ps.size();
   const int N = p->N, S = o->num_mc_samples, iters = o->iters;
@@ -505,8 +515,11 @@ static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_option
       p->keys_iters = iters;
     }
   }
+  lap("tables");
   CM_TRY(set_build(ctx, &s));                        // descriptors (after the table allocations they point to)
+  lap("descriptors");
   CM_TRY(upload_priors(ctx, s, prs));
+  lap("priors");
   CM_TRY(cm_launch_init_state(ctx, s, o->y_xcorr_thresh));
   // update_phi of an all-zero row depends only on the neuron's trial counts and priors: a per-run constant, produced once on the side
   // stream (first needed by the k_iter_mid of iteration 0, half a millisecond from here) and copied by dead rows in every iteration
@@ -611,6 +624,7 @@ static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_option
     }
   }
   CM_HIP(hipEventRecord(ctx->ev[2], st));
+  lap("iterations");
 
   if (o->fn_scan) {                                                  // caviar.py:94-98
     // mu | beta | z | lam are one device slab per circuit.  The scan reads mu and z and only ever WRITES lam (entries set to 1), so
@@ -653,8 +667,10 @@ static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_option
     CM_TRY(cm_launch_update_phi(ctx, s, st, iters > 0 ? 1 : 0));     // (iters == 0: the per-run constants were not produced)
   }
   CM_HIP(hipEventRecord(ctx->ev[3], st));
+  lap("fn_scan");
   CM_LAUNCH_SET(k_collect_status, s, 1, 64, 0, st, ctx->d_mailbox + CM_STATUS_OFF);
   CM_HIP(hipStreamSynchronize(st));
+  lap("final sync");
   const int32_t* status = ctx->h_pinned + CM_STATUS_OFF;
   if (iters > 0) {
     for (int c = 0; c < B; ++c) {

@@ -11,15 +11,15 @@
 // Neither role reads what the other writes (sigma/z/mu/beta vs phi/mcE), so they overlap inside the launch without
 // streams or events; the launch is as long as its longer role (~phi + MC logit).
 //
-// One circuit: 256-thread workgroups (4 waves = one per SIMD; the blocks spread one per CU: shortest latency).  A batch of circuits
-// (blockIdx.y): 1024-thread workgroups, so that the dynamic LDS block 0 needs (up to 56 KB, allocated by every workgroup of the
-// launch) still leaves the CU fully occupied by the per-neuron waves -- the batch is a throughput problem, not a latency one.
+// 256-thread workgroups (4 waves = one per SIMD; for one circuit the blocks spread one per CU: shortest latency).  A batch of
+// circuits (blockIdx.y) keeps that shape: measured 256 = 512 > 1024 threads per workgroup (a workgroup holds its CU slot until its
+// slowest wave -- a row with a full Newton iteration -- is done; the dynamic LDS, ~18 KB, does not limit occupancy).
 #include <stdlib.h>
 
 #include "cm_bodies.h"
 
 #define CM_ITER_THREADS 256
-#define CM_ITER_THREADS_BATCH 1024
+#define CM_ITER_THREADS_BATCH 256
 
 struct IterDyn {     // what changes from iteration to iteration (common to all circuits of a batch)
   int it, max_iters; double penalty, scale_factor, tol; int do_sigma, seq, do_solve, stage_ok, do_phi, do_mc, S, roles, nx, explicit_rng, skip_dead;
@@ -62,10 +62,8 @@ __global__ __launch_bounds__(256) void k_mc_dead(cm_parg<BATCH> pa, IterDyn a) {
   }
 }
 
-// (the FULLMC variant -- one launch per run, quantile function inlined -- keeps 256-thread workgroups in batches too: under the
-// 128-register cap of a 1024-thread workgroup it spills)
 template <bool BATCH, int SEG, bool FULLMC>
-__global__ __launch_bounds__((BATCH && !FULLMC) ? CM_ITER_THREADS_BATCH : CM_ITER_THREADS) void k_iter_mid(cm_parg<BATCH> pa, IterDyn a) {
+__global__ __launch_bounds__(CM_ITER_THREADS) void k_iter_mid(cm_parg<BATCH> pa, IterDyn a) {
   extern __shared__ double sm[];
   const cm_pdev& p = pa.get();
   if (blockIdx.x <= 1) {
@@ -127,7 +125,7 @@ int cm_small_cap(const cm_problem* p) {
 }
 
 template <int SEG, bool FULLMC>
-static int launch_iter2(cm_ctx* ctx, cm_set& s, const IterDyn& a0, size_t lds, int blocks, size_t lds_waves) {
+static int launch_iter2(cm_ctx* ctx, cm_set& s, const IterDyn& a0, size_t lds, int blocks, size_t lds_waves, int threads) {
   const int slot = CM_LDS_ITER + 4 * (31 - __builtin_clz((unsigned)SEG)) + (FULLMC ? 1 : 0) + (s.B > 1 ? 2 : 0);          // SEG = 1, 2, 4 .. 64
   if (s.B == 1) CM_TRY(cm_raise_lds(ctx, slot, reinterpret_cast<const void*>(k_iter_mid<false, SEG, FULLMC>), lds, 48 * 1024));
   else CM_TRY(cm_raise_lds(ctx, slot, reinterpret_cast<const void*>(k_iter_mid<true, SEG, FULLMC>), lds, 48 * 1024));
@@ -143,16 +141,16 @@ static int launch_iter2(cm_ctx* ctx, cm_set& s, const IterDyn& a0, size_t lds, i
     CM_HIP(hipGetLastError());
     return CM_OK;
   }
-  CM_LAUNCH_SET_T(k_iter_mid, (SEG, FULLMC), s, blocks, ((s.B == 1 || FULLMC) ? CM_ITER_THREADS : CM_ITER_THREADS_BATCH), lds, ctx->stream, a0);
+  CM_LAUNCH_SET_T(k_iter_mid, (SEG, FULLMC), s, blocks, threads, lds, ctx->stream, a0);
   if (a0.skip_dead)                                  // batches: the all-zero rows, in their lean kernel (after the mailboxes are on their way)
     CM_LAUNCH_SET(k_mc_dead, s, (s.lead->N + 3) / 4, 256, 4 * lds_waves, ctx->stream, a0);
   CM_HIP(hipGetLastError());
   return CM_OK;
 }
 template <int SEG>
-static int launch_iter(cm_ctx* ctx, cm_set& s, const IterDyn& a, size_t lds, int blocks) {
+static int launch_iter(cm_ctx* ctx, cm_set& s, const IterDyn& a, size_t lds, int blocks, int threads) {
   const size_t lw = 2 * (size_t)a.S * sizeof(double);
-  return a.it < 0 ? launch_iter2<SEG, true>(ctx, s, a, lds, blocks, lw) : launch_iter2<SEG, false>(ctx, s, a, lds, blocks, lw);
+  return a.it < 0 ? launch_iter2<SEG, true>(ctx, s, a, lds, blocks, lw, threads) : launch_iter2<SEG, false>(ctx, s, a, lds, blocks, lw, threads);
 }
 
 // it = -1: state init (no sigma / phi; MC logit and solve for iteration 0).  Otherwise the middle of iteration `it`.
@@ -169,7 +167,7 @@ int cm_launch_iter_mid(cm_ctx* ctx, cm_set& s, int it, int iters, int S, int rng
   a.explicit_rng = rng_mode == CM_RNG_EXPLICIT;
   a.skip_dead = (s.B > 1 && do_phi && it >= 0 && roles == 3) ? 1 : 0;
   a.dbg = (ctx->dbg_block0 && it >= 0 && it < 64) ? ctx->dbg_block0 + 8 * it : nullptr;
-  const int threads = (s.B == 1 || it < 0) ? CM_ITER_THREADS : CM_ITER_THREADS_BATCH;     // it < 0: the FULLMC variant
+  const int threads = s.B == 1 ? CM_ITER_THREADS : CM_ITER_THREADS_BATCH;
   const int waves = threads / CM_WAVE;
   size_t lds = (size_t)waves * 2 * S * sizeof(double);
   lds = std::max(lds, s.small_lds_max);
@@ -181,14 +179,14 @@ int cm_launch_iter_mid(cm_ctx* ctx, cm_set& s, int it, int iters, int S, int rng
   a.roles = roles;
   if (split && it >= 0 && roles == 3) {
     a.roles = 2;
-    if (V <= 4) { CM_TRY(launch_iter<4>(ctx, s, a, lds, blocks)); } else { CM_TRY(launch_iter<64>(ctx, s, a, lds, blocks)); }
+    if (V <= 4) { CM_TRY(launch_iter<4>(ctx, s, a, lds, blocks, threads)); } else { CM_TRY(launch_iter<64>(ctx, s, a, lds, blocks, threads)); }
     a.roles = 1;
   }
-  if (V <= 1) return launch_iter<1>(ctx, s, a, lds, blocks);
-  if (V <= 2) return launch_iter<2>(ctx, s, a, lds, blocks);
-  if (V <= 4) return launch_iter<4>(ctx, s, a, lds, blocks);
-  if (V <= 8) return launch_iter<8>(ctx, s, a, lds, blocks);
-  if (V <= 16) return launch_iter<16>(ctx, s, a, lds, blocks);
-  if (V <= 32) return launch_iter<32>(ctx, s, a, lds, blocks);
-  return launch_iter<64>(ctx, s, a, lds, blocks);
+  if (V <= 1) return launch_iter<1>(ctx, s, a, lds, blocks, threads);
+  if (V <= 2) return launch_iter<2>(ctx, s, a, lds, blocks, threads);
+  if (V <= 4) return launch_iter<4>(ctx, s, a, lds, blocks, threads);
+  if (V <= 8) return launch_iter<8>(ctx, s, a, lds, blocks, threads);
+  if (V <= 16) return launch_iter<16>(ctx, s, a, lds, blocks, threads);
+  if (V <= 32) return launch_iter<32>(ctx, s, a, lds, blocks, threads);
+  return launch_iter<64>(ctx, s, a, lds, blocks, threads);
 }

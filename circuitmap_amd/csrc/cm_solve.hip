@@ -21,8 +21,10 @@
   const cm_pdev& p = pa.get();                                                    \
   const int na = BATCH ? p.n_act[0] : na_arg;                                     \
   if (BATCH && cm_solve_kind(na, p.small_cap, skip_own != 0) != (KIND)) return;       \
-  const int nblk = (na + TS - 1) / TS, ld = nblk * TS;                            \
-  (void)nblk; (void)ld;
+  const int nblk = (na + TS - 1) / TS, nrow = nblk * TS, ld = nrow + CM_LD_PAD;  \
+  (void)nblk; (void)nrow; (void)ld;
+// Leading dimension of the solve matrices = rows + CM_LD_PAD: a power-of-two row stride (1024 doubles at N = 1000) maps the 32 rows
+// of a tile -- and the same tile of every circuit of a batch -- onto a fraction of the memory channels.
 #define CM_LARGE_TILES 48     // more tile rows than this: panel solve + lean trailing-update kernels (bandwidth-bound regime)
 
 #define CM_LINV_THREADS 1024  // threads that run the diagonal-tile elimination (256 was measured slower: 4 elements per thread)
@@ -35,7 +37,7 @@ template <bool BATCH>
 __global__ __launch_bounds__(64) void k_build_precision(cm_parg<BATCH> pa, int na_arg, int skip_own) {
   CM_SOLVE_PROLOGUE(2)
   const int n_act = na;
-  if ((int)blockIdx.x >= ld) return;
+  if ((int)blockIdx.x >= nrow) return;
   const double* __restrict__ lam = p.lam;
   const int* __restrict__ row_ptr = p.row_ptr;
   const int* __restrict__ col = p.col;
@@ -55,11 +57,11 @@ __global__ __launch_bounds__(64) void k_build_precision(cm_parg<BATCH> pa, int n
   const int lane = threadIdx.x;
   double* Arow = A + (size_t)a * ld;
   if (a >= n_act) {                 // identity padding up to the tile multiple
-    for (int b = lane; b < ld; b += CM_WAVE) Arow[b] = (b == a) ? 1.0 : 0.0;
+    for (int b = lane; b < nrow; b += CM_WAVE) Arow[b] = (b == a) ? 1.0 : 0.0;
     if (lane == 0) rhs[a] = 0.0;
     return;
   }
-  for (int b = lane; b < ld; b += CM_WAVE) acc[b] = 0.0;
+  for (int b = lane; b < nrow; b += CM_WAVE) acc[b] = 0.0;
   const int n = act_idx[a];
   const double sig = scal[CM_S_SHAPE] / scal[CM_S_RATE];
   for (int e = row_ptr[n]; e < row_ptr[n + 1]; ++e) {      // sequential over this neuron's trials: fixed summation order
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(64) void k_build_precision(cm_parg<BATCH> pa, int n
   }
   const double b0 = beta_prior[n];
   const double prec0 = 1.0 / (b0 * b0);
-  for (int b = lane; b < ld; b += CM_WAVE) {
+  for (int b = lane; b < nrow; b += CM_WAVE) {
     double v = 0.0;
     if (b < n_act) v = (b == a) ? sig * (rs[(size_t)n * 4 + 3] + acc[b]) + prec0 : sig * acc[b];
     Arow[b] = v;
@@ -592,7 +594,7 @@ __global__ __launch_bounds__(64) void k_colsum_partial(cm_parg<BATCH> pa, int na
   const int c = ((int)blockIdx.x % nbx) * 64 + threadIdx.x;
   const int chunk = (int)blockIdx.x / nbx;
   const int rbeg = chunk * CM_COLCHUNK, rend = min(n, rbeg + CM_COLCHUNK);
-  if (rbeg >= n || ((int)blockIdx.x % nbx) * 64 >= ld) return;
+  if (rbeg >= n || ((int)blockIdx.x % nbx) * 64 >= nrow) return;
   double sm = 0.0, sb = 0.0;
   if (c < n) {
     // 8 independent loads in flight, then the 8 accumulations in row order (the summation order is part of the result)
@@ -609,7 +611,7 @@ __global__ __launch_bounds__(64) void k_colsum_partial(cm_parg<BATCH> pa, int na
         if (r0 + i < rend) { sm = fma(x[i], ww[i], sm); sb = fma(x[i], x[i], sb); }
     }
   }
-  if (c < ld) {
+  if (c < nrow) {
     part[((size_t)chunk * 2 + 0) * ld + c] = sm;
     part[((size_t)chunk * 2 + 1) * ld + c] = sb;
   }
@@ -693,7 +695,7 @@ int cm_solve_launch(cm_ctx* ctx, cm_set& s, int skip_mode, hipEvent_t fact_begin
   CM_LAUNCH_SET(k_fill_prior, s, (N + 255) / 256, 256, 0, st, na1, skip_le);
   if (nblk_max == 0) { CM_HIP(hipGetLastError()); return CM_OK; }
   const int nblk = nblk_max;
-  const int ld = nblk * TS;
+  const int ld = nblk * TS;                        // rows (the row stride is ld + CM_LD_PAD)
   if ((size_t)ld * sizeof(double) > 150 * 1024) { cm_set_error("active set of %d neurons exceeds the LDS row accumulator", na_tiled); return CM_ERR_INVALID; }
   if (s.B == 1) CM_TRY(cm_raise_lds(ctx, CM_LDS_BUILD_PREC, reinterpret_cast<const void*>(k_build_precision<false>), (size_t)ld * sizeof(double), 48 * 1024));
   else CM_TRY(cm_raise_lds(ctx, CM_LDS_BUILD_PREC_B, reinterpret_cast<const void*>(k_build_precision<true>), (size_t)ld * sizeof(double), 48 * 1024));
