@@ -6,9 +6,10 @@
 `--workload nwd` benchmarks the upstream NWD demixer forward pass instead (its own metric, traces/s; see bench_nwd).
 
 A "step" is one pass of the hot path over one batch of synthetic input: B independent circuits of the BASELINE shape (N=1000
-neurons, K=2000 trials, T=900 samples; default B = 16) fitted per GPU as ONE lock-step batch -- `iters` (50) CAVIaR iterations each plus
-the false-negative scan and final phi update (reference circuitmap/optimise/caviar.py:79-98) -- through the C ABI's
-cm_caviar_run_batch: the circuit is the outer grid dimension of every kernel launch.  A single fit is a latency chain (N sequential
+neurons, K=2000 trials, T=900 samples; default B = 64) fitted per GPU as G = 4 lock-step batches of 16 -- `iters` (50) CAVIaR iterations
+each plus the false-negative scan and final phi update (reference circuitmap/optimise/caviar.py:79-98) -- through the C ABI's
+cm_caviar_run_batch: the circuit is the outer grid dimension of every kernel launch; the G batches run on G contexts (HIP streams, one
+host thread each), so that the serial phases of one overlap the wide phases of the others.  A single fit is a latency chain (N sequential
 Gauss-Seidel steps, 31 dependent Cholesky panels, 10 dependent Newton steps) that occupies a few percent of an MI355X; the batch is
 what fills it, and it is the reference's own scale-out unit (independent circuits, one process each:
 scripts/generate_loho_cv_slurm_scripts.py:8-36).  Every circuit of a batch is bit-identical to its own single fit
@@ -293,10 +294,10 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--circuits-per-gpu", type=int, default=None, help="B: every step fits B independent circuits per GPU as ONE lock-step batch "
                     "(cm_caviar_run_batch: the circuit is the outer grid dimension of every launch); value counts all of their iterations.  "
-                    "Default 16 (1 for cfg5: one N=5000 circuit already fills the GPU); 1 = one circuit at a time (the latency form)")
+                    "Default 64 (1 for cfg5: one N=5000 circuit already fills the GPU); 1 = one circuit at a time (the latency form)")
     ap.add_argument("--batch-leg", type=int, default=16, help="with --circuits-per-gpu 1 on one GPU: also time a lock-step batch of this many "
                     "circuits after the main measurement and report it under `batch_throughput` (0 = skip)")
-    ap.add_argument("--batch-streams", type=int, default=1, help="G > 1: the B circuits of a step run as G lock-step batches of B / G circuits, each on its "
+    ap.add_argument("--batch-streams", type=int, default=None, help="G (default 4, 1 when B < 8): the B circuits of a step run as G lock-step batches of B / G circuits, each on its "
                     "own context (stream + mailboxes) driven by its own host thread, so that the latency-bound phases of one batch overlap the "
                     "wide phases of another")
     ap.add_argument("--no-single-leg", action="store_true", help="with B > 1 on one GPU: skip the one-circuit-at-a-time measurement that is "
@@ -347,8 +348,10 @@ def main():
     wl = WORKLOADS[a.workload]
     N, K, T, H = wl["N"], wl["K"], wl["T"], wl["H"]
     if a.circuits_per_gpu is None:
-        a.circuits_per_gpu = 1 if a.workload == "cfg5" else 16
+        a.circuits_per_gpu = 1 if a.workload == "cfg5" else 64
     B = max(1, a.circuits_per_gpu)
+    if a.batch_streams is None:
+        a.batch_streams = 4 if B >= 8 else 1
     pri = default_priors(N)
     # `world` sets of B independent circuits (seeds circuit_seed ...); every rank holds all sets in HBM and fits set (rank + step) mod
     # world at step `step`: at any moment the GPUs work on different circuits, and over the run every GPU sees the same mix, so the

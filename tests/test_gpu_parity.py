@@ -278,18 +278,21 @@ def test_rare_paths_vs_literal_oracle(case):
         assert rel_err(res[i], ref[i]) < 1e-7, (case, nm)
 
 
-def test_fit_batch_single_gpu_equals_direct():
-    """batch.fit_batch without a process group == a loop of caviar() calls, bit for bit."""
+@pytest.mark.parametrize("per_launch,streams", [(16, 1), (2, 3)])
+def test_fit_batch_single_gpu_equals_direct(per_launch, streams):
+    """batch.fit_batch without a process group == a loop of caviar() calls, bit for bit: as one lock-step batch, and as several
+    batches in flight on several contexts (streams, one host thread each)."""
     from circuitmap_amd import batch
     from circuitmap_amd.optimise import caviar
     from circuitmap_amd.simulation import simulate
     circuits = []
-    for c in range(3):
+    for c in range(5):
         sim = simulate(N=40, trials=120, seed=50 + c)
         circuits.append((sim["psc"], sim["stim_matrix"]))
     pri = default_priors(40)
     opts = dict(iters=6, seed=1)
-    got = batch.fit_batch(circuits, priors=pri, fit_options=opts)
+    got = batch.fit_batch(circuits, priors=pri, fit_options=opts, circuits_per_launch=per_launch, streams=streams)
+    assert len(got) == 5
     for (psc, stim), g in zip(circuits, got):
         res = caviar(psc, stim, *prior_args(pri), **opts)
         for i, nm in enumerate(OUT_NAMES):
