@@ -6,10 +6,12 @@
 `--workload nwd` benchmarks the upstream NWD demixer forward pass instead (its own metric, traces/s; see bench_nwd).
 
 A "step" is one pass of the hot path over one batch of synthetic input: B independent circuits of the BASELINE shape (N=1000
-neurons, K=2000 trials, T=900 samples; default B = 64) fitted per GPU as G = 4 lock-step batches of 16 -- `iters` (50) CAVIaR iterations
-each plus the false-negative scan and final phi update (reference circuitmap/optimise/caviar.py:79-98) -- through the C ABI's
-cm_caviar_run_batch: the circuit is the outer grid dimension of every kernel launch; the G batches run on G contexts (HIP streams, one
-host thread each), so that the serial phases of one overlap the wide phases of the others.  A single fit is a latency chain (N sequential
+neurons, K=2000 trials, T=900 samples; default B = 64) fitted per GPU as ONE lock-step batch -- `iters` (50) CAVIaR iterations each plus
+the false-negative scan and final phi update (reference circuitmap/optimise/caviar.py:79-98) -- through the C ABI's
+cm_caviar_run_batch: the circuit is the outer grid dimension of every kernel launch.  (`--batch-streams G` splits the B circuits into G
+lock-step batches on G contexts / HIP streams, one host thread each, so that the serial phases of one overlap the wide phases of the
+others: ~15 % more throughput, reported by the default run as the extra leg `interleaved_streams`; the headline keeps one batch per
+step so that every per-kernel figure -- HIP events, rocprof, PMC -- describes a kernel that had the GPU to itself.)  A single fit is a latency chain (N sequential
 Gauss-Seidel steps, 31 dependent Cholesky panels, 10 dependent Newton steps) that occupies a few percent of an MI355X; the batch is
 what fills it, and it is the reference's own scale-out unit (independent circuits, one process each:
 scripts/generate_loho_cv_slurm_scripts.py:8-36).  Every circuit of a batch is bit-identical to its own single fit
@@ -297,9 +299,11 @@ def main():
                     "Default 64 (1 for cfg5: one N=5000 circuit already fills the GPU); 1 = one circuit at a time (the latency form)")
     ap.add_argument("--batch-leg", type=int, default=16, help="with --circuits-per-gpu 1 on one GPU: also time a lock-step batch of this many "
                     "circuits after the main measurement and report it under `batch_throughput` (0 = skip)")
-    ap.add_argument("--batch-streams", type=int, default=None, help="G (default 4, 1 when B < 8): the B circuits of a step run as G lock-step batches of B / G circuits, each on its "
+    ap.add_argument("--batch-streams", type=int, default=1, help="G (default 1): the B circuits of a step run as G lock-step batches of B / G circuits, each on its "
                     "own context (stream + mailboxes) driven by its own host thread, so that the latency-bound phases of one batch overlap the "
                     "wide phases of another")
+    ap.add_argument("--streams-leg", type=int, default=None, help="on one GPU with one lock-step batch per step: also time the same B circuits as "
+                    "this many interleaved batches on as many streams and report it under `interleaved_streams` (default 4; 0 = skip)")
     ap.add_argument("--no-single-leg", action="store_true", help="with B > 1 on one GPU: skip the one-circuit-at-a-time measurement that is "
                     "otherwise reported beside the batch under `single_circuit`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -350,8 +354,8 @@ def main():
     if a.circuits_per_gpu is None:
         a.circuits_per_gpu = 1 if a.workload == "cfg5" else 64
     B = max(1, a.circuits_per_gpu)
-    if a.batch_streams is None:
-        a.batch_streams = 4 if B >= 8 else 1
+    if a.streams_leg is None:
+        a.streams_leg = 4 if (B >= 16 and a.batch_streams == 1) else 0
     pri = default_priors(N)
     # `world` sets of B independent circuits (seeds circuit_seed ...); every rank holds all sets in HBM and fits set (rank + step) mod
     # world at step `step`: at any moment the GPUs work on different circuits, and over the run every GPU sees the same mix, so the
@@ -409,10 +413,7 @@ def main():
             return run_batch(probs, pri, timing=timing, **opts)[0].as_dict()
         futs = [pool.submit(run_batch, probs[g::G], pri, timing=timing, **opts) for g in range(G)]
         res = [f.result()[0].as_dict() for f in futs]
-        out_ = dict(res[0])
-        for k_ in ("fact_launches", "fact_tile_updates", "sum_seq_rows", "sum_seq_records"):      # counters add up over the groups; times are per group
-            out_[k_] = sum(r_[k_] for r_ in res)
-        return out_
+        return res[0]                                      # per-kernel times and counters: those of the first group (B / G circuits per launch)
 
     for w in range(max(a.warmup, world)):                  # every set of the rotation has run once before the clock starts
         step_fn(w, 0)
@@ -455,23 +456,35 @@ def main():
         #     The ndtri(u) table row the MC logit reads (2 S x 8 B per neuron) is listed SEPARATELY (`table_bytes_per_launch`): the
         #     table is an artefact of this implementation (it replaces S quantile evaluations per neuron), not compulsory traffic.
         mid_ms = mean_k("mid_ms") / its
-        mid_bytes = B * (K * (8 + 8 + 1 + 1 + 8) + N * (8 + 8 + 32) + nnz * 9 + N * (8 + 4 * nvals + 48 + 48 + 4 + 8 + 8 * (nvals - 1)))
-        mid_table = B * N * 2 * S * 8
+        Bl = B // G if G > 1 else B                          # circuits per launch
+        mid_bytes = Bl * (K * (8 + 8 + 1 + 1 + 8) + N * (8 + 8 + 32) + nnz * 9 + N * (8 + 4 * nvals + 48 + 48 + 4 + 8 + 8 * (nvals - 1)))
+        mid_table = Bl * N * 2 * S * 16
         # (2) the Gauss-Seidel chain kernel (k_sweep_par), one launch per iteration: the records it actually streamed
         seq_ms = mean_k("sweep_seq_ms") / its
         recs = float(np.mean([t["sum_seq_records"] for t in tms])) / its         # 32-B records per launch and circuit (average over the fit)
         rows = float(np.mean([t["sum_seq_rows"] for t in tms])) / its
-        chain_bytes = B * (recs * 32 + (recs - rows) * 8 + K * 12)                # records + lam writes + R and ticket vectors
+        chain_bytes = Bl * (recs * 32 + (recs - rows) * 8 + K * 12)               # records + lam writes + R and ticket vectors
         # (3) trailing updates of the tiled Cholesky (k_chol_panel, or k_chol_trsm + k_chol_bulk above 48 tile rows): per launch the
         #     t (t + 1) / 2 trailing 32 x 32 fp64 tiles are read and rewritten (16 KB per tile)
         fl = float(np.mean([t["fact_launches"] for t in tms_k]))
         ft = float(np.mean([t["fact_tile_updates"] for t in tms_k]))
         fact_total = mean_k("fact_ms")
+        mid_name = "k_iter_mid"
+        # batches: the all-zero rows (95 % in the steady state) run in their own lean kernel k_mc_dead, timed separately; their share of the bytes:
+        # phi / phi_cov constants in, phi / phi_cov out, inverse order, logits out (the shared table is listed separately, as above)
+        dead_ms = mean_k("mc_dead_ms") / its
+        dead_frac = 1.0 - float(np.mean([t["sum_active"] for t in tms])) / max(its, 1) / N
+        dead_bytes = Bl * dead_frac * N * (8 + 64 + 48 + 4 + 8 * (nvals - 1))
+        if Bl > 1:
+            mid_bytes -= dead_bytes
         cands = {
-            "k_iter_mid": dict(total_ms=mid_ms * its, launches=its, bytes=mid_bytes, note="latency-bound: 10 dependent Newton steps of fp64 exp/log per neuron, "
+            mid_name: dict(total_ms=mid_ms * its, launches=its, bytes=mid_bytes, note="latency-bound: 10 dependent Newton steps of fp64 exp/log per neuron, "
                                "then the next iteration's Monte-Carlo logit; block 0: sigma / z / fused small solve"),
             "k_sweep_par": dict(total_ms=seq_ms * its, launches=its, bytes=chain_bytes, note="dependency-bound: Gauss-Seidel chain, one workgroup per circuit"),
         }
+        if Bl > 1:
+            cands["k_mc_dead"] = dict(total_ms=dead_ms * its, launches=its, bytes=dead_bytes, note="fp64 VALU issue: the next Monte-Carlo logit of every all-zero row "
+                                      "(S x P sigmoid-logit evaluations per row), one wavefront per row")
         if fl > 0:
             cands["k_chol_bulk+k_chol_trsm" if (N > 48 * 32 or B > 1) else "k_chol_panel"] = dict(
                 total_ms=fact_total, launches=fl, bytes=ft * 16384.0 / fl,
@@ -483,9 +496,9 @@ def main():
         d = cands[dom]
         # HBM traffic of that kernel from rocprofv3 PMC passes (profiles/, gfx950 correction FETCH_SIZE x 2 + WRITE_SIZE per the MI355X guide);
         # only quoted when a summary for THIS build, workload and batch size is committed -- otherwise null (see profiles/README.md)
-        traffic = PMC_TRAFFIC.get((a.workload, B, dom))
+        traffic = PMC_TRAFFIC.get((a.workload, Bl, dom))
         phase = {k: float(np.mean([t[k] for t in tms])) for k in ("total_ms", "iters_ms", "fn_scan_ms")}
-        phase.update({k: mean_k(k) for k in ("solve_ms", "sweep_indep_ms", "sweep_seq_ms", "mid_ms", "post_ms", "fact_ms")})
+        phase.update({k: mean_k(k) for k in ("solve_ms", "sweep_indep_ms", "sweep_seq_ms", "mid_ms", "mc_dead_ms", "post_ms", "fact_ms")})
         phase["steps_with_kernel_events"] = int(sum(1 for st_ in stamped if st_ or a.phases))
         out = {
             "metric": "CAVIaR iterations/sec (N=%d, K=%d, T=%d)" % (N, K, T),
@@ -508,7 +521,10 @@ def main():
                          "other_kernels": {k_: {"avg_launch_ms": c_["avg_launch_ms"], "total_ms_per_step": c_["total_ms"],
                                                 "algorithmic_bytes_per_launch": int(c_["bytes"]), "achieved": c_["achieved"]}
                                            for k_, c_ in cands.items() if k_ != dom},
+                         "pmc_source": PMC_SOURCE.get((a.workload, Bl, dom)),
                          "k_iter_mid_table_bytes_per_launch": int(mid_table),
+                         "k_iter_mid_table_note": "(ndtri(u), u) pairs the Monte-Carlo logit reads, 2 S x 16 B per neuron and launch; one table serves all "
+                                                  "circuits of a batch (the streams are data independent), so its HBM share is 1 / B of this figure",
                          # whole-iteration dense-equivalent RATE: bytes the reference's dense formulation would move per
                          # iteration x iterations/s.  The compressed encoding never moves those bytes -- this is not traffic and not `achieved`.
                          "dense_equiv_rate": {"B_iter": B_iter, "F_iter": F_iter, "hbm_frac": B_iter * value / world / (HBM_PEAK_GBS * 1e9),
@@ -525,6 +541,43 @@ def main():
                                        "k_iter_mid_avg_launch_ms": btms[-1]["mid_ms"] / its, "k_sweep_par_avg_launch_ms": btms[-1]["sweep_seq_ms"] / its,
                                        "fact_ms_per_step": btms[-1]["fact_ms"],
                                        "note": "every circuit bit-identical to its single fit (tests/test_gpu_parity.py::test_fit_batch_baseline_config3)"}
+        if world == 1 and B > 1 and a.streams_leg and a.streams_leg > 1 and G == 1:
+            # the same B circuits as several lock-step batches in flight on separate contexts (HIP streams), one host thread each
+            from concurrent.futures import ThreadPoolExecutor
+            from circuitmap_amd.simulation import simulate_device
+            Gs = a.streams_leg
+            lctx = [_lib.Context(local_rank) for _ in range(Gs)]
+            lprobs = [[] for _ in range(Gs)]
+            for j in range(B):
+                cx = lctx[j % Gs]
+                d = simulate_device(N=N, T=T, H=H, trials=K, seed=a.circuit_seed + j, device_id=local_rank, keep_on_device=True, ctx=cx)
+                lprobs[j % Gs].append(Problem(cx, None, None, device_ptrs=(N, K, T, d["psc_ptr"], d["stim_ptr"])))
+                cx.free(d["psc_ptr"]); cx.free(d["stim_ptr"])
+            with ThreadPoolExecutor(max_workers=Gs) as ex:
+                def lstep():
+                    for f in [ex.submit(run_batch, lprobs[g], pri, **opts) for g in range(Gs)]:
+                        f.result()
+                for _ in range(2):
+                    lstep()
+                for cx in lctx:
+                    cx.synchronize()
+                gc.collect(); gc.disable()
+                t1 = time.perf_counter()
+                for _ in range(6):
+                    lstep()
+                for cx in lctx:
+                    cx.synchronize()
+                ldt = time.perf_counter() - t1
+                gc.enable()
+            for g in range(Gs):
+                for q in lprobs[g]:
+                    q.close()
+            lval = B * 6 * its / ldt
+            out["interleaved_streams"] = {"streams": Gs, "circuits_per_launch": B // Gs, "value": lval, "unit": "iterations/s", "steps": 6, "warmup": 2,
+                                          "ms_per_step": ldt / 6 * 1e3, "x_one_batch": lval / value,
+                                          "note": "the serial phases of one batch (Gauss-Seidel chains, Cholesky panels) overlap the wide phases of the "
+                                                  "others; per-kernel timings are then no longer those of a kernel alone on the GPU, which is why the "
+                                                  "headline keeps one batch per step"}
         if world == 1 and B > 1 and not a.no_single_leg:
             # the same path one circuit at a time: the latency of a fit (what round 1's bench line reported)
             q = sets[0][0]
@@ -556,7 +609,23 @@ def main():
 
 # HBM bytes per launch from committed rocprofv3 PMC summaries, keyed (workload, circuits per GPU, kernel): filled in when a profile of
 # the current build exists (profiles/README.md lists the source file of every entry)
-PMC_TRAFFIC = {}
+def _kb(fetch_kb, write_kb):
+    return int((2.0 * fetch_kb + write_kb) * 1024)
+
+
+PMC_TRAFFIC = {
+    # one lock-step batch of 64 circuits (profiles/r02_a_cfg3_B64_pmc_{fetch,write}_size.csv): k_iter_mid 7093.3 + k_mc_dead 9963.9 KB fetched,
+    # 1921.8 + 4668.2 KB written per launch pair; k_chol_bulk 62438.5 + k_chol_trsm 5135.0 KB fetched, 71869.5 + 6817.1 KB written per panel
+    ("cfg3", 64, "k_iter_mid"): _kb(7093.3, 1921.8),
+    ("cfg3", 64, "k_mc_dead"): _kb(9963.9, 4668.2),
+    ("cfg3", 64, "k_chol_bulk+k_chol_trsm"): _kb(62438.5 + 5135.0, 71869.5 + 6817.1),
+    # one circuit at a time (profiles/r02_b_cfg3_B1_pmc_{fetch,write}_size.csv)
+    ("cfg3", 1, "k_iter_mid"): _kb(1802.1, 101.8),
+    ("cfg3", 1, "k_chol_panel"): _kb(1112.5, 1317.2),
+    ("cfg3", 1, "k_sweep_par"): _kb(57.3, 13.0),
+}
+PMC_SOURCE = {k: ("profiles/r02_a_cfg3_B64_pmc_fetch_size.csv + _pmc_write_size.csv" if k[1] == 64 else "profiles/r02_b_cfg3_B1_pmc_fetch_size.csv + _pmc_write_size.csv")
+              + " (separate --pmc passes; traffic = 2 x FETCH_SIZE + WRITE_SIZE per the MI355X guide's gfx950 correction)" for k in PMC_TRAFFIC}
 
 
 if __name__ == "__main__":

@@ -613,7 +613,7 @@ static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_option
     // :84-88 update_sigma, update_phi, z, spont_rate; then block_update_mu (small sets) and the MC logit of iteration it + 1
     if (it == 0) CM_HIP(hipStreamWaitEvent(st, ctx->ev[9], 0));      // the dead-row constants (long done)
     if (timed) CM_HIP(hipEventRecord(EV(it, 8), st));
-    CM_TRY(cm_launch_iter_mid(ctx, s, it, iters, S, o->rng_mode, o, 1, 1));
+    CM_TRY(cm_launch_iter_mid(ctx, s, it, iters, S, o->rng_mode, o, 1, 1, 3, (timed && B > 1) ? EV(it, 2) : nullptr));
     if (timed) CM_HIP(hipEventRecord(EV(it, 9), st));
     CM_TRY(post_wait_fallback());
     if (o->save_histories) for (cm_problem* q : s.ps) CM_TRY(record_hist(ctx, q, it, 1));   // shape, rate, phi, phi_cov, z
@@ -703,8 +703,13 @@ static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_option
       float d = 0;
       hipEventElapsedTime(&d, EV(it, 3), EV(it, 4));
       t0.sweep_seq_ms += d;
-      hipEventElapsedTime(&d, EV(it, 8), EV(it, 9));
-      t0.mid_ms += d;
+      if (B > 1) {                                                            // k_iter_mid | k_mc_dead
+        hipEventElapsedTime(&d, EV(it, 8), EV(it, 2)); t0.mid_ms += d;
+        hipEventElapsedTime(&d, EV(it, 2), EV(it, 9)); t0.mc_dead_ms += d;
+      } else {
+        hipEventElapsedTime(&d, EV(it, 8), EV(it, 9));
+        t0.mid_ms += d;
+      }
       if (fact_it[it] && hipEventElapsedTime(&d, EV(it, 6), EV(it, 7)) == hipSuccess) t0.fact_ms += d;
       if (trace_iters && it > 0) {                                            // diagnostic: wall time of every iteration
         float e = 0;

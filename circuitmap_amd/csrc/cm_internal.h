@@ -407,7 +407,8 @@ int cm_launch_expand_lam(cm_ctx* ctx, cm_problem* p, const double* d_lam_sparse,
 int cm_solve_mu(cm_ctx* ctx, cm_set& s, int* n_active_out);                          // syncs once (active-set size)
 int cm_solve_launch(cm_ctx* ctx, cm_set& s, int skip_mode, hipEvent_t fact_begin = nullptr, hipEvent_t fact_end = nullptr);                          // sizes from s.na; skip_mode 0: circuits the fused kernel solved are left alone, -1: solve all
 int cm_small_cap(const cm_problem* p);
-int cm_launch_iter_mid(cm_ctx* ctx, cm_set& s, int it, int iters, int S, int rng_mode, const cm_options* o, int do_sigma, int do_phi, int roles = 3);
+int cm_launch_iter_mid(cm_ctx* ctx, cm_set& s, int it, int iters, int S, int rng_mode, const cm_options* o, int do_sigma, int do_phi, int roles = 3,
+                       hipEvent_t between = nullptr);   // between: recorded between k_iter_mid and k_mc_dead (batches)
 int cm_launch_ndtri_table(cm_ctx* ctx, cm_problem* p, int it0, int n_it, int S, int rng_mode, hipStream_t st);
 int cm_launch_rng(cm_ctx* ctx, cm_problem* p, int it0, int n_it, hipStream_t st);
 int cm_launch_sweep(cm_ctx* ctx, cm_set& s, int it, const cm_options* o, hipEvent_t mid, int table_it = -1);   // table_it: iteration whose sweep order is used (default: it)

@@ -125,7 +125,7 @@ int cm_small_cap(const cm_problem* p) {
 }
 
 template <int SEG, bool FULLMC>
-static int launch_iter2(cm_ctx* ctx, cm_set& s, const IterDyn& a0, size_t lds, int blocks, size_t lds_waves, int threads) {
+static int launch_iter2(cm_ctx* ctx, cm_set& s, const IterDyn& a0, size_t lds, int blocks, size_t lds_waves, int threads, hipEvent_t between) {
   const int slot = CM_LDS_ITER + 4 * (31 - __builtin_clz((unsigned)SEG)) + (FULLMC ? 1 : 0) + (s.B > 1 ? 2 : 0);          // SEG = 1, 2, 4 .. 64
   if (s.B == 1) CM_TRY(cm_raise_lds(ctx, slot, reinterpret_cast<const void*>(k_iter_mid<false, SEG, FULLMC>), lds, 48 * 1024));
   else CM_TRY(cm_raise_lds(ctx, slot, reinterpret_cast<const void*>(k_iter_mid<true, SEG, FULLMC>), lds, 48 * 1024));
@@ -142,20 +142,23 @@ static int launch_iter2(cm_ctx* ctx, cm_set& s, const IterDyn& a0, size_t lds, i
     return CM_OK;
   }
   CM_LAUNCH_SET_T(k_iter_mid, (SEG, FULLMC), s, blocks, threads, lds, ctx->stream, a0);
-  if (a0.skip_dead)                                  // batches: the all-zero rows, in their lean kernel (after the mailboxes are on their way)
+  if (a0.skip_dead) {                                // batches: the all-zero rows, in their lean kernel (after the mailboxes are on their way)
+    if (between) CM_HIP(hipEventRecord(between, ctx->stream));
     CM_LAUNCH_SET(k_mc_dead, s, (s.lead->N + 3) / 4, 256, 4 * lds_waves, ctx->stream, a0);
+  }
   CM_HIP(hipGetLastError());
   return CM_OK;
 }
 template <int SEG>
-static int launch_iter(cm_ctx* ctx, cm_set& s, const IterDyn& a, size_t lds, int blocks, int threads) {
+static int launch_iter(cm_ctx* ctx, cm_set& s, const IterDyn& a, size_t lds, int blocks, int threads, hipEvent_t between) {
   const size_t lw = 2 * (size_t)a.S * sizeof(double);
-  return a.it < 0 ? launch_iter2<SEG, true>(ctx, s, a, lds, blocks, lw, threads) : launch_iter2<SEG, false>(ctx, s, a, lds, blocks, lw, threads);
+  return a.it < 0 ? launch_iter2<SEG, true>(ctx, s, a, lds, blocks, lw, threads, between) : launch_iter2<SEG, false>(ctx, s, a, lds, blocks, lw, threads, between);
 }
 
 // it = -1: state init (no sigma / phi; MC logit and solve for iteration 0).  Otherwise the middle of iteration `it`.
 // roles: 1 = the single-workgroup role, 2 = the per-neuron role, 3 = both.
-int cm_launch_iter_mid(cm_ctx* ctx, cm_set& s, int it, int iters, int S, int rng_mode, const cm_options* o, int do_sigma, int do_phi, int roles) {
+int cm_launch_iter_mid(cm_ctx* ctx, cm_set& s, int it, int iters, int S, int rng_mode, const cm_options* o, int do_sigma, int do_phi, int roles,
+                       hipEvent_t between) {
   IterDyn a;
   const cm_problem* p = s.lead;
   const int N = p->N, nxt = it + 1;
@@ -179,14 +182,14 @@ int cm_launch_iter_mid(cm_ctx* ctx, cm_set& s, int it, int iters, int S, int rng
   a.roles = roles;
   if (split && it >= 0 && roles == 3) {
     a.roles = 2;
-    if (V <= 4) { CM_TRY(launch_iter<4>(ctx, s, a, lds, blocks, threads)); } else { CM_TRY(launch_iter<64>(ctx, s, a, lds, blocks, threads)); }
+    if (V <= 4) { CM_TRY(launch_iter<4>(ctx, s, a, lds, blocks, threads, between)); } else { CM_TRY(launch_iter<64>(ctx, s, a, lds, blocks, threads, between)); }
     a.roles = 1;
   }
-  if (V <= 1) return launch_iter<1>(ctx, s, a, lds, blocks, threads);
-  if (V <= 2) return launch_iter<2>(ctx, s, a, lds, blocks, threads);
-  if (V <= 4) return launch_iter<4>(ctx, s, a, lds, blocks, threads);
-  if (V <= 8) return launch_iter<8>(ctx, s, a, lds, blocks, threads);
-  if (V <= 16) return launch_iter<16>(ctx, s, a, lds, blocks, threads);
-  if (V <= 32) return launch_iter<32>(ctx, s, a, lds, blocks, threads);
-  return launch_iter<64>(ctx, s, a, lds, blocks, threads);
+  if (V <= 1) return launch_iter<1>(ctx, s, a, lds, blocks, threads, between);
+  if (V <= 2) return launch_iter<2>(ctx, s, a, lds, blocks, threads, between);
+  if (V <= 4) return launch_iter<4>(ctx, s, a, lds, blocks, threads, between);
+  if (V <= 8) return launch_iter<8>(ctx, s, a, lds, blocks, threads, between);
+  if (V <= 16) return launch_iter<16>(ctx, s, a, lds, blocks, threads, between);
+  if (V <= 32) return launch_iter<32>(ctx, s, a, lds, blocks, threads, between);
+  return launch_iter<64>(ctx, s, a, lds, blocks, threads, between);
 }

@@ -118,6 +118,7 @@ typedef struct cm_timings {
   double sweep_seq_ms;   /* timing >= 1, sum: chain-kernel launches (k_sweep_par / k_sweep_seq: the Gauss-Seidel chain) */
   double mid_ms;         /* timing >= 1, sum: k_iter_mid launches (sigma, z, small solve || phi + next MC logit), each incl. one launch boundary */
   double post_ms;        /* timing >= 2, sum: k_stats + k_iter_mid                            */
+  double mc_dead_ms;     /* timing >= 1, batches only, sum: k_mc_dead launches (the all-zero rows' Monte-Carlo logit; for one circuit those rows are inside k_iter_mid) */
   double fact_ms;        /* timing >= 1, sum over the tiled solves of the run: first to last launch of the Cholesky factorisation (event pair per solve) */
   int32_t iters;
   int32_t batch;         /* circuits that shared the launches of this run (1 for cm_caviar_run): the *_ms fields are those of the whole set */
