@@ -417,6 +417,7 @@ __global__ __launch_bounds__(256) void k_seq_pack(cm_parg<BATCH> pa, int gated, 
     int turn = 0;
     if (turns)
       for (int ce = col_ptr[k]; ce < col_ptr[k + 1]; ++ce) { const int q = seq_pos[csc_row[ce]]; turn += (q >= 0 && q < j); }
+    if (turns == 2 && j == 1 && lane == 0) turn = (turn + 1) & 0xFF;   // fault injection (CAVIAR_HIP_TEST_BAD_TICKET): a turn that never comes
     r.b = e | (turn << 24);
     r.x = a.lam[e];
     r.y = a.mcE[(size_t)n * CM_MAX_VALS + g];
@@ -690,7 +691,8 @@ int cm_launch_sweep(cm_ctx* ctx, cm_set& s, int it, const cm_options* o, hipEven
   static const bool split = getenv("CAVIAR_HIP_SPLIT_PRESWEEP") != nullptr;     // diagnostic: one launch per role (profiling only)
   for (int pass = 0; pass < (split ? 3 : 1); ++pass)
     CM_LAUNCH_SET(k_presweep, s, nbI + nbC + 1, 1024, 0, st, (table_it < 0 ? it : table_it), gated, msrmp, min_count, nbI, nbC, split ? (1 << pass) : 7, gran);
-  CM_LAUNCH_SET(k_seq_pack, s, (N + 3) / 4, 256, 0, st, gated, msrmp, min_count, par ? 1 : 0);
+  static const bool bad_ticket = getenv("CAVIAR_HIP_TEST_BAD_TICKET") != nullptr;   // test hook: exercises the bounded wait + error report of the ticketed chain
+  CM_LAUNCH_SET(k_seq_pack, s, (N + 3) / 4, 256, 0, st, gated, msrmp, min_count, par ? (bad_ticket ? 2 : 1) : 0);
   if (mid) CM_HIP(hipEventRecord(mid, st));
   const size_t lds = (size_t)p->K * sizeof(double);
   const long long nrec = (long long)p->N + s.nnz_min;          // smallest allocation of `packed` (records) and of the chunk table in the set

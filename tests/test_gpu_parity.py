@@ -225,6 +225,34 @@ def test_edge_cases(ctx):
         caviar(psc, stim, *prior_args(pri), minimax_spk_prob=0.3)
 
 
+def test_ticket_timeout_is_reported_not_hung():
+    """The multi-wave chain waits for per-trial tickets with a BOUNDED spin; a ticket that never comes (injected through
+    CAVIAR_HIP_TEST_BAD_TICKET in a child process: the flag is read once per process) must end the run with an error, not hang the GPU
+    and not return wrong results silently."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import torch\n"
+        "from circuitmap_amd import _lib\n"
+        "from circuitmap_amd.optimise import caviar\n"
+        "from circuitmap_amd.simulation import simulate\n"
+        "from helpers import default_priors, prior_args\n"
+        "sim = simulate(N=40, trials=120, seed=3)\n"
+        "try:\n"
+        "    caviar(sim['psc'], sim['stim_matrix'], *prior_args(default_priors(40)), iters=3)\n"
+        "    print('NO ERROR')\n"
+        "except _lib.CaviarHipError as e:\n"
+        "    print('ERROR:', e)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CAVIAR_HIP_TEST_BAD_TICKET="1")
+    p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+    out = p.stdout.decode()
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert "ERROR:" in out and "ticket" in out, out
+
+
 def test_model_interface():
     import circuitmap_amd as cm
     sim = cm.simulate(N=50, trials=200, seed=5)
