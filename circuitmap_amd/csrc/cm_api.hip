@@ -315,6 +315,12 @@ int cm_set_single(cm_ctx* ctx, cm_problem* p, cm_set* s) {
   return set_build(ctx, s);
 }
 
+__global__ __launch_bounds__(256) void k_priors_scatter(cm_parg<true> pa, const double* __restrict__ stage, size_t per) {
+  const cm_pdev& p = pa.get();
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < per) const_cast<double*>(p.pslab)[i] = stage[(size_t)blockIdx.y * per + i];
+}
+
 // priors -> device, one pinned transfer per circuit (mu_prior | beta_prior | phi_prior | phi_cov_prior | scalars); the state is
 // then initialised from them on the device (k_init_state, caviar.py:44-49)
 static int upload_priors(cm_ctx* ctx, cm_set& s, const cm_priors* prs) {
@@ -331,7 +337,13 @@ static int upload_priors(cm_ctx* ctx, cm_set& s, const cm_priors* prs) {
     double* sc = h + 8 * N;
     for (int i = 0; i < CM_S_COUNT; ++i) sc[i] = 0.0;
     sc[CM_S_SHAPE] = pr->shape; sc[CM_S_RATE] = pr->rate; sc[CM_S_SHAPE_PRIOR] = pr->shape; sc[CM_S_RATE_PRIOR] = pr->rate;
-    CM_HIP(hipMemcpyAsync(s.ps[c]->pslab, h, n * sizeof(double), hipMemcpyHostToDevice, st));
+    if (s.B == 1) CM_HIP(hipMemcpyAsync(s.ps[c]->pslab, h, n * sizeof(double), hipMemcpyHostToDevice, st));
+  }
+  if (s.B > 1) {                                     // one kernel reads the pinned staging buffer for all circuits (instead of B copies)
+    double* dbase = nullptr;
+    CM_HIP(hipHostGetDevicePointer((void**)&dbase, ctx->h_stage, 0));
+    hipLaunchKernelGGL(k_priors_scatter, dim3((unsigned)((n + 255) / 256), s.B), dim3(256), 0, st, cm_parg<true>{s.d_arr}, (const double*)dbase, n);
+    CM_HIP(hipGetLastError());
   }
   return CM_OK;
 }
@@ -353,9 +365,23 @@ __global__ __launch_bounds__(64) void k_collect_status(cm_parg<BATCH> pa, int* _
   else if (i < 6) out[8 * c + i] = p.seq_meta[i];
 }
 
-__global__ __launch_bounds__(256) void k_set_ones(double* __restrict__ lam, const int32_t* __restrict__ idx, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) lam[idx[i]] = 1.0;
+// false-negative scan, device side: mu | beta | z of every circuit to / from host-mapped pinned memory (`stage`: `per` doubles per
+// circuit), and on the way back the lam entries the scan set to 1 (`hdr`: per circuit (count, start), then the index lists)
+template <bool BATCH>
+__global__ __launch_bounds__(256) void k_fn_gather(cm_parg<BATCH> pa, double* __restrict__ stage, size_t per) {
+  const cm_pdev& p = pa.get();
+  const size_t c = BATCH ? blockIdx.y : 0, i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < per) stage[c * per + i] = p.mu[i];                   // the slab: mu [N] | beta [N] | z [K] (| lam, which stays)
+}
+template <bool BATCH>
+__global__ __launch_bounds__(256) void k_fn_scatter(cm_parg<BATCH> pa, const double* __restrict__ stage, size_t per, const int32_t* __restrict__ hdr) {
+  const cm_pdev& p = pa.get();
+  const size_t c = BATCH ? blockIdx.y : 0, i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < per) p.mu[i] = stage[c * per + i];
+  const int B = BATCH ? (int)gridDim.y : 1;
+  const int cnt = hdr[2 * c], start = hdr[2 * c + 1];
+  const int32_t* __restrict__ idx = hdr + 2 * (size_t)B + start;
+  for (size_t e = i; e < (size_t)cnt; e += (size_t)gridDim.x * blockDim.x) p.lam[idx[e]] = 1.0;
 }
 
 static int alloc_hist(cm_problem* p, int iters) {
@@ -628,22 +654,24 @@ static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_option
 
   if (o->fn_scan) {                                                  // caviar.py:94-98
     // mu | beta | z | lam are one device slab per circuit.  The scan reads mu and z and only ever WRITES lam (entries set to 1), so
-    // mu | beta | z travel (one pinned copy down, one back) and lam stays in HBM; the few entries a reconnection sets are sent
-    // as an index list.  The scans of a batch are independent: they run on a few host threads.
-    std::vector<size_t> off(B + 1, 0);
-    for (int c = 0; c < B; ++c) off[c + 1] = off[c] + 2 * (size_t)N + s.ps[c]->K;
+    // only mu | beta | z travel and lam stays in HBM; the few entries a reconnection sets go back as an index list.  Both directions
+    // are ONE kernel for the whole set, reading / writing host-mapped pinned memory directly (a batch of 64 would otherwise issue
+    // 128 copies: 2.5 ms of a 35 ms step).  The scans of a batch are independent: they run on a few persistent host threads.
+    const size_t per = 2 * (size_t)N + p->K;                           // doubles per circuit (N, K are those of the group)
     size_t nnz_tot = 0;
     for (int c = 0; c < B; ++c) nnz_tot += (size_t)s.ps[c]->nnz;
-    CM_TRY(stage_reserve(ctx, off[B] * sizeof(double) + nnz_tot * sizeof(int32_t)));     // slabs, then room for the index lists (pinned)
+    CM_TRY(stage_reserve(ctx, (size_t)B * per * sizeof(double) + ((size_t)2 * B + nnz_tot) * sizeof(int32_t)));
     double* hbase = (double*)ctx->h_stage;
-    int32_t* hidx = (int32_t*)(hbase + off[B]);
-    for (int c = 0; c < B; ++c)
-      CM_HIP(hipMemcpyAsync(hbase + off[c], s.ps[c]->slab, (off[c + 1] - off[c]) * sizeof(double), hipMemcpyDeviceToHost, st));
+    int32_t* hhdr = (int32_t*)(hbase + (size_t)B * per);               // per circuit: (count, start) of its index list, then the lists
+    int32_t* hidx = hhdr + 2 * (size_t)B;
+    double* dbase = nullptr;
+    CM_HIP(hipHostGetDevicePointer((void**)&dbase, ctx->h_stage, 0));
+    CM_LAUNCH_SET(k_fn_gather, s, (unsigned)((per + 255) / 256), 256, 0, st, dbase, per);
     CM_HIP(hipStreamSynchronize(st));
     std::vector<std::vector<int32_t>> ones(B);
     auto scan = [&](int c) {
       const cm_problem* q = s.ps[c];
-      double* h = hbase + off[c];
+      double* h = hbase + (size_t)c * per;
       cm_host_reconnect(host_rows(q), h, h + N, nullptr, h + 2 * (size_t)N, o->msrmp, o->minimum_spike_count, o->verbose, &ones[c]);
     };
     if (B > 1 && o->verbose == 0) {
@@ -652,18 +680,14 @@ static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_option
     } else {
       for (int c = 0; c < B; ++c) scan(c);
     }
-    for (int c = 0; c < B; ++c) {
-      cm_problem* q = s.ps[c];
-      CM_HIP(hipMemcpyAsync(q->slab, hbase + off[c], (off[c + 1] - off[c]) * sizeof(double), hipMemcpyHostToDevice, st));
-      if (!ones[c].empty()) {                                          // lam[e] = 1 for the reconnected cells' events (:136)
-        const size_t cnt = ones[c].size();
-        memcpy(hidx, ones[c].data(), cnt * sizeof(int32_t));           // pinned: the upload below does not block the host
-        int32_t* d_idx = (int32_t*)q->packed;                          // chain records are dead by now: scratch for the index list
-        CM_HIP(hipMemcpyAsync(d_idx, hidx, cnt * sizeof(int32_t), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_set_ones, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, q->lam, d_idx, (int)cnt);
-        hidx += cnt;
-      }
+    size_t start = 0;
+    for (int c = 0; c < B; ++c) {                                      // lam[e] = 1 for the reconnected cells' events (:136)
+      hhdr[2 * c] = (int32_t)ones[c].size();
+      hhdr[2 * c + 1] = (int32_t)start;
+      if (!ones[c].empty()) memcpy(hidx + start, ones[c].data(), ones[c].size() * sizeof(int32_t));
+      start += ones[c].size();
     }
+    CM_LAUNCH_SET(k_fn_scatter, s, (unsigned)((per + 255) / 256), 256, 0, st, (const double*)dbase, per, (const int32_t*)(dbase + (size_t)B * per));
     CM_TRY(cm_launch_update_phi(ctx, s, st, iters > 0 ? 1 : 0));     // (iters == 0: the per-run constants were not produced)
   }
   CM_HIP(hipEventRecord(ctx->ev[3], st));
