@@ -260,6 +260,52 @@ __device__ __forceinline__ void sweep_step_long(const SweepArgs& a, int n, RPtr 
   }
 }
 
+// ---- two rows per wavefront (one per 32-lane half): rows with <= 32 targeted trials, <= 8 powers.
+// Sum over each half, every lane receiving its half's sum.  Bitwise what cm_wave_sum gives the same row alone in a wavefront (there
+// the upper two 16-lane partial sums are zeros and (r0 + r1) + (0 + 0) == r0 + r1).
+__device__ __forceinline__ double cm_half_sum(double v) {
+  v = cm_seg_sum<16>(v);
+  const double r0 = cm_readlane_f64(v, 0), r1 = cm_readlane_f64(v, 16), r2 = cm_readlane_f64(v, 32), r3 = cm_readlane_f64(v, 48);
+  return (threadIdx.x & 32) ? (r2 + r3) : (r0 + r1);
+}
+// row_gate_small for two rows at once: the same operations per row, in the same order (the per-power divisions in lanes 0..P-1 of
+// the row's half, the suffix means likewise), so each row's gate is bit for bit that of row_gate_small
+template <int PS>
+__device__ __forceinline__ double row_gate_half(bool valid, int g, double est, int Prt, double thresh, double min_count) {
+  const int P = PS > 0 ? PS : Prt;
+  constexpr int PM = PS > 0 ? PS : 8;
+  const int lane = (int)(threadIdx.x % CM_WAVE), sub = lane & 31, hb = lane & 32;
+  const double total = cm_half_sum(est);
+  double num = 0.0, den = 1.0;
+#pragma unroll
+  for (int p = 0; p < PM; ++p) {
+    if (p < P) {
+      const bool in = valid && g == p + 1;
+      const double s_ = cm_half_sum(in ? est : 0.0);
+      const int cnt = __popc((unsigned)((__ballot(in) >> hb) & 0xFFFFFFFFull));
+      if (sub == p) { num = s_; den = (double)cnt + 1e-4 * (double)(cnt == 0); }   // caviar.py:183
+    }
+  }
+  const double sr_l = num / den;                 // lane hb + p: mean rate of this half's row at power p
+  double S = 0.0, numj = 0.0, denj = 1.0;
+  int c = 0;
+#pragma unroll
+  for (int j = PM - 1; j >= 0; --j) {
+    if (j < P) {
+      S += __shfl(sr_l, hb + j, CM_WAVE); ++c;
+      if (sub == j) { numj = S; denj = (double)c; }
+    }
+  }
+  const double m_l = numj / denj;                // lane hb + j: mean(srates[j:])
+  double best = -1.0;
+#pragma unroll
+  for (int j = 0; j < PM; ++j) {
+    if (j < P) { const double m = __shfl(m_l, hb + j, CM_WAVE); best = m > best ? m : best; }
+  }
+  const double iso = P > 0 ? best : 0.0;
+  return (iso >= thresh && total >= min_count) ? 1.0 : 0.0;                // caviar.py:220
+}
+
 // rows with mu == 0: arg = sigma * beta^2 does not involve R and mu * lam contributes nothing to R, so these rows are
 // independent of the chain and of each other -> one wave each over the whole chip
 __device__ __forceinline__ void sweep_indep_row(const SweepArgs& a, int n, int lane, double* scr) {
@@ -281,6 +327,43 @@ __device__ __forceinline__ void sweep_indep_row(const SweepArgs& a, int n, int l
   double pava = 1.0;
   if (a.gated) pava = row_gate(valid, g, est, a.V - 1, thresh, a.min_count, scr);
   if (valid) a.lam[beg + lane] = est * pava;
+}
+
+// Rows n0 and n0 + 1 in one wavefront (batches: half the wavefronts of the one-row-per-wave launch, whose duration is set by their
+// number).  Falls back to one row after the other when a row is longer than 32 trials or there are more than 8 powers.
+__device__ __forceinline__ void sweep_indep_pair(const SweepArgs& a, int n0, int N, int lane, double* scr) {
+  const int sub = lane & 31, n = n0 + (lane >> 5);
+  const bool row_on = n < N && a.mu[n < N ? n : 0] == 0.0;
+  const int beg = row_on ? a.row_ptr[n] : 0, len = row_on ? a.row_ptr[n + 1] - beg : 0;
+  const int P = a.V - 1;
+  if (__any(len > 32) || P > 8) {
+    sweep_indep_row(a, n0, lane, scr);
+    if (n0 + 1 < N) sweep_indep_row(a, n0 + 1, lane, scr);
+    return;
+  }
+  const double sig = a.scal[CM_S_SHAPE] / a.scal[CM_S_RATE];
+  const double thresh = a.msrmp + a.scal[CM_S_SPONT_RATE];
+  const bool valid = sub < len;
+  int g = -1;
+  double est = 0.0;
+  if (valid) {
+    const double be = a.beta[n];
+    const double arg = sig * (be * be);              // mu == 0: caviar.py:205-206 reduces to sigma * beta^2
+    const int e = beg + sub;
+    g = a.grp[e];
+    if (a.mask[a.col[e]]) est = cm_sigmoid(a.mcE[(size_t)n * CM_MAX_VALS + g] - 0.5 * arg);
+  }
+  double pava = 1.0;
+  if (a.gated) {
+    switch (P) {
+      case 1: pava = row_gate_half<1>(valid, g, est, P, thresh, a.min_count); break;
+      case 2: pava = row_gate_half<2>(valid, g, est, P, thresh, a.min_count); break;
+      case 3: pava = row_gate_half<3>(valid, g, est, P, thresh, a.min_count); break;
+      case 4: pava = row_gate_half<4>(valid, g, est, P, thresh, a.min_count); break;
+      default: pava = row_gate_half<0>(valid, g, est, P, thresh, a.min_count); break;
+    }
+  }
+  if (valid) a.lam[beg + sub] = est * pava;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -374,8 +457,13 @@ __global__ __launch_bounds__(1024) void k_presweep(cm_parg<BATCH> pa, int it, in
   const int b = blockIdx.x;
   if (b < nbI) {
     if (!(roles & 1)) return;
-    const int n = b * 16 + threadIdx.x / CM_WAVE;
-    if (n < N) sweep_indep_row(a, n, threadIdx.x % CM_WAVE, scr_all[threadIdx.x / CM_WAVE]);
+    if (BATCH) {                                     // two rows per wavefront: the launch is as long as its number of wavefronts
+      const int n0 = 2 * (b * 16 + threadIdx.x / CM_WAVE);
+      if (n0 < N) sweep_indep_pair(a, n0, N, threadIdx.x % CM_WAVE, scr_all[threadIdx.x / CM_WAVE]);
+    } else {
+      const int n = b * 16 + threadIdx.x / CM_WAVE;
+      if (n < N) sweep_indep_row(a, n, threadIdx.x % CM_WAVE, scr_all[threadIdx.x / CM_WAVE]);
+    }
   } else if (b < nbI + nbC) {
     if (!(roles & 2)) return;
     cm_col_dot16((b - nbI) * 1024 + threadIdx.x, p.K, a.mu, a.lam, p.col_ptr, p.csc_row, p.csc_pos, 0.0, p.R, nullptr);
@@ -680,7 +768,8 @@ int cm_launch_sweep(cm_ctx* ctx, cm_set& s, int it, const cm_options* o, hipEven
   const double msrmp = o->msrmp, min_count = o->minimum_spike_count;
   hipStream_t st = ctx->stream;
   const int N = p->N;
-  const int nbI = (N + 15) / 16, nbC = (p->K * 16 + 1023) / 1024;    // 16 rows per block; 16 lanes per trial column
+  const int nbI = s.B > 1 ? (N + 31) / 32 : (N + 15) / 16;          // 16 rows per block (batches: 32, two rows per wavefront)
+  const int nbC = (p->K * 16 + 1023) / 1024;                         // 16 lanes per trial column
   // multi-wave chain when the ticket encoding fits (see k_sweep_par): variant 1 = 1024-record buffers + 32-bit tickets,
   // variant 2 = 512-record buffers + 8-bit tickets (larger K); 0 = single-consumer kernel.  Whichever kernel walks the chain,
   // every R_k sees its updates in sweep order: the variants give bit-identical results.
