@@ -164,7 +164,7 @@ extern "C" int cm_problem_destroy(cm_problem* p) {
   hipStreamSynchronize(p->ctx->stream);
   void* ptrs[] = {p->y, p->ss, p->sum_y, p->vals, p->row_ptr, p->col, p->grp, p->rowcnt, p->col_ptr, p->csc_row, p->csc_pos,
                   p->mask, p->slab, p->pslab, p->phi, p->phi_cov, p->phi_dead,
-                  p->R, p->colany, p->mcE, p->rs, p->act_idx, p->act_inv, p->n_act, p->orders_all, p->orders_tmp, p->inv_all, p->wtab,
+                  p->R, p->colany, p->mcE, p->rs, p->act_idx, p->act_inv, p->n_act, p->alive, p->orders_all, p->orders_tmp, p->inv_all, p->wtab,
                   p->keys, p->uexp, p->A, p->X, p->Lf, p->Dinv, p->rhs, p->seq_n, p->seq_off, p->seq_pos, p->chunk_first,
                   p->seq_meta, p->packed};
   for (void* q : ptrs) if (q) hipFree(q);
@@ -207,7 +207,7 @@ extern "C" int cm_problem_create(cm_ctx* ctx, int32_t N, int32_t K, int32_t T, c
       (rc = dmalloc(&p->phi_cov, 4 * (size_t)N)) || (rc = dmalloc(&p->phi_dead, 8 * (size_t)N)) || (rc = dmalloc(&p->R, K)) ||
       (rc = dmalloc(&p->colany, K)) || (rc = dmalloc(&p->mcE, (size_t)N * CM_MAX_VALS)) ||
       (rc = dmalloc(&p->rs, 4 * (size_t)N)) || (rc = dmalloc(&p->act_idx, N)) || (rc = dmalloc(&p->act_inv, N)) ||
-      (rc = dmalloc(&p->n_act, 4)) || (rc = dmalloc(&p->A, ld * (ld + CM_LD_PAD))) || (rc = dmalloc(&p->X, ld * (ld + CM_LD_PAD))) ||
+      (rc = dmalloc(&p->n_act, 4)) || (rc = dmalloc(&p->alive, (size_t)N + 1)) || (rc = dmalloc(&p->A, ld * (ld + CM_LD_PAD))) || (rc = dmalloc(&p->X, ld * (ld + CM_LD_PAD))) ||
       (rc = dmalloc(&p->Lf, ld * (ld + CM_LD_PAD))) ||
       (rc = dmalloc(&p->Dinv, ld * CM_TILE)) || (rc = dmalloc(&p->rhs, 2 * ld)) || (rc = dmalloc(&p->seq_n, N)) ||
       (rc = dmalloc(&p->seq_off, (size_t)N + 1)) || (rc = dmalloc(&p->seq_pos, N)) || (rc = dmalloc(&p->chunk_first, ((size_t)N + p->nnz) / 256 + 8)) ||
@@ -216,7 +216,8 @@ extern "C" int cm_problem_create(cm_ctx* ctx, int32_t N, int32_t K, int32_t T, c
   p->mu = p->slab; p->beta = p->slab + N; p->z = p->slab + 2 * (size_t)N; p->lam = p->slab + 2 * (size_t)N + K;
   p->mu_prior = p->pslab; p->beta_prior = p->pslab + N; p->phi_prior = p->pslab + 2 * (size_t)N;
   p->phi_cov_prior = p->pslab + 4 * (size_t)N; p->scal = p->pslab + 8 * (size_t)N;
-  if (hipMemsetAsync(p->mcE, 0, (size_t)N * CM_MAX_VALS * sizeof(double), st) != hipSuccess) return fail(CM_ERR_HIP);
+  if (hipMemsetAsync(p->mcE, 0, (size_t)N * CM_MAX_VALS * sizeof(double), st) != hipSuccess ||
+      hipMemsetAsync(p->alive, 0, ((size_t)N + 1) * sizeof(int), st) != hipSuccess) return fail(CM_ERR_HIP);
   if (hipStreamSynchronize(st) != hipSuccess) { cm_set_error("prologue failed: %s", hipGetErrorString(hipGetLastError())); return fail(CM_ERR_HIP); }
   *out = p;
   return CM_OK;
@@ -257,7 +258,7 @@ void cm_fill_pdev(const cm_problem* p, const cm_problem* r, int* mailbox, cm_pde
   d->rowcnt = p->rowcnt; d->col_ptr = p->col_ptr; d->csc_row = p->csc_row; d->csc_pos = p->csc_pos; d->mask = p->mask; d->colany = p->colany;
   d->lam = p->lam; d->mu = p->mu; d->beta = p->beta; d->phi = p->phi; d->phi_cov = p->phi_cov; d->scal = p->scal; d->R = p->R; d->z = p->z;
   d->mcE = p->mcE; d->rs = p->rs; d->phi_dead = p->phi_dead; d->phi_cov_dead = p->phi_dead ? p->phi_dead + 2 * (size_t)p->N : nullptr; d->phi_c_dead = p->phi_dead ? p->phi_dead + 6 * (size_t)p->N : nullptr; d->pslab = p->pslab; d->mu_prior = p->mu_prior; d->beta_prior = p->beta_prior; d->phi_prior = p->phi_prior;
-  d->phi_cov_prior = p->phi_cov_prior; d->act_idx = p->act_idx; d->act_inv = p->act_inv; d->n_act = p->n_act; d->seq_n = p->seq_n;
+  d->phi_cov_prior = p->phi_cov_prior; d->act_idx = p->act_idx; d->act_inv = p->act_inv; d->n_act = p->n_act; d->alive = p->alive; d->seq_n = p->seq_n;
   d->seq_off = p->seq_off; d->seq_pos = p->seq_pos; d->chunk_first = p->chunk_first; d->seq_meta = p->seq_meta; d->packed = p->packed;
   d->A = p->A; d->X = p->X; d->Lf = p->Lf; d->Dinv = p->Dinv; d->rhs = p->rhs; d->mailbox = mailbox;
   d->orders_all = r->orders_all; d->inv_all = r->inv_all; d->wtab = r->wtab; d->uexp = r->uexp; d->keys = r->keys;

@@ -164,6 +164,7 @@ struct cm_problem {
   int32_t* act_idx = nullptr; // [N] active neurons (compact list)
   int32_t* act_inv = nullptr; // [N] neuron -> compact index or -1
   int32_t* n_act = nullptr;   // [4] device: N_a, flags
+  int32_t* alive = nullptr;   // [1 + N] count + list of rows with lam != 0 (batches: work list of the per-neuron role of k_iter_mid)
   int32_t* order = nullptr;   // sweep order of the current iteration (points into orders_all)
   int32_t* orders_all = nullptr; // [iters*N] sweep orders of every iteration (device generated, or the explicit stream)
   int32_t* orders_tmp = nullptr; // [iters*N] ping-pong buffer of the shuffle rounds
@@ -215,6 +216,7 @@ struct cm_pdev {
   double *phi_dead, *phi_cov_dead, *phi_c_dead;   // update_phi of an all-zero row, per neuron, and ndtr(-mean / sdev) of it: constants of a run (k_phi_dead)
   const double *pslab, *mu_prior, *beta_prior, *phi_prior, *phi_cov_prior;
   int *act_idx, *act_inv, *n_act, *seq_n, *seq_off, *seq_pos, *chunk_first, *seq_meta;
+  int* alive;                    // [1 + N] batches: number and list of the rows with lam != 0 after the sweep (k_stats)
   void* packed;
   double *A, *X, *Lf, *Dinv, *rhs;
   int* mailbox;                  // this circuit's 64-bit word in host-mapped pinned memory (nullptr: no mailbox)

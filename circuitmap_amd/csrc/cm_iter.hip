@@ -88,15 +88,32 @@ __global__ __launch_bounds__(CM_ITER_THREADS) void k_iter_mid(cm_parg<BATCH> pa,
   }
   if (!(a.roles & 2)) return;
   const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE;
-  const int n = ((int)blockIdx.x - 2) * (int)(blockDim.x / CM_WAVE) + wave;
   const int N = p.N;
+  if (BATCH && a.skip_dead) {
+    // Batches: the rows with lam != 0 -- listed by k_stats, a few percent of the rows in the steady state -- are spread over a grid
+    // sized for them (the host knows the previous active-set sizes; the stride loop covers whatever else turns up), instead of
+    // N wavefronts per circuit of which most leave at once: that launch was bound by the number of wavefronts, not by its work.
+    const int total = ((int)gridDim.x - 2) * (int)(blockDim.x / CM_WAVE);
+    const int n_alive = min(p.alive[0], N);
+    for (int i = ((int)blockIdx.x - 2) * (int)(blockDim.x / CM_WAVE) + wave; i < n_alive; i += total) {
+      const int n = p.alive[1 + i];
+      double pc[4];
+      phi_body<SEG>(n, lane, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, pc);
+      if (a.do_mc) {
+        const int m = p.inv_all[(size_t)a.nx * N + n];
+        const size_t off = ((size_t)a.nx * N + m) * 2 * a.S;
+        mc_logit_body<FULLMC>(n, lane, pc[0], pc[1], pc[2], pc[3], (const double2*)p.wtab + off, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE);
+      }
+    }
+    return;
+  }
+  const int n = ((int)blockIdx.x - 2) * (int)(blockDim.x / CM_WAVE) + wave;
   if (n >= N) return;
   double pc[4];
   bool dead_row = false;
   double dc0 = 0.0, dc1 = 0.0;
   if (a.do_phi && p.rs[(size_t)n * 4 + 3] < 0.0) {
     // the row is identically zero (k_stats of this iteration): its update_phi is the per-run constant of this neuron
-    if (a.skip_dead) return;                           // batches: these rows belong to the lean kernel k_mc_dead
     dead_row = true;
     dead_phi_copy(p, n, lane, pc, &dc0, &dc1);
   } else if (a.do_phi) {
@@ -176,7 +193,13 @@ int cm_launch_iter_mid(cm_ctx* ctx, cm_set& s, int it, int iters, int S, int rng
   lds = std::max(lds, s.small_lds_max);
   a.stage_ok = 0;
   if ((size_t)p->K * 9 + 16 <= 56 * 1024) { lds = std::max(lds, (size_t)p->K * 9 + 16); a.stage_ok = 1; }   // residual + flag per trial
-  const int blocks = 2 + ((do_phi || a.do_mc) ? (N + waves - 1) / waves : 0);
+  int blocks = 2 + ((do_phi || a.do_mc) ? (N + waves - 1) / waves : 0);
+  if (a.skip_dead) {
+    // rows with lam != 0 after this sweep: at most a few more than the active set the iteration started with (rows can be revived);
+    // twice that, at least 64 wavefronts per circuit -- the kernel's stride loop takes care of the rest
+    const int want = std::min(N, std::max(64, 2 * s.na_max));
+    blocks = 2 + (want + waves - 1) / waves;
+  }
   const int V = p->V;
   static const bool split = getenv("CAVIAR_HIP_SPLIT_ITER") != nullptr;         // diagnostic: one launch per role (profiling only)
   a.roles = roles;

@@ -41,6 +41,9 @@ __global__ __launch_bounds__(256) void k_stats(cm_parg<BATCH> pa, int nbR, doubl
       rs[(size_t)n * 4 + 1] = s2;
       rs[(size_t)n * 4 + 2] = sy;
       rs[(size_t)n * 4 + 3] = any ? d : -1.0;   // sum lam(1-lam) for active rows, -1 marks an all-zero row
+      // batches: list of the rows with lam != 0 (order irrelevant) for the per-neuron role of k_iter_mid; one atomic per such row
+      // (a few dozen per circuit in the steady state), counter zeroed by k_init_state / k_presweep
+      if (BATCH && any) { const int pos = atomicAdd(&p.alive[0], 1); if (pos < p.N) p.alive[1 + pos] = n; }
     }
   } else {
     cm_col_dot16(((int)blockIdx.x - nbR) * blockDim.x + threadIdx.x, p.K, p.mu, lam, p.col_ptr, p.csc_row, p.csc_pos, orth, p.R, p.colany);

@@ -308,6 +308,7 @@ __global__ __launch_bounds__(256) void k_init_state(cm_parg<BATCH> pa, double th
   if (i < 4 * (long long)N) p.phi_cov[i] = pslab[4 * (size_t)N + i];
   if (i < 4) p.n_act[i] = 0;
   if (i < 8) p.seq_meta[i] = 0;
+  if (i == 0) p.alive[0] = 0;
 }
 template <bool BATCH>
 __global__ __launch_bounds__(1024) void k_sum_y_set(cm_parg<BATCH> pa) {
