@@ -330,15 +330,22 @@ def main():
         a.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no GPU visible (the HIP path has no CPU fallback)")
+    if os.environ.get("CAVIAR_BENCH_SHARE_GPU") == "1":    # rehearsal of the multi-rank path on a one-GPU box: every rank uses device 0
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    dist = None
+    dist, control_plane = None, None
     if world > 1 or ("RANK" in os.environ and os.environ.get("CAVIAR_BENCH_FORCE_DIST") == "1"):
         # one process per GPU under torch.distributed.run; backend "nccl" is RCCL on ROCm.  The data path has no collective
-        # (independent circuits): RCCL only carries the barriers and the max-over-ranks of the elapsed time.
+        # (independent circuits): the process group only carries the barriers and the max-over-ranks of the elapsed time.
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        control_plane = os.environ.get("CAVIAR_BENCH_BACKEND", "nccl")
+        if control_plane == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:                                              # CAVIAR_BENCH_BACKEND=gloo: the same two calls over gloo (rehearsals on a one-GPU box)
+            control_plane = "gloo"
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import __graft_entry__ as ge
     if rank == 0:
@@ -434,7 +441,7 @@ def main():
         print("step wall ms:", " ".join("%.2f" % v for v in step_wall), file=sys.stderr)
     n_ranks_seen = 1
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if control_plane == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         n_ranks_seen = dist.get_world_size()
@@ -502,7 +509,7 @@ def main():
         phase["steps_with_kernel_events"] = int(sum(1 for st_ in stamped if st_ or a.phases))
         out = {
             "metric": "CAVIaR iterations/sec (N=%d, K=%d, T=%d)" % (N, K, T),
-            "value": value, "unit": "iterations/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": a.steps, "warmup": a.warmup,
+            "value": value, "unit": "iterations/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen, "control_plane": control_plane, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic" if gen_ms is None else "synthetic (generated on the GPU in %.2f ms per circuit)" % gen_ms,
             "config": {"workload": "%s: N=%d neurons, K=%d trials, T=%d, H=%d targets/trial, %d iterations + fn_scan per step, "
