@@ -231,11 +231,27 @@ template <bool BATCH> struct cm_parg;
 template <> struct cm_parg<false> {
   cm_pdev d;
   __device__ __forceinline__ const cm_pdev& get() const { return d; }
+  __device__ __forceinline__ const cm_pdev& get(int) const { return d; }
 };
 template <> struct cm_parg<true> {
   const cm_pdev* __restrict__ arr;
   __device__ __forceinline__ const cm_pdev& get() const { return arr[blockIdx.y]; }
+  __device__ __forceinline__ const cm_pdev& get(int c) const { return arr[c]; }
 };
+// XCD-aware workgroup -> (tile, circuit) map for the bandwidth-bound kernels of a batch.  Workgroups are dealt to the 8 XCDs (each
+// with its own 4 MB L2) round-robin by their linear index; with the plain (blockIdx.x, blockIdx.y) = (tile, circuit) reading,
+// the tiles of one circuit land on all eight and every panel tile they share is fetched into eight L2s.  Remapped, circuit c runs
+// entirely on XCD c mod 8 (needs gridDim.y % 8 == 0, otherwise the plain map).  Placement is a speed heuristic only: any map is correct.
+__device__ __forceinline__ void cm_xcd_remap(int& bx, int& c) {
+  const int nx = (int)gridDim.x, B = (int)gridDim.y;
+  bx = (int)blockIdx.x; c = (int)blockIdx.y;
+  if (B % 8) return;
+  const long long L = (long long)blockIdx.y * nx + blockIdx.x;
+  const int xcd = (int)(L % 8), per = B / 8;
+  const long long q = L / 8;
+  c = xcd + 8 * (int)(q % per);
+  bx = (int)(q / per);
+}
 #endif
 
 // LDS footprint of the one-workgroup solver (solve_small_body, cm_bodies.h) for n active rows with tot_cap staged entries

@@ -17,8 +17,9 @@
 // batch (blockIdx.y = circuit): then each circuit reads its own active-set size from HBM, derives its own tile count and leading
 // dimension, and leaves at once if the tiled solve is not the solver of that size (cm_solve_kind) or if the block lies outside
 // its (smaller) matrix -- the grid is sized for the largest matrix of the batch.
-#define CM_SOLVE_PROLOGUE(KIND)                                                   \
-  const cm_pdev& p = pa.get();                                                    \
+#define CM_SOLVE_PROLOGUE(KIND) CM_SOLVE_PROLOGUE_AT(KIND, pa.get())
+#define CM_SOLVE_PROLOGUE_AT(KIND, PDEV)                                          \
+  const cm_pdev& p = PDEV;                                                        \
   const int na = BATCH ? p.n_act[0] : na_arg;                                     \
   if (BATCH && cm_solve_kind(na, p.small_cap, skip_own != 0) != (KIND)) return;       \
   const int nblk = (na + TS - 1) / TS, nrow = nblk * TS, ld = nrow + CM_LD_PAD;  \
@@ -348,10 +349,12 @@ __global__ __launch_bounds__(256) void k_chol_trsm(cm_parg<BATCH> pa, int na_arg
 // per CU keep enough bytes in flight; block 0 owns the diagonal tile (j+1, j+1) and factors it in place.
 template <bool BATCH>
 __global__ __launch_bounds__(256) void k_chol_bulk(cm_parg<BATCH> pa, int na_arg, int skip_own, int j, int large_min) {
-  CM_SOLVE_PROLOGUE(2)
+  int bx = (int)blockIdx.x, circ = 0;
+  if (BATCH) cm_xcd_remap(bx, circ);                 // all tiles of a circuit on one XCD: its panel tiles go through one L2
+  CM_SOLVE_PROLOGUE_AT(2, pa.get(circ))
   {
     const int tr = nblk - j - 1;
-    if (nblk <= large_min || tr <= 0 || (int)blockIdx.x >= tr * (tr + 1) / 2) return;
+    if (nblk <= large_min || tr <= 0 || bx >= tr * (tr + 1) / 2) return;
   }
   double* __restrict__ A = p.A;
   const double* __restrict__ Lf = p.Lf;
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(256) void k_chol_bulk(cm_parg<BATCH> pa, int na_arg
   __shared__ double Sm[3][TS][TP];
   double (*Xi)[TP] = Sm[0], (*Xl)[TP] = Sm[1];
   // linear block id -> (i, l), 0 <= l' <= i' in the trailing tile rows; id 0 is the diagonal tile (j+1, j+1)
-  const int t = blockIdx.x;
+  const int t = bx;
   int ip = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
   while ((ip + 1) * (ip + 2) / 2 <= t) ++ip;
   while (ip * (ip + 1) / 2 > t) --ip;
@@ -498,13 +501,15 @@ __global__ __launch_bounds__(256) void k_inv_seed(cm_parg<BATCH> pa, int na_arg,
 
 template <bool BATCH>
 __global__ __launch_bounds__(256) void k_inv_T(cm_parg<BATCH> pa, int na_arg, int skip_own, int b) {
-  CM_SOLVE_PROLOGUE(2)
+  int bx = (int)blockIdx.x, circ = 0;
+  if (BATCH) cm_xcd_remap(bx, circ);                 // the tile rows / columns the workgroups of a circuit share: one L2
+  CM_SOLVE_PROLOGUE_AT(2, pa.get(circ))
   double* __restrict__ A = p.A;
   const double* __restrict__ Lf = p.Lf;
   const double* __restrict__ X = p.X;
   __shared__ double Lt[TS][TP], Xt[TS][TP];
   const int per = b * b;
-  const int q = blockIdx.x / per, rem = blockIdx.x % per;
+  const int q = bx / per, rem = bx % per;
   const int j2 = (2 * q + 1) * b + rem / b;     // tile row in the second half
   const int c = 2 * q * b + rem % b;            // tile col in the first half
   if (j2 >= nblk) return;
@@ -532,12 +537,14 @@ __global__ __launch_bounds__(256) void k_inv_T(cm_parg<BATCH> pa, int na_arg, in
 
 template <bool BATCH>
 __global__ __launch_bounds__(256) void k_inv_X21(cm_parg<BATCH> pa, int na_arg, int skip_own, int b) {
-  CM_SOLVE_PROLOGUE(2)
+  int bx = (int)blockIdx.x, circ = 0;
+  if (BATCH) cm_xcd_remap(bx, circ);
+  CM_SOLVE_PROLOGUE_AT(2, pa.get(circ))
   const double* __restrict__ A = p.A;
   double* __restrict__ X = p.X;
   __shared__ double Xa[TS][TP], Tt[TS][TP];
   const int per = b * b;
-  const int q = blockIdx.x / per, rem = blockIdx.x % per;
+  const int q = bx / per, rem = bx % per;
   const int i = (2 * q + 1) * b + rem / b;
   const int c = 2 * q * b + rem % b;
   if (i >= nblk) return;
