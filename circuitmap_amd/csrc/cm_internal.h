@@ -343,6 +343,13 @@ __device__ __forceinline__ double cm_wave_sum(double v) {
   const double r0 = cm_readlane_f64(v, 0), r1 = cm_readlane_f64(v, 16), r2 = cm_readlane_f64(v, 32), r3 = cm_readlane_f64(v, 48);
   return (r0 + r1) + (r2 + r3);
 }
+// Sum over each half, every lane receiving its half's sum.  Bitwise what cm_wave_sum gives the same row alone in a wavefront (there
+// the upper two 16-lane partial sums are zeros and (r0 + r1) + (0 + 0) == r0 + r1).
+__device__ __forceinline__ double cm_half_sum(double v) {
+  v = cm_seg_sum<16>(v);
+  const double r0 = cm_readlane_f64(v, 0), r1 = cm_readlane_f64(v, 16), r2 = cm_readlane_f64(v, 32), r3 = cm_readlane_f64(v, 48);
+  return (threadIdx.x & 32) ? (r2 + r3) : (r0 + r1);
+}
 __device__ __forceinline__ int cm_wave_sum_i(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, CM_WAVE);

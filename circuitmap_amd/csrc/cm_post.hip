@@ -12,39 +12,82 @@
 //   blocks [nbR, ..): 16 lanes per trial -> R_k = sum_n mu_n lam_nk (= lam.T @ mu),
 //                     colany_k = any_n lam_nk >= spont_orthogonality
 // ------------------------------------------------------------------------------------------------
+// statistics of one row by one wavefront: rs[n] = {sum lam, sum lam^2, sum y lam, sum lam (1 - lam) or -1 for an all-zero row}
+template <bool BATCH>
+__device__ __forceinline__ void stats_row(const cm_pdev& p, const double* __restrict__ lam, int n, int lane) {
+    const int* __restrict__ row_ptr = p.row_ptr;
+  const int* __restrict__ col = p.col;
+  const double* __restrict__ y = p.y;
+  double s1 = 0.0, s2 = 0.0, sy = 0.0, d = 0.0;
+  int any = 0;
+  for (int e = row_ptr[n] + lane; e < row_ptr[n + 1]; e += CM_WAVE) {
+    const double l = lam[e];
+    s1 += l;
+    s2 = fma(l, l, s2);
+    sy = fma(y[col[e]], l, sy);
+    d = fma(l, 1.0 - l, d);
+    any |= (l != 0.0);
+  }
+  s1 = cm_wave_sum(s1); s2 = cm_wave_sum(s2); sy = cm_wave_sum(sy); d = cm_wave_sum(d);
+  any = __any(any);
+  if (lane == 0) {
+    double* __restrict__ rs = p.rs;
+    rs[(size_t)n * 4 + 0] = s1;
+    rs[(size_t)n * 4 + 1] = s2;
+    rs[(size_t)n * 4 + 2] = sy;
+    rs[(size_t)n * 4 + 3] = any ? d : -1.0;   // sum lam(1-lam) for active rows, -1 marks an all-zero row
+    // batches: list of the rows with lam != 0 (order irrelevant) for the per-neuron role of k_iter_mid; one atomic per such row
+    // (a few dozen per circuit in the steady state), counter zeroed by k_init_state / k_presweep
+    if (BATCH && any) { const int pos = atomicAdd(&p.alive[0], 1); if (pos < p.N) p.alive[1 + pos] = n; }
+  }
+}
+
 template <bool BATCH>
 __global__ __launch_bounds__(256) void k_stats(cm_parg<BATCH> pa, int nbR, double orth) {
   const cm_pdev& p = pa.get();
   const double* __restrict__ lam = p.lam;
-  if ((int)blockIdx.x < nbR) {
+  if (BATCH && (int)blockIdx.x < nbR) {
+    // batches: two rows per wavefront (one per 32-lane half) when both fit -- the launch is as long as its number of wavefronts;
+    // cm_half_sum gives each row bitwise the sums cm_wave_sum gives it alone in a wavefront
+    const int lane = threadIdx.x % CM_WAVE, sub = lane & 31;
+    const int n0 = 2 * (int)((blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE), N = p.N;
+    if (n0 >= N) return;
+    const int* __restrict__ row_ptr = p.row_ptr;
+    const int n = n0 + (lane >> 5);
+    const bool row_on = n < N;
+    const int beg = row_on ? row_ptr[n] : 0, len = row_on ? row_ptr[n + 1] - beg : 0;
+    if (!__any(len > 32)) {
+      const int* __restrict__ col = p.col;
+      const double* __restrict__ y = p.y;
+      double s1 = 0.0, s2 = 0.0, sy = 0.0, d = 0.0;
+      bool nz = false;
+      if (sub < len) {
+        const double l = lam[beg + sub];
+        s1 += l;
+        s2 = fma(l, l, s2);
+        sy = fma(y[col[beg + sub]], l, sy);
+        d = fma(l, 1.0 - l, d);
+        nz = l != 0.0;
+      }
+      s1 = cm_half_sum(s1); s2 = cm_half_sum(s2); sy = cm_half_sum(sy); d = cm_half_sum(d);
+      const bool any = ((__ballot(nz) >> (lane & 32)) & 0xFFFFFFFFull) != 0ull;
+      if (sub == 0 && row_on) {
+        double* __restrict__ rs = p.rs;
+        rs[(size_t)n * 4 + 0] = s1;
+        rs[(size_t)n * 4 + 1] = s2;
+        rs[(size_t)n * 4 + 2] = sy;
+        rs[(size_t)n * 4 + 3] = any ? d : -1.0;
+        if (any) { const int pos = atomicAdd(&p.alive[0], 1); if (pos < N) p.alive[1 + pos] = n; }
+      }
+      return;
+    }
+    // a long row in the pair: one row after the other, a full wavefront each
+    for (int r = 0; r < 2 && n0 + r < N; ++r) stats_row<BATCH>(p, lam, n0 + r, lane);
+  } else if ((int)blockIdx.x < nbR) {
     const int n = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE;
     const int lane = threadIdx.x % CM_WAVE;
     if (n >= p.N) return;
-    const int* __restrict__ row_ptr = p.row_ptr;
-    const int* __restrict__ col = p.col;
-    const double* __restrict__ y = p.y;
-    double s1 = 0.0, s2 = 0.0, sy = 0.0, d = 0.0;
-    int any = 0;
-    for (int e = row_ptr[n] + lane; e < row_ptr[n + 1]; e += CM_WAVE) {
-      const double l = lam[e];
-      s1 += l;
-      s2 = fma(l, l, s2);
-      sy = fma(y[col[e]], l, sy);
-      d = fma(l, 1.0 - l, d);
-      any |= (l != 0.0);
-    }
-    s1 = cm_wave_sum(s1); s2 = cm_wave_sum(s2); sy = cm_wave_sum(sy); d = cm_wave_sum(d);
-    any = __any(any);
-    if (lane == 0) {
-      double* __restrict__ rs = p.rs;
-      rs[(size_t)n * 4 + 0] = s1;
-      rs[(size_t)n * 4 + 1] = s2;
-      rs[(size_t)n * 4 + 2] = sy;
-      rs[(size_t)n * 4 + 3] = any ? d : -1.0;   // sum lam(1-lam) for active rows, -1 marks an all-zero row
-      // batches: list of the rows with lam != 0 (order irrelevant) for the per-neuron role of k_iter_mid; one atomic per such row
-      // (a few dozen per circuit in the steady state), counter zeroed by k_init_state / k_presweep
-      if (BATCH && any) { const int pos = atomicAdd(&p.alive[0], 1); if (pos < p.N) p.alive[1 + pos] = n; }
-    }
+    stats_row<BATCH>(p, lam, n, lane);
   } else {
     cm_col_dot16(((int)blockIdx.x - nbR) * blockDim.x + threadIdx.x, p.K, p.mu, lam, p.col_ptr, p.csc_row, p.csc_pos, orth, p.R, p.colany);
   }
@@ -61,7 +104,8 @@ __global__ __launch_bounds__(CM_POST_THREADS) void k_post_single(cm_parg<false> 
 // Row + column statistics of the current lam.
 int cm_launch_stats(cm_ctx* ctx, cm_set& s, double spont_orthogonality) {
   const cm_problem* p = s.lead;
-  const int nbR = (p->N + 3) / 4, nbC = (p->K * 16 + 255) / 256;     // one wave per row; 16 lanes per trial column
+  const int nbR = s.B > 1 ? (p->N + 7) / 8 : (p->N + 3) / 4;        // one wave per row (batches: per two rows)
+  const int nbC = (p->K * 16 + 255) / 256;                           // 16 lanes per trial column
   CM_LAUNCH_SET(k_stats, s, nbR + nbC, 256, 0, ctx->stream, nbR, spont_orthogonality);
   CM_HIP(hipGetLastError());
   return CM_OK;

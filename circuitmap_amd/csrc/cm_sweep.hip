@@ -261,13 +261,6 @@ __device__ __forceinline__ void sweep_step_long(const SweepArgs& a, int n, RPtr 
 }
 
 // ---- two rows per wavefront (one per 32-lane half): rows with <= 32 targeted trials, <= 8 powers.
-// Sum over each half, every lane receiving its half's sum.  Bitwise what cm_wave_sum gives the same row alone in a wavefront (there
-// the upper two 16-lane partial sums are zeros and (r0 + r1) + (0 + 0) == r0 + r1).
-__device__ __forceinline__ double cm_half_sum(double v) {
-  v = cm_seg_sum<16>(v);
-  const double r0 = cm_readlane_f64(v, 0), r1 = cm_readlane_f64(v, 16), r2 = cm_readlane_f64(v, 32), r3 = cm_readlane_f64(v, 48);
-  return (threadIdx.x & 32) ? (r2 + r3) : (r0 + r1);
-}
 // row_gate_small for two rows at once: the same operations per row, in the same order (the per-power divisions in lanes 0..P-1 of
 // the row's half, the suffix means likewise), so each row's gate is bit for bit that of row_gate_small
 template <int PS>
