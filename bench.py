@@ -548,43 +548,6 @@ def main():
                                        "k_iter_mid_avg_launch_ms": btms[-1]["mid_ms"] / its, "k_sweep_par_avg_launch_ms": btms[-1]["sweep_seq_ms"] / its,
                                        "fact_ms_per_step": btms[-1]["fact_ms"],
                                        "note": "every circuit bit-identical to its single fit (tests/test_gpu_parity.py::test_fit_batch_baseline_config3)"}
-        if world == 1 and B > 1 and a.streams_leg and a.streams_leg > 1 and G == 1:
-            # the same B circuits as several lock-step batches in flight on separate contexts (HIP streams), one host thread each
-            from concurrent.futures import ThreadPoolExecutor
-            from circuitmap_amd.simulation import simulate_device
-            Gs = a.streams_leg
-            lctx = [_lib.Context(local_rank) for _ in range(Gs)]
-            lprobs = [[] for _ in range(Gs)]
-            for j in range(B):
-                cx = lctx[j % Gs]
-                d = simulate_device(N=N, T=T, H=H, trials=K, seed=a.circuit_seed + j, device_id=local_rank, keep_on_device=True, ctx=cx)
-                lprobs[j % Gs].append(Problem(cx, None, None, device_ptrs=(N, K, T, d["psc_ptr"], d["stim_ptr"])))
-                cx.free(d["psc_ptr"]); cx.free(d["stim_ptr"])
-            with ThreadPoolExecutor(max_workers=Gs) as ex:
-                def lstep():
-                    for f in [ex.submit(run_batch, lprobs[g], pri, **opts) for g in range(Gs)]:
-                        f.result()
-                for _ in range(2):
-                    lstep()
-                for cx in lctx:
-                    cx.synchronize()
-                gc.collect(); gc.disable()
-                t1 = time.perf_counter()
-                for _ in range(6):
-                    lstep()
-                for cx in lctx:
-                    cx.synchronize()
-                ldt = time.perf_counter() - t1
-                gc.enable()
-            for g in range(Gs):
-                for q in lprobs[g]:
-                    q.close()
-            lval = B * 6 * its / ldt
-            out["interleaved_streams"] = {"streams": Gs, "circuits_per_launch": B // Gs, "value": lval, "unit": "iterations/s", "steps": 6, "warmup": 2,
-                                          "ms_per_step": ldt / 6 * 1e3, "x_one_batch": lval / value,
-                                          "note": "the serial phases of one batch (Gauss-Seidel chains, Cholesky panels) overlap the wide phases of the "
-                                                  "others; per-kernel timings are then no longer those of a kernel alone on the GPU, which is why the "
-                                                  "headline keeps one batch per step"}
         if world == 1 and B > 1 and not a.no_single_leg:
             # the same path one circuit at a time: the latency of a fit (what round 1's bench line reported)
             q = sets[0][0]
@@ -602,6 +565,52 @@ def main():
                                      "fact_ms_per_fit": float(np.mean([t["fact_ms"] for t in sk])),
                                      "batch_x_single": value / (8 * its / sdt),
                                      "note": "one circuit per step on the same GPU: a latency chain occupying a few percent of the chip"}
+        if world == 1 and B > 1 and a.streams_leg and a.streams_leg > 1 and G == 1:
+            # the same B circuits as several lock-step batches in flight on separate contexts (HIP streams), one host thread each
+            for probs_ in sets:                              # (the main measurement's circuits are released first)
+                for q_ in probs_:
+                    q_.close()
+            sets = []
+            from concurrent.futures import ThreadPoolExecutor
+            from circuitmap_amd.simulation import simulate_device
+            Gs = a.streams_leg
+            lctx = [ctx] + [_lib.Context(local_rank) for _ in range(Gs - 1)]     # the main context + Gs - 1 more (as --batch-streams Gs creates them)
+            lprobs = [[] for _ in range(Gs)]
+            for j in range(B):
+                cx = lctx[j % Gs]
+                d = simulate_device(N=N, T=T, H=H, trials=K, seed=a.circuit_seed + j, device_id=local_rank, keep_on_device=True, ctx=cx)
+                lprobs[j % Gs].append(Problem(cx, None, None, device_ptrs=(N, K, T, d["psc_ptr"], d["stim_ptr"])))
+                cx.free(d["psc_ptr"]); cx.free(d["stim_ptr"])
+            with ThreadPoolExecutor(max_workers=Gs) as ex:
+                def lstep():
+                    for f in [ex.submit(run_batch, lprobs[g], pri, **opts) for g in range(Gs)]:
+                        f.result()
+                for _ in range(2):
+                    lstep()
+                for cx in lctx:
+                    cx.synchronize()
+                gc.collect(); gc.disable()
+                t1 = time.perf_counter()
+                lwall = []
+                for _ in range(6):
+                    ts_ = time.perf_counter()
+                    lstep()
+                    lwall.append((time.perf_counter() - ts_) * 1e3)
+                for cx in lctx:
+                    cx.synchronize()
+                ldt = time.perf_counter() - t1
+                if os.environ.get("CAVIAR_BENCH_TRACE_STEPS"):
+                    print("interleaved leg step wall ms:", " ".join("%.2f" % v for v in lwall), file=sys.stderr)
+                gc.enable()
+            for g in range(Gs):
+                for q in lprobs[g]:
+                    q.close()
+            lval = B * 6 * its / ldt
+            out["interleaved_streams"] = {"streams": Gs, "circuits_per_launch": B // Gs, "value": lval, "unit": "iterations/s", "steps": 6, "warmup": 2,
+                                          "ms_per_step": ldt / 6 * 1e3, "x_one_batch": lval / value,
+                                          "note": "the serial phases of one batch (Gauss-Seidel chains, Cholesky panels) overlap the wide phases of the "
+                                                  "others; per-kernel timings are then no longer those of a kernel alone on the GPU, which is why the "
+                                                  "headline keeps one batch per step"}
         if world == 1 and not a.no_cpu_baseline and sims:
             out["cpu_baseline"] = cpu_baseline(sims[0], pri, wl)
         emit(json.dumps(out))
