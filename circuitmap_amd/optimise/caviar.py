@@ -129,15 +129,16 @@ def _priors_struct(N, mu_prior, beta_prior, shape_prior, rate_prior, phi_prior, 
     return _lib.CmPriors(_lib.dptr(arrs[0]), _lib.dptr(arrs[1]), float(shape_prior), float(rate_prior), _lib.dptr(arrs[2]), _lib.dptr(arrs[3]))
 
 
-def run_batch(problems, priors, verbose=0, timing=0, **fit_options):
+def run_batch(problems, priors, update_orders=None, uniforms=None, verbose=0, timing=0, **fit_options):
     """cm_caviar_run_batch: fit several `Problem`s of ONE context in lock-step (the circuit is the outer grid dimension of every
     launch).  `priors`: one dict (shared) or a list of dicts with keys mu, beta, shape, rate, phi, phi_cov.  Results stay in HBM
-    (`Problem.fetch`), each bit-identical to the circuit's own `Problem.run`.  Returns the list of device timings."""
+    (`Problem.fetch`), each bit-identical to the circuit's own `Problem.run`.  `update_orders` [iters, N] / `uniforms`
+    [iters, N, S, 2]: explicit RNG streams, shared by all circuits (which must then have the same N).  Returns the device timings."""
     if not problems:
         return []
     ctx = problems[0].ctx
     if any(q.ctx is not ctx for q in problems):
-        raise ValueError("run_batch: all problems must live on the same context")
+        raise _lib.CaviarHipError("run_batch: all problems must live on the same context")
     unknown = set(fit_options) - set(_OPTION_NAMES)
     if unknown:
         raise TypeError("caviar() got an unexpected keyword argument '%s'" % sorted(unknown)[0])
@@ -147,6 +148,16 @@ def run_batch(problems, priors, verbose=0, timing=0, **fit_options):
     keep = []
     prs = (_lib.CmPriors * n)(*[_priors_struct(q.N, pr["mu"], pr["beta"], pr["shape"], pr["rate"], pr["phi"], pr["phi_cov"], keep)
                                 for q, pr in zip(problems, plist)])
+    if update_orders is not None or uniforms is not None:
+        N, S = problems[0].N, o.num_mc_samples
+        if any(q.N != N for q in problems):
+            raise ValueError("run_batch: explicit RNG streams need circuits of one size")
+        uo = np.ascontiguousarray(update_orders, dtype=np.int32).reshape(o.iters, N)
+        uu = _lib.f64(uniforms, (o.iters, N, S, 2))
+        keep += [uo, uu]
+        o.rng_mode = _lib.CM_RNG_EXPLICIT
+        o.update_orders = uo.ctypes.data_as(C.POINTER(C.c_int32))
+        o.uniforms = _lib.dptr(uu)
     handles = (C.c_void_p * n)(*[q.handle for q in problems])
     tms = (_lib.CmTimings * n)()
     with ctx.lock:

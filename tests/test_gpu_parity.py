@@ -371,6 +371,42 @@ def test_run_batch_bit_identical_to_serial(ctx):
         q.close()
 
 
+def test_run_batch_explicit_streams_and_argument_checks(ctx):
+    """A batch fed explicit RNG streams (shared by its circuits) equals the seeded batch bit for bit; argument errors come back as
+    error codes (problems of another context, a problem listed twice, NULL priors), not as faults."""
+    from circuitmap_amd import _lib
+    from circuitmap_amd.optimise.caviar import Problem, run_batch
+    from oracle import threefry
+    sims = [_sim_case(60, 150, 950 + i)[0] for i in range(3)]
+    pri = default_priors(60)
+    opts = dict(iters=7, seed=5, num_mc_samples=20)
+    orders, u = threefry.make_explicit_streams(5, 7, 60, 20)
+    probs = [Problem(ctx, s_["psc"], s_["stim_matrix"]) for s_ in sims]
+    run_batch(probs, pri, **opts)
+    seeded = [q.fetch() for q in probs]
+    run_batch(probs, pri, update_orders=orders, uniforms=u, **opts)
+    for q, ref in zip(probs, seeded):
+        _assert_same_fit(q.fetch(), ref, "explicit streams")
+    other = _lib.Context(0)
+    foreign = Problem(other, sims[0]["psc"], sims[0]["stim_matrix"])
+    with pytest.raises(_lib.CaviarHipError):
+        run_batch([probs[0], foreign], pri, **opts)                      # mixed contexts are refused in Python ...
+    handles = (C.c_void_p * 2)(probs[0].handle, foreign.handle)
+    o = _lib.CmOptions(); ctx.lib.cm_options_default(C.byref(o))
+    keep = []
+    from circuitmap_amd.optimise.caviar import _priors_struct
+    prs = (_lib.CmPriors * 2)(*[_priors_struct(60, *prior_args(pri), keep) for _ in range(2)])
+    assert ctx.lib.cm_caviar_run_batch(ctx.handle, 2, handles, prs, C.byref(o), None) == -1     # ... and by the C ABI (CM_ERR_INVALID)
+    handles = (C.c_void_p * 2)(probs[0].handle, probs[0].handle)
+    assert ctx.lib.cm_caviar_run_batch(ctx.handle, 2, handles, prs, C.byref(o), None) == -1     # the same problem twice
+    assert b"twice" in ctx.lib.cm_last_error()
+    bad = (_lib.CmPriors * 1)(_lib.CmPriors())
+    assert ctx.lib.cm_caviar_run_batch(ctx.handle, 1, (C.c_void_p * 1)(probs[0].handle), bad, C.byref(o), None) == -1   # NULL prior arrays
+    foreign.close(); other.close()
+    for q in probs:
+        q.close()
+
+
 def test_fit_batch_baseline_config3():
     """BASELINE configs[3]: the batch of 8 independent N=1000 / K=2000 circuits (seeds 2000..2007), 50 iterations + fn_scan, here
     all on ONE GPU as one lock-step batch through batch.fit_batch; every circuit bit-identical to its direct caviar() call."""
