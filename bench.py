@@ -296,7 +296,7 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--circuits-per-gpu", type=int, default=None, help="B: every step fits B independent circuits per GPU as ONE lock-step batch "
                     "(cm_caviar_run_batch: the circuit is the outer grid dimension of every launch); value counts all of their iterations.  "
-                    "Default 64 (1 for cfg5: one N=5000 circuit already fills the GPU); 1 = one circuit at a time (the latency form)")
+                    "Default 128 (1 for cfg5: one N=5000 circuit already fills the GPU); 1 = one circuit at a time (the latency form)")
     ap.add_argument("--batch-leg", type=int, default=16, help="with --circuits-per-gpu 1 on one GPU: also time a lock-step batch of this many "
                     "circuits after the main measurement and report it under `batch_throughput` (0 = skip)")
     ap.add_argument("--batch-streams", type=int, default=1, help="G (default 1): the B circuits of a step run as G lock-step batches of B / G circuits, each on its "
@@ -359,7 +359,7 @@ def main():
     wl = WORKLOADS[a.workload]
     N, K, T, H = wl["N"], wl["K"], wl["T"], wl["H"]
     if a.circuits_per_gpu is None:
-        a.circuits_per_gpu = 1 if a.workload == "cfg5" else 64
+        a.circuits_per_gpu = 1 if a.workload == "cfg5" else 128
     B = max(1, a.circuits_per_gpu)
     if a.streams_leg is None:
         a.streams_leg = 4 if (B >= 16 and a.batch_streams == 1) else 0
@@ -471,10 +471,14 @@ def main():
         recs = float(np.mean([t["sum_seq_records"] for t in tms])) / its         # 32-B records per launch and circuit (average over the fit)
         rows = float(np.mean([t["sum_seq_rows"] for t in tms])) / its
         chain_bytes = Bl * (recs * 32 + (recs - rows) * 8 + K * 12)               # records + lam writes + R and ticket vectors
-        # (3) trailing updates of the tiled Cholesky (k_chol_panel, or k_chol_trsm + k_chol_bulk above 48 tile rows): per launch the
-        #     t (t + 1) / 2 trailing 32 x 32 fp64 tiles are read and rewritten (16 KB per tile)
+        # (3) the passes of the tiled Cholesky over the trailing matrix: k_chol_panel (one panel per launch; one circuit up to 48 tile rows), or
+        #     panel-pair steps k_chol_trsm + thin k_chol_bulk + k_chol_trsm + rank-64 k_chol_bulk (batches, larger matrices), timed as a
+        #     group by one event pair per factorisation.  Algorithmic bytes of a pass: every trailing 32 x 32 fp64 tile
+        #     read and rewritten once (16 KB), plus the 8 KB tiles no blocking of this width avoids, each counted once per launch however many
+        #     workgroups share it -- panel tiles read, solved panel tiles written, the diagonal tile's inverse
         fl = float(np.mean([t["fact_launches"] for t in tms_k]))
         ft = float(np.mean([t["fact_tile_updates"] for t in tms_k]))
+        fp = float(np.mean([t["fact_panel_tiles"] for t in tms_k]))
         fact_total = mean_k("fact_ms")
         mid_name = "k_iter_mid"
         # batches: the all-zero rows (95 % in the steady state) run in their own lean kernel k_mc_dead, timed separately; their share of the bytes:
@@ -494,8 +498,9 @@ def main():
                                       "(S x P sigmoid-logit evaluations per row), one wavefront per row")
         if fl > 0:
             cands["k_chol_bulk+k_chol_trsm" if (N > 48 * 32 or B > 1) else "k_chol_panel"] = dict(
-                total_ms=fact_total, launches=fl, bytes=ft * 16384.0 / fl,
-                note="trailing update of the blocked fp64 Cholesky: bandwidth-bound above ~48 tile rows, launch-chain-bound below")
+                total_ms=fact_total, launches=fl, bytes=(ft * 16384.0 + fp * 8192.0) / fl,
+                note="passes of the blocked fp64 Cholesky over the trailing matrix (two panels per pass): bandwidth-bound while the trailing "
+                     "matrix is large, launch-chain-bound in the last panels and for one circuit")
         dom = max(cands, key=lambda k_: cands[k_]["total_ms"])
         for k_, c_ in cands.items():
             c_["avg_launch_ms"] = c_["total_ms"] / max(c_["launches"], 1)

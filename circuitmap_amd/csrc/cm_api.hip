@@ -72,6 +72,8 @@ static int ctx_init(cm_ctx* c, int device_id, void* hip_stream) {
   memset(c->h_pinned, 0, CM_MAILBOX_WORDS * sizeof(int32_t));
   CM_HIP(hipHostGetDevicePointer((void**)&c->d_mailbox, c->h_pinned, 0));
   c->use_mailbox = getenv("CAVIAR_HIP_NO_MAILBOX") == nullptr;
+  if (const char* e = getenv("CAVIAR_HIP_SOLVE_GROUP")) c->solve_group = atoi(e);
+  if (const char* e = getenv("CAVIAR_HIP_XCD_MODE")) c->xcd_mode = atoi(e);
   if (getenv("CAVIAR_HIP_TRACE_BLOCK0")) { CM_HIP(hipMalloc((void**)&c->dbg_block0, 64 * 8 * sizeof(long long))); CM_HIP(hipMemset(c->dbg_block0, 0, 64 * 8 * sizeof(long long))); }
   hipDeviceProp_t prop;
   CM_HIP(hipGetDeviceProperties(&prop, device_id));
@@ -676,7 +678,7 @@ static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_option
       cm_host_reconnect(host_rows(q), h, h + N, nullptr, h + 2 * (size_t)N, o->msrmp, o->minimum_spike_count, o->verbose, &ones[c]);
     };
     if (B > 1 && o->verbose == 0) {
-      if (!ctx->pool_host) ctx->pool_host = new cm_host_pool((int)std::max(1u, std::min(7u, std::thread::hardware_concurrency() > 1 ? std::thread::hardware_concurrency() - 1 : 1u)));
+      if (!ctx->pool_host) ctx->pool_host = new cm_host_pool((int)std::max(1u, std::min(15u, std::thread::hardware_concurrency() > 1 ? std::thread::hardware_concurrency() - 1 : 1u)));
       ctx->pool_host->run(B, scan);
     } else {
       for (int c = 0; c < B; ++c) scan(c);
@@ -723,7 +725,7 @@ static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_option
     cm_timings t0;
     memset(&t0, 0, sizeof(t0));
     t0.total_ms = a; t0.iters_ms = b; t0.fn_scan_ms = c; t0.iters = iters; t0.batch = B;
-    t0.fact_launches = s.fact_launches; t0.fact_tile_updates = s.fact_tile_updates;
+    t0.fact_launches = s.fact_launches; t0.fact_tile_updates = s.fact_tile_updates; t0.fact_panel_tiles = s.fact_panel_tiles;
     for (int it = 0; timed && it < iters; ++it) {
       float d = 0;
       hipEventElapsedTime(&d, EV(it, 3), EV(it, 4));

@@ -541,16 +541,59 @@ __device__ __forceinline__ double cm_uniform64(uint32_t k0, uint32_t k1, int j, 
 // reference forms them, log(r) = x + log1p(r e - 1) up to the last-ulp error of e; r e - 1 is the rounding residue of those three
 // operations, a single fma away, and tiny for moderate |x| (|r e - 1| < 2e-7 below |x| = 20), where two terms of log1p are exact to
 // double precision.  Beyond, and for non-finite x, the literal form (with its saturation to +-inf) is evaluated.
-__device__ __forceinline__ double cm_logit_of_sigmoid(double x) {
+// exp(x) for the Monte-Carlo logit stream (|x| < 20: no overflow / underflow / NaN handling), table-driven:
+//   x = (64 m + j) ln2 / 64 + r,  |r| <= ln2 / 128:   exp(x) = 2^m * 2^(j/64) * (1 + r + r^2/2 + ... + r^5/120)
+// 16 instructions against ~30 of the library routine (whose degree-11 polynomial serves |r| <= ln2 / 2); 1.3 ulp worst case measured
+// over 2e6 arguments (library: 0.7) -- far inside what the consumer can see (see cm_logit_of_sigmoid: the error of e enters the logit as an
+// ABSOLUTE 1e-16).  `tab` = the 64 correctly rounded values 2^(j/64) in LDS (cm_exptab_init).
+static __device__ const double cm_exp2_64[64] = {
+    0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
+    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
+    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
+    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
+    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
+    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
+    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
+    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
+    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
+    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
+    0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
+    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
+    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
+    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0};
+__device__ __forceinline__ void cm_exptab_init(double* tab) {       // first 64 threads of the workgroup; the caller synchronises
+  if (threadIdx.x < 64) tab[threadIdx.x] = cm_exp2_64[threadIdx.x];
+}
+__device__ __forceinline__ double cm_exp_tab(double x, const double* tab) {
+  const double kf = rint(x * 0x1.71547652b82fep+6);            // 64 / ln2
+  double r = fma(kf, -0x1.62e42fefa3000p-7, x);                // ln2 / 64, 41 significant bits: the product is exact
+  r = fma(kf, -0x1.3de6af278ece6p-48, r);
+  const int k = (int)kf;
+  double q = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+  q = fma(r, q, 1.0 / 6.0);
+  q = fma(r, q, 0.5);
+  q = fma(r, q, 1.0);
+  const double t = tab[k & 63];
+  return ldexp(fma(t, r * q, t), k >> 6);
+}
+
+// saturating arguments (and non-finite ones): the literal form, out of line -- rare, and its logarithm and divisions would otherwise
+// set the register budget of every copy of the evaluation loop
+__device__ __noinline__ double cm_logit_literal(double x) {
+  const double f = cm_sigmoid(x);
+  return log(f / (1.0 - f));
+}
+__device__ __forceinline__ double cm_logit_of_sigmoid(double x, const double* etab) {
   if (fabs(x) < 20.0) {
-    const double e = exp(-x);
+    const double e = cm_exp_tab(-x, etab);
     const double f = cm_rcp(1.0 + e);                  // 1 + e in [1, 5e8]: normal range
     const double r = f * cm_rcp(1.0 - f);              // 1 - f in [2e-9, 1)
     const double t = fma(r, e, -1.0);
     return x + (t - 0.5 * t * t);
   }
-  const double f = cm_sigmoid(x);
-  return log(f / (1.0 - f));
+  return cm_logit_literal(x);
 }
 
 // rare path of the steady-state kernel, kept out of line so that its registers do not burden the common path
@@ -568,7 +611,7 @@ __device__ __noinline__ double cm_quantile_slow(double arg) { return normcdfinv(
 template <bool FULL, bool HAVE_C = false>
 __device__ __forceinline__ void mc_logit_body(int n, int lane, double mean0, double mean1, double sd0, double sd1,
                                               const double2* __restrict__ wu, const double* __restrict__ vals, int V, int S,
-                                              double* mc, double* __restrict__ mcE, double c0_in = 0.0, double c1_in = 0.0) {
+                                              double* mc, double* __restrict__ mcE, const double* etab, double c0_in = 0.0, double c1_in = 0.0) {
   const double c0 = HAVE_C ? c0_in : normcdf(-mean0 / sd0), c1 = HAVE_C ? c1_in : normcdf(-mean1 / sd1);
 #pragma unroll
   for (int comp = 0; comp < 2; ++comp) {
@@ -594,11 +637,55 @@ __device__ __forceinline__ void mc_logit_body(int n, int lane, double mean0, dou
   // same-wave LDS write -> read: the LDS pipe is in order for one wave; the (free) wave barrier keeps the compiler from moving the
   // reads above the writes of other lanes
   __builtin_amdgcn_wave_barrier();
+  // The S x P evaluations.  Lane l sums the samples l, l + 64, ... of a power (in that order), then the lanes are reduced.  With
+  // S = 100 the second round of every power fills 36 of the 64 lanes, so the tails of up to four powers are PACKED into shared
+  // rounds (item = power * tail + i), their values handed to lane i through the draw scratch (dead by then) and added where the
+  // plain loop adds them: the same sums in the same order, in ceil(P tail / 64) tail rounds instead of P.
+  const int nfull = S / CM_WAVE, Tn = S - nfull * CM_WAVE;
+  int gi[4] = {0, 0, 0, 0}, P = 0;
+  for (int g = 0; g < V; ++g)
+    if (vals[g] > 0.0) { if (P < 4) gi[P] = g; ++P; }
+  const int tail_items = P * Tn;
+  if (P >= 2 && P <= 4 && Tn > 0 && tail_items <= 2 * CM_WAVE && tail_items <= 2 * S && (tail_items + CM_WAVE - 1) / CM_WAVE < P) {
+    double acc[4] = {0.0, 0.0, 0.0, 0.0}, vk[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      vk[k] = vals[gi[k]];
+      if (k < P)
+        for (int r = 0; r < nfull; ++r) { const int s = r * CM_WAVE + lane; acc[k] += cm_logit_of_sigmoid(mc[2 * s] * vk[k] - mc[2 * s + 1], etab); }
+    }
+    double vt[2] = {0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int item = q * CM_WAVE + lane;
+      if (item < tail_items) {
+        const int k = (item >= Tn) + (item >= 2 * Tn) + (item >= 3 * Tn);
+        const int s = nfull * CM_WAVE + (item - k * Tn);
+        const double v = k == 0 ? vk[0] : (k == 1 ? vk[1] : (k == 2 ? vk[2] : vk[3]));
+        vt[q] = cm_logit_of_sigmoid(mc[2 * s] * v - mc[2 * s + 1], etab);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();                 // every read of the draws is done: the scratch carries the tail values
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { const int item = q * CM_WAVE + lane; if (item < tail_items) mc[item] = vt[q]; }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k < P) {
+        double a = acc[k];
+        if (lane < Tn) a += mc[k * Tn + lane];
+        a = cm_wave_sum(a);
+        if (lane == 0) mcE[(size_t)n * CM_MAX_VALS + gi[k]] = a / (double)S;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();                 // (a caller's next row rewrites the scratch)
+    return;
+  }
   for (int g = 0; g < V; ++g) {
     const double v = vals[g];
     if (!(v > 0.0)) continue;
     double acc = 0.0;
-    for (int s = lane; s < S; s += CM_WAVE) acc += cm_logit_of_sigmoid(mc[2 * s] * v - mc[2 * s + 1]);
+    for (int s = lane; s < S; s += CM_WAVE) acc += cm_logit_of_sigmoid(mc[2 * s] * v - mc[2 * s + 1], etab);
     acc = cm_wave_sum(acc);
     if (lane == 0) mcE[(size_t)n * CM_MAX_VALS + g] = acc / (double)S;
   }

@@ -102,6 +102,8 @@ struct cm_ctx {
   int mail_seq = 0;
   int mb_n = 0, mb_flag = 0;     // last values read from the mailbox (active-set size, not-SPD flag)
   bool use_mailbox = true;
+  int solve_group = 0;           // circuits per group of the tiled solve of a batch (0: the whole batch in lock-step); CAVIAR_HIP_SOLVE_GROUP
+  int xcd_mode = 1;              // cm_xcd_remap mode of the bandwidth-bound solve kernels; CAVIAR_HIP_XCD_MODE
   int num_cus = 256;
   void* h_stage = nullptr;        // pinned staging buffer (priors upload, fn_scan round trip), grown on demand
   size_t h_stage_bytes = 0;
@@ -242,15 +244,17 @@ template <> struct cm_parg<true> {
 // with its own 4 MB L2) round-robin by their linear index; with the plain (blockIdx.x, blockIdx.y) = (tile, circuit) reading,
 // the tiles of one circuit land on all eight and every panel tile they share is fetched into eight L2s.  Remapped, circuit c runs
 // entirely on XCD c mod 8 (needs gridDim.y % 8 == 0, otherwise the plain map).  Placement is a speed heuristic only: any map is correct.
-__device__ __forceinline__ void cm_xcd_remap(int& bx, int& c) {
+// mode 0: plain; 1: the circuits of an XCD interleaved (workgroup by workgroup); 2: circuit-major (an XCD works through one of its
+// circuits after the other: the panel tiles in its L2 are those of one or two circuits instead of all of them).
+__device__ __forceinline__ void cm_xcd_remap(int& bx, int& c, int mode) {
   const int nx = (int)gridDim.x, B = (int)gridDim.y;
   bx = (int)blockIdx.x; c = (int)blockIdx.y;
-  if (B % 8) return;
+  if (B % 8 || mode == 0) return;
   const long long L = (long long)blockIdx.y * nx + blockIdx.x;
   const int xcd = (int)(L % 8), per = B / 8;
   const long long q = L / 8;
-  c = xcd + 8 * (int)(q % per);
-  bx = (int)(q / per);
+  if (mode == 1) { c = xcd + 8 * (int)(q % per); bx = (int)(q / per); }
+  else { c = xcd + 8 * (int)(q / nx); bx = (int)(q % nx); }
 }
 #endif
 
@@ -281,7 +285,7 @@ struct cm_set {
   int small_cap_max = 0, max_row_len_max = 0, max_col_len_max = 0;
   size_t small_lds_max = 0;              // largest LDS need of the fused in-LDS solve over the circuits of the set
   long long nnz_max = 0, nnz_min = 0;
-  long long fact_launches = 0, fact_tile_updates = 0;   // counters of the tiled solves (cm_timings)
+  long long fact_launches = 0, fact_tile_updates = 0, fact_panel_tiles = 0;   // counters of the tiled solves (cm_timings)
   bool last_fact = false;                // the last cm_solve_launch ran a factorisation (and recorded its event pair)
   std::vector<int> na;                   // last active-set sizes read from the mailboxes
   int na_max = 0;

@@ -47,6 +47,9 @@ __device__ __forceinline__ void dead_phi_copy(const cm_pdev& p, int n, int lane,
 template <bool BATCH>
 __global__ __launch_bounds__(256) void k_mc_dead(cm_parg<BATCH> pa, IterDyn a) {
   extern __shared__ double sm[];
+  __shared__ double etab[64];
+  cm_exptab_init(etab);
+  __syncthreads();                                   // (before any wavefront leaves)
   const cm_pdev& p = pa.get();
   const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE;
   const int n = (int)blockIdx.x * (int)(blockDim.x / CM_WAVE) + wave;
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(256) void k_mc_dead(cm_parg<BATCH> pa, IterDyn a) {
     const int m = p.inv_all[(size_t)a.nx * N + n];
     const size_t off = ((size_t)a.nx * N + m) * 2 * a.S;
     mc_logit_body<false, true>(n, lane, pc[0], pc[1], pc[2], pc[3], (const double2*)p.wtab + off, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S,
-                               p.mcE, c0, c1);
+                               p.mcE, etab, c0, c1);
   }
 }
 
@@ -87,6 +90,9 @@ __global__ __launch_bounds__(CM_ITER_THREADS) void k_iter_mid(cm_parg<BATCH> pa,
     return;
   }
   if (!(a.roles & 2)) return;
+  __shared__ double etab[64];
+  cm_exptab_init(etab);
+  __syncthreads();                                   // (before any wavefront leaves)
   const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE;
   const int N = p.N;
   if (BATCH && a.skip_dead) {
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(CM_ITER_THREADS) void k_iter_mid(cm_parg<BATCH> pa,
       if (a.do_mc) {
         const int m = p.inv_all[(size_t)a.nx * N + n];
         const size_t off = ((size_t)a.nx * N + m) * 2 * a.S;
-        mc_logit_body<FULLMC>(n, lane, pc[0], pc[1], pc[2], pc[3], (const double2*)p.wtab + off, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE);
+        mc_logit_body<FULLMC>(n, lane, pc[0], pc[1], pc[2], pc[3], (const double2*)p.wtab + off, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE, etab);
       }
     }
     return;
@@ -127,9 +133,9 @@ __global__ __launch_bounds__(CM_ITER_THREADS) void k_iter_mid(cm_parg<BATCH> pa,
     const size_t off = ((size_t)a.nx * N + m) * 2 * a.S;
     const double2* wu = (const double2*)p.wtab + off;   // (ndtri(u), u) of that sweep step
     if (!FULLMC && dead_row)
-      mc_logit_body<false, true>(n, lane, pc[0], pc[1], pc[2], pc[3], wu, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE, dc0, dc1);
+      mc_logit_body<false, true>(n, lane, pc[0], pc[1], pc[2], pc[3], wu, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE, etab, dc0, dc1);
     else
-      mc_logit_body<FULLMC>(n, lane, pc[0], pc[1], pc[2], pc[3], wu, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE);
+      mc_logit_body<FULLMC>(n, lane, pc[0], pc[1], pc[2], pc[3], wu, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE, etab);
   }
 }
 

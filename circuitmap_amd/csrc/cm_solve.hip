@@ -21,7 +21,7 @@
 #define CM_SOLVE_PROLOGUE_AT(KIND, PDEV)                                          \
   const cm_pdev& p = PDEV;                                                        \
   const int na = BATCH ? p.n_act[0] : na_arg;                                     \
-  if (BATCH && cm_solve_kind(na, p.small_cap, skip_own != 0) != (KIND)) return;       \
+  if (BATCH && cm_solve_kind(na, p.small_cap, (skip_own & 1) != 0) != (KIND)) return;   \
   const int nblk = (na + TS - 1) / TS, nrow = nblk * TS, ld = nrow + CM_LD_PAD;  \
   (void)nblk; (void)nrow; (void)ld;
 // Leading dimension of the solve matrices = rows + CM_LD_PAD: a power-of-two row stride (1024 doubles at N = 1000) maps the 32 rows
@@ -32,8 +32,20 @@
 #define TP (CM_TILE + 1)   // padded LDS row (doubles)
 
 // ------------------------------------------------------------------------------------------------
-// precision matrix over the active set; one wave per (padded) row, accumulator row in LDS
+// precision matrix over the active set; one wave per (padded) row, accumulator row in LDS.
+//
+// Row a (neuron n) receives, for every trial e of n with lam[e] != 0 and every neuron m targeted in the same trial, lam[e] * lam[m, trial]
+// at column act_inv[m] -- accumulated in the fixed order of the row's trials (the summation order the results are pinned to).  The
+// operands sit behind a four-deep chain of dependent gathers (col -> col_ptr -> csc_row / csc_pos -> act_inv / lam); walked trial by
+// trial that is ~20 x 3 memory round trips per row.  So the wave first GATHERS: one lane per trial fetches (lam, col, column range), a
+// wave scan lays the column mates of all trials out as one item list, and the lanes fetch the items' (active index, lam) side by side
+// (four per lane in flight) into LDS; then it ACCUMULATES from LDS in the original order -- operation for operation the sum of the
+// trial-by-trial walk, with the memory latency paid once per level instead of once per trial and level.
 // ------------------------------------------------------------------------------------------------
+#define CM_BP_ITEMS 256           // staged items per gather round = one round of 4 per lane (a trial with more targeted neurons than this is walked
+                                  // directly); small on purpose: the kernel is latency-bound and LDS is what limits its wavefronts per CU
+__host__ __device__ static inline size_t build_prec_lds(int ld) { return (size_t)ld * sizeof(double) + CM_BP_ITEMS * (sizeof(double) + sizeof(int)); }
+
 template <bool BATCH>
 __global__ __launch_bounds__(64) void k_build_precision(cm_parg<BATCH> pa, int na_arg, int skip_own) {
   CM_SOLVE_PROLOGUE(2)
@@ -53,30 +65,104 @@ __global__ __launch_bounds__(64) void k_build_precision(cm_parg<BATCH> pa, int n
   const double* __restrict__ beta_prior = p.beta_prior;
   double* __restrict__ A = p.A;
   double* __restrict__ rhs = p.rhs;
-  extern __shared__ double acc[];   // [ld]
+  extern __shared__ double acc[];                  // [ld] accumulator row, then the staged items
+  double* il = acc + ld;                           // [CM_BP_ITEMS] lam of the column mate
+  int* ib = reinterpret_cast<int*>(il + CM_BP_ITEMS);   // [CM_BP_ITEMS] its active index (-1: not in the active set)
+  __shared__ int s_off[CM_WAVE], s_cs[CM_WAVE];
+  __shared__ double s_le[CM_WAVE];
   const int a = blockIdx.x;
   const int lane = threadIdx.x;
   double* Arow = A + (size_t)a * ld;
+  // Only the tiles on and below the diagonal are ever read (the factorisation works on the lower triangle, the inverse uses the
+  // strictly-upper tiles as scratch it writes first): the row is produced up to the end of its diagonal tile.
+  const int b_end = (a / TS + 1) * TS;
   if (a >= n_act) {                 // identity padding up to the tile multiple
-    for (int b = lane; b < nrow; b += CM_WAVE) Arow[b] = (b == a) ? 1.0 : 0.0;
+    for (int b = lane; b < b_end; b += CM_WAVE) Arow[b] = (b == a) ? 1.0 : 0.0;
     if (lane == 0) rhs[a] = 0.0;
     return;
   }
-  for (int b = lane; b < nrow; b += CM_WAVE) acc[b] = 0.0;
+  for (int b = lane; b < b_end; b += CM_WAVE) acc[b] = 0.0;
   const int n = act_idx[a];
   const double sig = scal[CM_S_SHAPE] / scal[CM_S_RATE];
-  for (int e = row_ptr[n]; e < row_ptr[n + 1]; ++e) {      // sequential over this neuron's trials: fixed summation order
-    const double le = lam[e];
-    if (le == 0.0) continue;
-    const int k = col[e];
-    for (int ce = col_ptr[k] + lane; ce < col_ptr[k + 1]; ce += CM_WAVE) {   // co-targeted neurons: distinct -> no conflicts
-      const int b = act_inv[csc_row[ce]];
-      if (b >= 0) acc[b] = fma(le, lam[csc_pos[ce]], acc[b]);
+  const int e_beg = row_ptr[n], e_end = row_ptr[n + 1];
+  for (int e0 = e_beg; e0 < e_end; e0 += CM_WAVE) {          // 64 trials of the row at a time, one per lane
+    const int e = e0 + lane;
+    const bool have = e < e_end;
+    const double le = have ? lam[e] : 0.0;
+    const int k = have ? col[e] : 0;
+    int cs = 0, cl = 0;
+    if (have && le != 0.0) { cs = col_ptr[k]; cl = col_ptr[k + 1] - cs; }
+    int incl = cl;                                            // inclusive wave scan of the column lengths
+#pragma unroll
+    for (int d = 1; d < CM_WAVE; d <<= 1) { const int v = __shfl_up(incl, d, CM_WAVE); if (lane >= d) incl += v; }
+    s_off[lane] = incl - cl; s_cs[lane] = cs; s_le[lane] = le;                 // (the gather's search and the direct walk read these)
+    __builtin_amdgcn_wave_barrier();
+    const int nv = min(CM_WAVE, e_end - e0);                  // trials in this chunk
+    const int off = incl - cl;
+    int j0 = 0;
+    while (j0 < nv) {
+      const int base = __builtin_amdgcn_readlane(off, j0);
+      // as many whole trials from j0 on as fit into the staging area (the offsets are monotone: the fitting lanes form a run from j0)
+      const bool fits = lane >= j0 && lane < nv && incl - base <= CM_BP_ITEMS;
+      const int n_take = __popcll(__ballot(fits));
+      if (n_take == 0) {                                      // one trial with more mates than the staging area: walk it directly
+        const double lj = s_le[j0];
+        const int c0 = s_cs[j0], c1 = c0 + __builtin_amdgcn_readlane(cl, j0);
+        for (int ce = c0 + lane; ce < c1; ce += CM_WAVE) {
+          const int b = act_inv[csc_row[ce]];
+          if (b >= 0) acc[b] = fma(lj, lam[csc_pos[ce]], acc[b]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        ++j0;
+        continue;
+      }
+      const int j1 = j0 + n_take, cnt = __builtin_amdgcn_readlane(incl, j1 - 1) - base;
+      // gather: item g of the list belongs to the trial j with s_off[j] <= g < s_off[j + 1]
+      for (int it0 = 0; it0 < cnt; it0 += 4 * CM_WAVE) {
+        int ce[4], pos[4], row[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int it = it0 + q * CM_WAVE + lane;
+          ce[q] = -1;
+          if (it < cnt) {
+            const int g = base + it;
+            int lo = j0, hi = j1 - 1;                         // last trial whose offset is <= g
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_off[mid] <= g) lo = mid; else hi = mid - 1; }
+            ce[q] = s_cs[lo] + (g - s_off[lo]);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { row[q] = ce[q] >= 0 ? csc_row[ce[q]] : 0; pos[q] = ce[q] >= 0 ? csc_pos[ce[q]] : 0; }
+        int bq[4];
+        double lq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { bq[q] = ce[q] >= 0 ? act_inv[row[q]] : -1; lq[q] = ce[q] >= 0 ? lam[pos[q]] : 0.0; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int it = it0 + q * CM_WAVE + lane;
+          if (it < cnt) { ib[it] = bq[q]; il[it] = lq[q]; }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      // accumulate: trial by trial in the row's order; the mates of one trial are distinct neurons -> no conflicts within a step
+      for (int j = j0; j < j1; ++j) {
+        const int c = __builtin_amdgcn_readlane(cl, j);
+        if (c == 0) continue;                                 // lam[e] == 0: the trial contributes nothing
+        const int o = __builtin_amdgcn_readlane(off, j) - base;
+        const double lj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(le), j), __builtin_amdgcn_readlane(__double2loint(le), j));
+        for (int q = lane; q < c; q += CM_WAVE) {
+          const int b = ib[o + q];
+          if (b >= 0) acc[b] = fma(lj, il[o + q], acc[b]);
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      j0 = j1;
     }
+    __builtin_amdgcn_wave_barrier();
   }
   const double b0 = beta_prior[n];
   const double prec0 = 1.0 / (b0 * b0);
-  for (int b = lane; b < nrow; b += CM_WAVE) {
+  for (int b = lane; b < b_end; b += CM_WAVE) {
     double v = 0.0;
     if (b < n_act) v = (b == a) ? sig * (rs[(size_t)n * 4 + 3] + acc[b]) + prec0 : sig * acc[b];
     Arow[b] = v;
@@ -87,8 +173,19 @@ __global__ __launch_bounds__(64) void k_build_precision(cm_parg<BATCH> pa, int n
 // ------------------------------------------------------------------------------------------------
 // 32x32 tile helpers (256 threads, each owns a 2x2 patch)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void tile_load(double (*dst)[TP], const double* __restrict__ src, int ld) {
-  for (int i = threadIdx.x; i < TS * TS; i += blockDim.x) dst[i / TS][i % TS] = src[(size_t)(i / TS) * ld + (i % TS)];
+// A tile always moves as "every load in flight, then consume": the 1024 / NT elements of a thread go through registers, and a
+// kernel that needs several tiles fetches all of them before the first tile_put (a load-and-store loop per tile costs one memory
+// round trip per element and tile -- measured: 8 dependent round trips in front of a 0.2 us tile product).  NT = threads of the
+// workgroup taking part (compile time).
+template <int NT = 256>
+__device__ __forceinline__ void tile_fetch(double (&r)[TS * TS / NT], const double* __restrict__ src, int ld) {
+#pragma unroll
+  for (int q = 0; q < TS * TS / NT; ++q) { const int i = threadIdx.x + NT * q; r[q] = src[(size_t)(i / TS) * ld + (i % TS)]; }
+}
+template <int NT = 256>
+__device__ __forceinline__ void tile_put(double (*dst)[TP], const double (&r)[TS * TS / NT]) {
+#pragma unroll
+  for (int q = 0; q < TS * TS / NT; ++q) { const int i = threadIdx.x + NT * q; dst[i / TS][i % TS] = r[q]; }
 }
 __device__ __forceinline__ void tile_store(double* __restrict__ dst, int ld, const double (*src)[TP]) {
   for (int i = threadIdx.x; i < TS * TS; i += blockDim.x) dst[(size_t)(i / TS) * ld + (i % TS)] = src[i / TS][i % TS];
@@ -316,7 +413,9 @@ __global__ __launch_bounds__(256) void k_chol_first(cm_parg<BATCH> pa, int na_ar
   double* __restrict__ Dinv = p.Dinv;
   int* __restrict__ flag = p.n_act + 1;
   __shared__ double C[TS][TP], Li[TS][TP];
-  tile_load(C, A, ld);
+  double rc[4];
+  tile_fetch(rc, A, ld);
+  tile_put(C, rc);
   __syncthreads();
   tile_linv_reg(C, Li, flag);
   for (int i = threadIdx.x; i < TS * TS; i += 256) Dinv[(size_t)(i / TS) * TS + (i % TS)] = Li[i / TS][i % TS];
@@ -332,8 +431,11 @@ __global__ __launch_bounds__(256) void k_chol_trsm(cm_parg<BATCH> pa, int na_arg
   const double* __restrict__ Dinv = p.Dinv;
   __shared__ double P[TS][TP], Li[TS][TP];
   const int i = j + 1 + blockIdx.x;
-  tile_load(P, A + (size_t)i * TS * ld + (size_t)j * TS, ld);
-  tile_load(Li, Dinv + (size_t)j * TS * TS, TS);
+  double rp[4], rl[4];
+  tile_fetch(rp, A + (size_t)i * TS * ld + (size_t)j * TS, ld);
+  tile_fetch(rl, Dinv + (size_t)j * TS * TS, TS);
+  tile_put(P, rp);
+  tile_put(Li, rl);
   __syncthreads();
   const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE, rb = wave >> 1, cb = wave & 1;
   cm_d4 c = {0.0, 0.0, 0.0, 0.0};
@@ -343,54 +445,78 @@ __global__ __launch_bounds__(256) void k_chol_trsm(cm_parg<BATCH> pa, int na_arg
   for (int reg = 0; reg < 4; ++reg) out[(size_t)BLK_ROW(rb, lane, reg) * ld + BLK_COL(cb, lane)] = c[reg];
 }
 
-// Large matrices (more than 48 tiles): the trailing update is bandwidth-bound -- every panel re-reads and re-writes the
-// whole trailing matrix -- so it gets its own lean kernel: 256-thread workgroups, two LDS tiles (the solved panel tiles X_i,
-// X_l from Lf), one 16x16 output block per wave on the matrix cores, output tile prefetched into registers.  Many workgroups
-// per CU keep enough bytes in flight; block 0 owns the diagonal tile (j+1, j+1) and factors it in place.
-template <bool BATCH>
+// Large matrices (more than 48 tiles) and every batch: the trailing update is bandwidth-bound -- every pass re-reads and re-writes
+// the trailing matrix -- so the panels go in PAIRS (j, j + 1) and the trailing matrix is read and rewritten once per pair:
+//   k_chol_trsm(j)        X^j_i   = A[i][j] L_jj^-T                                   i > j
+//   k_chol_bulk<thin>(j)  A[i][j+1] -= X^j_i X^j_{j+1}^T                              i >= j + 1   (one tile column; block 0 factors the diagonal tile (j+1, j+1))
+//   k_chol_trsm(j + 1)    X^{j+1}_i = A[i][j+1] L_{j+1,j+1}^-T                        i > j + 1
+//   k_chol_bulk<wide>(j)  A[i][l] = (A[i][l] - X^j_i X^j_l^T) - X^{j+1}_i X^{j+1}_l^T   i >= l >= j + 2  (block 0 factors the diagonal tile (j+2, j+2))
+// Each product is its own matrix-core accumulation from zero and the two subtractions happen in panel order, so every tile holds
+// bitwise what one rank-32 update per panel leaves (k_chol_panel).  256-thread workgroups, one 16x16 output block per wave, the
+// output tile prefetched into registers, all panel tiles of the workgroup staged in LDS by one round of loads.  A circuit whose last
+// panel has no partner (one trailing tile row) is complete after the thin pass: its wide pass has no tiles.
+template <bool BATCH, bool WIDE>
 __global__ __launch_bounds__(256) void k_chol_bulk(cm_parg<BATCH> pa, int na_arg, int skip_own, int j, int large_min) {
   int bx = (int)blockIdx.x, circ = 0;
-  if (BATCH) cm_xcd_remap(bx, circ);                 // all tiles of a circuit on one XCD: its panel tiles go through one L2
+  if (BATCH) cm_xcd_remap(bx, circ, skip_own >> 8);  // all tiles of a circuit on one XCD: its panel tiles go through one L2
   CM_SOLVE_PROLOGUE_AT(2, pa.get(circ))
-  {
-    const int tr = nblk - j - 1;
-    if (nblk <= large_min || tr <= 0 || bx >= tr * (tr + 1) / 2) return;
-  }
+  const int tr = nblk - j - 1;                       // trailing tile rows of panel j
+  if (nblk <= large_min || tr <= 0 || bx >= (WIDE ? (tr - 1) * tr / 2 : tr)) return;
   double* __restrict__ A = p.A;
   const double* __restrict__ Lf = p.Lf;
   double* __restrict__ Dinv = p.Dinv;
   int* __restrict__ flag = p.n_act + 1;
-  __shared__ double Sm[3][TS][TP];
-  double (*Xi)[TP] = Sm[0], (*Xl)[TP] = Sm[1];
-  // linear block id -> (i, l), 0 <= l' <= i' in the trailing tile rows; id 0 is the diagonal tile (j+1, j+1)
-  const int t = bx;
-  int ip = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-  while ((ip + 1) * (ip + 2) / 2 <= t) ++ip;
-  while (ip * (ip + 1) / 2 > t) --ip;
-  const int lp = t - ip * (ip + 1) / 2;
-  const int i = j + 1 + ip, l = j + 1 + lp;
+  __shared__ double Sm[WIDE ? 4 : 3][TS][TP];
+  const int t = bx;                                  // id 0 is the pass's diagonal tile
+  int i, l;
+  if (WIDE) {                                        // linear id -> (i, l), j + 2 <= l <= i
+    int ip = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((ip + 1) * (ip + 2) / 2 <= t) ++ip;
+    while (ip * (ip + 1) / 2 > t) --ip;
+    i = j + 2 + ip; l = j + 2 + (t - ip * (ip + 1) / 2);
+  } else { i = j + 1 + t; l = j + 1; }
   const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE, rb = wave >> 1, cb = wave & 1;
   double* out = A + (size_t)i * TS * ld + (size_t)l * TS;
-  double oprev[4];
+  double o[4];
 #pragma unroll
-  for (int reg = 0; reg < 4; ++reg) oprev[reg] = out[(size_t)BLK_ROW(rb, lane, reg) * ld + BLK_COL(cb, lane)];
-  tile_load(Xi, Lf + (size_t)i * TS * ld + (size_t)j * TS, ld);
-  if (l != i) tile_load(Xl, Lf + (size_t)l * TS * ld + (size_t)j * TS, ld);
+  for (int reg = 0; reg < 4; ++reg) o[reg] = out[(size_t)BLK_ROW(rb, lane, reg) * ld + BLK_COL(cb, lane)];
+  // every load of the workgroup is issued before the first one is consumed (one memory round trip, not one per tile): the panel
+  // tiles go through registers, and a diagonal output tile (l == i) simply fetches its panel tile twice -- no branch between loads
+  double rx[WIDE ? 4 : 2][4];
+  tile_fetch(rx[0], Lf + (size_t)i * TS * ld + (size_t)j * TS, ld);
+  tile_fetch(rx[1], Lf + (size_t)l * TS * ld + (size_t)j * TS, ld);
+  if (WIDE) {
+    tile_fetch(rx[2], Lf + (size_t)i * TS * ld + (size_t)(j + 1) * TS, ld);
+    tile_fetch(rx[3], Lf + (size_t)l * TS * ld + (size_t)(j + 1) * TS, ld);
+  }
+#pragma unroll
+  for (int q = 0; q < (WIDE ? 4 : 2); ++q) tile_put(Sm[q], rx[q]);
   __syncthreads();
-  cm_d4 c = {0.0, 0.0, 0.0, 0.0};
-  c = (l != i) ? blk_mfma_nt(c, Xi, Xl, rb, cb, lane) : blk_mfma_nt(c, Xi, Xi, rb, cb, lane);
+  {
+    cm_d4 c = {0.0, 0.0, 0.0, 0.0};
+    c = blk_mfma_nt(c, Sm[0], Sm[1], rb, cb, lane);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) o[reg] -= c[reg];
+  }
+  if (WIDE) {
+    cm_d4 c = {0.0, 0.0, 0.0, 0.0};
+    c = blk_mfma_nt(c, Sm[2], Sm[3], rb, cb, lane);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) o[reg] -= c[reg];
+  }
   if (t != 0) {
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) out[(size_t)BLK_ROW(rb, lane, reg) * ld + BLK_COL(cb, lane)] = oprev[reg] - c[reg];
+    for (int reg = 0; reg < 4; ++reg) out[(size_t)BLK_ROW(rb, lane, reg) * ld + BLK_COL(cb, lane)] = o[reg];
     return;
   }
   // block 0: the updated diagonal tile never goes back to HBM -- factor it here, next to the bulk of the update, and
   // publish L^-1 for the next panel's solve (the tile's own copy in A is dead after this)
+  __syncthreads();                                 // every wave is done with the panel tiles: tile 0 receives the diagonal tile, tile 1 L^-1
 #pragma unroll
-  for (int reg = 0; reg < 4; ++reg) Sm[2][BLK_ROW(rb, lane, reg)][BLK_COL(cb, lane)] = oprev[reg] - c[reg];
-  __syncthreads();                                 // all reads of Xi are done: tile 1 receives L^-1
-  tile_linv_reg2(Sm[2], Sm[1], flag);
-  tile_store(Dinv + (size_t)(j + 1) * TS * TS, TS, Sm[1]);
+  for (int reg = 0; reg < 4; ++reg) Sm[0][BLK_ROW(rb, lane, reg)][BLK_COL(cb, lane)] = o[reg];
+  __syncthreads();
+  tile_linv_reg2(Sm[0], Sm[1], flag);
+  tile_store(Dinv + (size_t)(WIDE ? j + 2 : j + 1) * TS * TS, TS, Sm[1]);
 }
 
 // Panel j in ONE launch (1024-thread workgroups, one per trailing tile (i, l), j < l <= i):
@@ -398,10 +524,9 @@ __global__ __launch_bounds__(256) void k_chol_bulk(cm_parg<BATCH> pa, int na_arg
 //   A[i][l] -= X_i X_l^T                             (trailing update, in place: the tile is owned by this workgroup)
 //   l == j + 1: Lf[i][j] = X_i                       (the factor's panel goes to a separate matrix: A[i][j] is still being read)
 //   i == l == j + 1: factor the next diagonal tile on the spot -> Dinv[j + 1]
-// The 32x32x32 tile products use the first 256 threads (2x2 register patches); the diagonal elimination uses all 1024.
-// SOLVED = true: the panel tiles A[.][j] were already solved (k_chol_trsm wrote X into Lf), so the workgroup only does the
-// trailing update -- used for large matrices where recomputing the panel solve per tile pair would triple the flops.
-template <bool BATCH, bool SOLVED>
+// The 32x32x32 tile products run on waves 0-3 (one 16x16 block each); all 1024 threads move the tiles (one element each, every
+// load of the workgroup in flight before the first is consumed; a diagonal output tile fetches its panel tile twice rather than branch).
+template <bool BATCH>
 __global__ __launch_bounds__(1024) void k_chol_panel(cm_parg<BATCH> pa, int na_arg, int skip_own, int j, int large_min) {
   CM_SOLVE_PROLOGUE(2)
   {
@@ -421,22 +546,21 @@ __global__ __launch_bounds__(1024) void k_chol_panel(cm_parg<BATCH> pa, int na_a
   const int i = j + 1 + ip, l = j + 1 + lp;
   const bool mm = threadIdx.x < 256;                 // waves 0-3 own the four 16x16 blocks of the tile products
   const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE, rb = (wave >> 1) & 1, cb = wave & 1;
-  if (SOLVED) {
-    tile_load(Xi, Lf + (size_t)i * TS * ld + (size_t)j * TS, ld);
-    if (l != i) tile_load(Xl, Lf + (size_t)l * TS * ld + (size_t)j * TS, ld);
-  } else {
-    tile_load(Pi, A + (size_t)i * TS * ld + (size_t)j * TS, ld);
-    if (l != i) tile_load(Pl, A + (size_t)l * TS * ld + (size_t)j * TS, ld);
-    tile_load(Li, Dinv + (size_t)j * TS * TS, TS);
-  }
+  double rpi[1], rpl[1], rli[1];
+  tile_fetch<1024>(rpi, A + (size_t)i * TS * ld + (size_t)j * TS, ld);
+  tile_fetch<1024>(rpl, A + (size_t)l * TS * ld + (size_t)j * TS, ld);
+  tile_fetch<1024>(rli, Dinv + (size_t)j * TS * TS, TS);
   double* out = A + (size_t)i * TS * ld + (size_t)l * TS;
   double oprev[4] = {0.0, 0.0, 0.0, 0.0};
   if (mm) {                                          // the tile to be updated: requested now, consumed after the products
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) oprev[reg] = out[(size_t)BLK_ROW(rb, lane, reg) * ld + BLK_COL(cb, lane)];
   }
+  tile_put<1024>(Pi, rpi);
+  tile_put<1024>(Pl, rpl);
+  tile_put<1024>(Li, rli);
   __syncthreads();
-  if (mm && !SOLVED) {
+  if (mm) {
     cm_d4 c = {0.0, 0.0, 0.0, 0.0};
     c = blk_mfma_nt(c, Pi, Li, rb, cb, lane);          // X_i = P_i Linv^T
 #pragma unroll
@@ -449,7 +573,7 @@ __global__ __launch_bounds__(1024) void k_chol_panel(cm_parg<BATCH> pa, int na_a
     }
   }
   __syncthreads();
-  if (!SOLVED && l == j + 1) tile_store(Lf + (size_t)i * TS * ld + (size_t)j * TS, ld, Xi);
+  if (l == j + 1) tile_store(Lf + (size_t)i * TS * ld + (size_t)j * TS, ld, Xi);
   const bool diag = (i == j + 1 && l == j + 1);
   if (mm) {
     cm_d4 c = {0.0, 0.0, 0.0, 0.0};
@@ -470,17 +594,6 @@ __global__ __launch_bounds__(1024) void k_chol_panel(cm_parg<BATCH> pa, int na_a
   }
 }
 
-// 256-thread register staging of a 32x32 tile (4 elements per thread): lets the global loads of the NEXT tile pair fly while
-// the matrix cores work on the current one
-__device__ __forceinline__ void tile_fetch(double r[4], const double* __restrict__ src, int ld) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) { const int i = threadIdx.x + 256 * q; r[q] = src[(size_t)(i / TS) * ld + (i % TS)]; }
-}
-__device__ __forceinline__ void tile_put(double (*dst)[TP], const double r[4]) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) { const int i = threadIdx.x + 256 * q; dst[i / TS][i % TS] = r[q]; }
-}
-
 // ------------------------------------------------------------------------------------------------
 // X = L^-1 by recursive doubling.  Level with half-size b tiles, pair q = rows/cols [2qb, 2qb+2b):
 //    T   = L21 * X11        (stored in the unused strictly-upper tile (c, j2) of A)
@@ -492,17 +605,18 @@ __global__ __launch_bounds__(256) void k_inv_seed(cm_parg<BATCH> pa, int na_arg,
   if ((int)blockIdx.x >= nblk) return;
   const double* __restrict__ Dinv = p.Dinv;
   double* __restrict__ X = p.X;
-  __shared__ double Tm[TS][TP];
   const int d = blockIdx.x;
-  tile_load(Tm, Dinv + (size_t)d * TS * TS, TS);
-  __syncthreads();
-  tile_store(X + (size_t)d * TS * ld + (size_t)d * TS, ld, Tm);
+  double r[4];
+  tile_fetch(r, Dinv + (size_t)d * TS * TS, TS);
+  double* dst = X + (size_t)d * TS * ld + (size_t)d * TS;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { const int i = threadIdx.x + 256 * q; dst[(size_t)(i / TS) * ld + (i % TS)] = r[q]; }
 }
 
 template <bool BATCH>
 __global__ __launch_bounds__(256) void k_inv_T(cm_parg<BATCH> pa, int na_arg, int skip_own, int b) {
   int bx = (int)blockIdx.x, circ = 0;
-  if (BATCH) cm_xcd_remap(bx, circ);                 // the tile rows / columns the workgroups of a circuit share: one L2
+  if (BATCH) cm_xcd_remap(bx, circ, skip_own >> 8);  // the tile rows / columns the workgroups of a circuit share: one L2
   CM_SOLVE_PROLOGUE_AT(2, pa.get(circ))
   double* __restrict__ A = p.A;
   const double* __restrict__ Lf = p.Lf;
@@ -538,7 +652,7 @@ __global__ __launch_bounds__(256) void k_inv_T(cm_parg<BATCH> pa, int na_arg, in
 template <bool BATCH>
 __global__ __launch_bounds__(256) void k_inv_X21(cm_parg<BATCH> pa, int na_arg, int skip_own, int b) {
   int bx = (int)blockIdx.x, circ = 0;
-  if (BATCH) cm_xcd_remap(bx, circ);
+  if (BATCH) cm_xcd_remap(bx, circ, skip_own >> 8);
   CM_SOLVE_PROLOGUE_AT(2, pa.get(circ))
   const double* __restrict__ A = p.A;
   double* __restrict__ X = p.X;
@@ -701,46 +815,98 @@ int cm_solve_launch(cm_ctx* ctx, cm_set& s, int skip_mode, hipEvent_t fact_begin
   if (!any_tiled) { CM_HIP(hipGetLastError()); return CM_OK; }
   CM_LAUNCH_SET(k_fill_prior, s, (N + 255) / 256, 256, 0, st, na1, skip_le);
   if (nblk_max == 0) { CM_HIP(hipGetLastError()); return CM_OK; }
-  const int nblk = nblk_max;
-  const int ld = nblk * TS;                        // rows (the row stride is ld + CM_LD_PAD)
-  if ((size_t)ld * sizeof(double) > 150 * 1024) { cm_set_error("active set of %d neurons exceeds the LDS row accumulator", na_tiled); return CM_ERR_INVALID; }
-  if (s.B == 1) CM_TRY(cm_raise_lds(ctx, CM_LDS_BUILD_PREC, reinterpret_cast<const void*>(k_build_precision<false>), (size_t)ld * sizeof(double), 48 * 1024));
-  else CM_TRY(cm_raise_lds(ctx, CM_LDS_BUILD_PREC_B, reinterpret_cast<const void*>(k_build_precision<true>), (size_t)ld * sizeof(double), 48 * 1024));
-  CM_LAUNCH_SET(k_build_precision, s, ld, 64, (size_t)ld * sizeof(double), st, na1, skip_le);
-  // Cholesky
-  if (fact_begin) CM_HIP(hipEventRecord(fact_begin, st));
+  {
+    const size_t lds_bp = build_prec_lds(nblk_max * TS + CM_LD_PAD);
+    if (lds_bp > 150 * 1024) { cm_set_error("active set of %d neurons exceeds the LDS row accumulator", na_tiled); return CM_ERR_INVALID; }
+    if (s.B == 1) CM_TRY(cm_raise_lds(ctx, CM_LDS_BUILD_PREC, reinterpret_cast<const void*>(k_build_precision<false>), lds_bp, 48 * 1024));
+    else CM_TRY(cm_raise_lds(ctx, CM_LDS_BUILD_PREC_B, reinterpret_cast<const void*>(k_build_precision<true>), lds_bp, 48 * 1024));
+  }
   s.last_fact = true;
-  for (int c = 0; c < s.B; ++c) {                  // bookkeeping for cm_timings: launches and tiles of the trailing updates
+  for (int c = 0; c < s.B; ++c) {                  // bookkeeping for cm_timings: trailing-update passes and the tiles they read and rewrote
     const int nb = (s.na[c] + TS - 1) / TS;
     if (cm_solve_kind(s.na[c], s.ps[c]->small_cap, skip_mode >= 0) != 2) continue;
-    for (int j = 0; j + 1 < nb; ++j) { const long long t = nb - j - 1; s.fact_tile_updates += t * (t + 1) / 2; }
-  }
-  s.fact_launches += std::max(0, nblk - 1);
-  CM_LAUNCH_SET(k_chol_first, s, 1, 256, 0, st, na1, skip_le);
-  for (int j = 0; j + 1 < nblk; ++j) {
-    const int t = nblk - j - 1;
-    if (any_large) {                                 // large: solve the panel once, then the bandwidth-lean trailing update (block 0 factors the next diagonal tile)
-      CM_LAUNCH_SET(k_chol_trsm, s, t, 256, 0, st, na1, skip_le, j, large_min);
-      CM_LAUNCH_SET(k_chol_bulk, s, t * (t + 1) / 2, 256, 0, st, na1, skip_le, j, large_min);
+    if (nb > large_min) {
+      for (int j = 0; j + 1 < nb; j += 2) {          // panel pair: two panel solves, the thin column, the rank-64 update
+        const long long t = nb - j - 1;
+        s.fact_tile_updates += t + (t - 1) * t / 2;
+        s.fact_panel_tiles += (2 * t + 1) + t;                             // k_chol_trsm(j): t in, t out, L^-1; thin pass: the t solved panel tiles
+        if (t >= 2) s.fact_panel_tiles += (2 * (t - 1) + 1) + 2 * (t - 1);  // k_chol_trsm(j + 1); rank-64 pass: both panels' tiles
+      }
+    } else {
+      for (int j = 0; j + 1 < nb; ++j) {               // k_chol_panel: panel tiles in, solved tiles out, L^-1
+        const long long t = nb - j - 1;
+        s.fact_tile_updates += t * (t + 1) / 2;
+        s.fact_panel_tiles += 2 * t + 1;
+      }
     }
-    if (any_panel && j + 1 < nblk_panel) {           // small / medium: one launch per panel
-      const int tp = nblk_panel - j - 1;
-      CM_LAUNCH_SET_T(k_chol_panel, (false), s, tp * (tp + 1) / 2, 1024, 0, st, na1, skip_le, j, large_min);
+  }
+  // A batch is solved in groups of `solve_group` circuits, each group from its precision matrices to mu / beta before the next one
+  // starts: the matrices of a group (3 x 8 MB per circuit at N = 1000) then stay in the 256 MB Infinity Cache from one pass to the
+  // next, where the lock-step batch as a whole streams ~1 GB per pass through it.
+  const int G = (s.B > 1 && ctx->solve_group > 0) ? std::min(ctx->solve_group, s.B) : s.B;
+  const int xflags = skip_le | (ctx->xcd_mode << 8);
+  struct sub_t { int B; cm_pdev h0; const cm_pdev* d_arr; } g;
+  bool first_group = true;
+  for (int c0 = 0; c0 < s.B; c0 += G) {
+    g.B = std::min(G, s.B - c0);
+    if (s.B == 1) g.h0 = s.h0;
+    g.d_arr = s.d_arr ? s.d_arr + c0 : nullptr;
+    int nblk = 0, na_g = 0;
+    for (int c = c0; c < c0 + g.B; ++c) {
+      if (cm_solve_kind(s.na[c], s.ps[c]->small_cap, skip_mode >= 0) != 2) continue;
+      nblk = std::max(nblk, (s.na[c] + TS - 1) / TS); na_g = std::max(na_g, s.na[c]);
     }
+    if (nblk == 0) continue;
+    const bool large_g = nblk > large_min;
+    const int ld = nblk * TS;                        // rows (the row stride is ld + CM_LD_PAD)
+    const unsigned gy = s.B == 1 ? 1u : (unsigned)g.B;
+#define CM_LAUNCH_G(KERN, gridx, block, lds, ...)                                                                                           \
+    do {                                                                                                                                  \
+      if (s.B == 1) hipLaunchKernelGGL((KERN<false>), dim3(gridx), dim3(block), lds, st, cm_parg<false>{g.h0}, ##__VA_ARGS__);              \
+      else hipLaunchKernelGGL((KERN<true>), dim3(gridx, gy), dim3(block), lds, st, cm_parg<true>{g.d_arr}, ##__VA_ARGS__);                  \
+    } while (0)
+#define CM_LAUNCH_GT(KERN, TARG, gridx, block, lds, ...)                                                                                    \
+    do {                                                                                                                                  \
+      if (s.B == 1) hipLaunchKernelGGL((KERN<false, TARG>), dim3(gridx), dim3(block), lds, st, cm_parg<false>{g.h0}, ##__VA_ARGS__);        \
+      else hipLaunchKernelGGL((KERN<true, TARG>), dim3(gridx, gy), dim3(block), lds, st, cm_parg<true>{g.d_arr}, ##__VA_ARGS__);            \
+    } while (0)
+    CM_LAUNCH_G(k_build_precision, ld, 64, build_prec_lds(ld + CM_LD_PAD), na1, skip_le);
+    // Cholesky
+    if (first_group && fact_begin) CM_HIP(hipEventRecord(fact_begin, st));
+    first_group = false;
+    s.fact_launches += large_g ? nblk / 2 : std::max(0, nblk - 1);
+    CM_LAUNCH_G(k_chol_first, 1, 256, 0, na1, skip_le);
+    if (large_g) {                                     // panels in pairs: panel solve, thin column, panel solve, rank-64 trailing update
+      for (int j = 0; j + 1 < nblk; j += 2) {
+        const int t = nblk - j - 1;
+        CM_LAUNCH_G(k_chol_trsm, t, 256, 0, na1, skip_le, j, large_min);
+        CM_LAUNCH_GT(k_chol_bulk, false, t, 256, 0, na1, xflags, j, large_min);
+        if (t < 2) break;
+        CM_LAUNCH_G(k_chol_trsm, t - 1, 256, 0, na1, skip_le, j + 1, large_min);
+        CM_LAUNCH_GT(k_chol_bulk, true, (t - 1) * t / 2, 256, 0, na1, xflags, j, large_min);
+      }
+    } else {                                           // small / medium (one circuit): one launch per panel
+      for (int j = 0; j + 1 < nblk; ++j) {
+        const int tp = nblk - j - 1;
+        CM_LAUNCH_G(k_chol_panel, tp * (tp + 1) / 2, 1024, 0, na1, skip_le, j, large_min);
+      }
+    }
+    if (c0 + G >= s.B && fact_end) CM_HIP(hipEventRecord(fact_end, st));
+    // inverse of the factor (strictly-upper tiles of X are never read: no clearing needed)
+    CM_LAUNCH_G(k_inv_seed, nblk, 256, 0, na1, skip_le);
+    for (int b = 1; b < nblk; b *= 2) {
+      const int npairs = (nblk + 2 * b - 1) / (2 * b);
+      CM_LAUNCH_G(k_inv_T, npairs * b * b, 256, 0, na1, xflags, b);
+      CM_LAUNCH_G(k_inv_X21, npairs * b * b, 256, 0, na1, xflags, b);
+    }
+    // mu, beta
+    CM_LAUNCH_G(k_tri_matvec, (na_g + 3) / 4, 256, 0, na1, skip_le);
+    const int nchunks = (na_g + CM_COLCHUNK - 1) / CM_COLCHUNK, nbx = (ld + 63) / 64;
+    CM_LAUNCH_G(k_colsum_partial, nbx * nchunks, 64, 0, na1, skip_le, nbx);
+    CM_LAUNCH_G(k_colsum_final, (na_g + 255) / 256, 256, 0, na1, skip_le);
+#undef CM_LAUNCH_G
+#undef CM_LAUNCH_GT
   }
-  if (fact_end) CM_HIP(hipEventRecord(fact_end, st));
-  // inverse of the factor (strictly-upper tiles of X are never read: no clearing needed)
-  CM_LAUNCH_SET(k_inv_seed, s, nblk, 256, 0, st, na1, skip_le);
-  for (int b = 1; b < nblk; b *= 2) {
-    const int npairs = (nblk + 2 * b - 1) / (2 * b);
-    CM_LAUNCH_SET(k_inv_T, s, npairs * b * b, 256, 0, st, na1, skip_le, b);
-    CM_LAUNCH_SET(k_inv_X21, s, npairs * b * b, 256, 0, st, na1, skip_le, b);
-  }
-  // mu, beta
-  CM_LAUNCH_SET(k_tri_matvec, s, (na_tiled + 3) / 4, 256, 0, st, na1, skip_le);
-  const int nchunks = (na_tiled + CM_COLCHUNK - 1) / CM_COLCHUNK, nbx = (ld + 63) / 64;
-  CM_LAUNCH_SET(k_colsum_partial, s, nbx * nchunks, 64, 0, st, na1, skip_le, nbx);
-  CM_LAUNCH_SET(k_colsum_final, s, (na_tiled + 255) / 256, 256, 0, st, na1, skip_le);
   CM_HIP(hipGetLastError());
   return CM_OK;
 }

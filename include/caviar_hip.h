@@ -126,8 +126,11 @@ typedef struct cm_timings {
   int64_t sum_active;    /* sum over iterations of the active-set size                        */
   int64_t sum_seq_rows;  /* sum over iterations: rows in the sequential chain (mu != 0)        */
   int64_t sum_seq_records; /* sum over iterations: 32-byte records streamed by k_sweep_seq (rows + their trials) */
-  int64_t fact_launches; /* trailing-update launches (k_chol_panel, or k_chol_trsm + k_chol_bulk pairs) inside fact_ms               */
-  int64_t fact_tile_updates; /* 32 x 32 tiles those launches updated (sum of t (t + 1) / 2 over the panels, times the circuits that took part) */
+  int64_t fact_launches; /* trailing-update passes inside fact_ms: k_chol_panel launches (one panel each), or panel-pair steps
+                            (k_chol_trsm, thin k_chol_bulk, k_chol_trsm, rank-64 k_chol_bulk) for batches and above 48 tile rows   */
+  int64_t fact_tile_updates; /* 32 x 32 fp64 tiles those passes read AND rewrote (16 KB each), summed over the circuits that took part */
+  int64_t fact_panel_tiles;  /* further 8 KB tile transfers the same passes cannot avoid, each counted once per launch: panel tiles read,
+                                solved panel tiles written, the diagonal tile's inverse                                               */
 } cm_timings;
 
 const char* cm_last_error(void);
