@@ -567,16 +567,20 @@ __device__ __forceinline__ void cm_exptab_init(double* tab) {       // first 64 
   if (threadIdx.x < 64) tab[threadIdx.x] = cm_exp2_64[threadIdx.x];
 }
 __device__ __forceinline__ double cm_exp_tab(double x, const double* tab) {
-  const double kf = rint(x * 0x1.71547652b82fep+6);            // 64 / ln2
+  // k = rint(64 x / ln2) by the 1.5 * 2^52 shift: the sum's low word is k in two's complement, the difference is k as a double.
+  // (v_rndne_f64, v_cvt_i32_f64 and v_ldexp_f64 issue at a quarter of the fma rate: three of them cost more than the polynomial.)
+  const double y = fma(x, 0x1.71547652b82fep+6, 0x1.8p52);     // 64 / ln2
+  const double kf = y - 0x1.8p52;
+  const int k = __double2loint(y);
   double r = fma(kf, -0x1.62e42fefa3000p-7, x);                // ln2 / 64, 41 significant bits: the product is exact
   r = fma(kf, -0x1.3de6af278ece6p-48, r);
-  const int k = (int)kf;
   double q = fma(r, 1.0 / 120.0, 1.0 / 24.0);
   q = fma(r, q, 1.0 / 6.0);
   q = fma(r, q, 0.5);
   q = fma(r, q, 1.0);
   const double t = tab[k & 63];
-  return ldexp(fma(t, r * q, t), k >> 6);
+  const double v = fma(t, r * q, t);                           // in [1, 2): scaling by 2^(k >> 6) is an add to the exponent field
+  return __hiloint2double(__double2hiint(v) + ((k >> 6) << 20), __double2loint(v));
 }
 
 // saturating arguments (and non-finite ones): the literal form, out of line -- rare, and its logarithm and divisions would otherwise

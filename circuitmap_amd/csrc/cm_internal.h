@@ -103,7 +103,7 @@ struct cm_ctx {
   int mb_n = 0, mb_flag = 0;     // last values read from the mailbox (active-set size, not-SPD flag)
   bool use_mailbox = true;
   int solve_group = 0;           // circuits per group of the tiled solve of a batch (0: the whole batch in lock-step); CAVIAR_HIP_SOLVE_GROUP
-  int xcd_mode = 1;              // cm_xcd_remap mode of the bandwidth-bound solve kernels; CAVIAR_HIP_XCD_MODE
+  int xcd_mode = 3;              // cm_xcd_remap mode of the bandwidth-bound solve kernels; CAVIAR_HIP_XCD_MODE
   int num_cus = 256;
   void* h_stage = nullptr;        // pinned staging buffer (priors upload, fn_scan round trip), grown on demand
   size_t h_stage_bytes = 0;
@@ -245,16 +245,19 @@ template <> struct cm_parg<true> {
 // the tiles of one circuit land on all eight and every panel tile they share is fetched into eight L2s.  Remapped, circuit c runs
 // entirely on XCD c mod 8 (needs gridDim.y % 8 == 0, otherwise the plain map).  Placement is a speed heuristic only: any map is correct.
 // mode 0: plain; 1: the circuits of an XCD interleaved (workgroup by workgroup); 2: circuit-major (an XCD works through one of its
-// circuits after the other: the panel tiles in its L2 are those of one or two circuits instead of all of them).
+// circuits after the other: the panel tiles in its L2 are those of one or two circuits instead of all of them); 3: circuit-major after
+// the block 0 of every circuit.
 __device__ __forceinline__ void cm_xcd_remap(int& bx, int& c, int mode) {
-  const int nx = (int)gridDim.x, B = (int)gridDim.y;
+  // (32-bit unsigned arithmetic throughout: a 64-bit division is ~150 scalar instructions in front of the workgroup's first load)
+  const unsigned nx = gridDim.x, B = gridDim.y;
   bx = (int)blockIdx.x; c = (int)blockIdx.y;
-  if (B % 8 || mode == 0) return;
-  const long long L = (long long)blockIdx.y * nx + blockIdx.x;
-  const int xcd = (int)(L % 8), per = B / 8;
-  const long long q = L / 8;
-  if (mode == 1) { c = xcd + 8 * (int)(q % per); bx = (int)(q / per); }
-  else { c = xcd + 8 * (int)(q / nx); bx = (int)(q % nx); }
+  if ((B & 7u) || mode == 0) return;
+  const unsigned L = blockIdx.y * nx + blockIdx.x;
+  const unsigned xcd = L & 7u, per = B >> 3, q = L >> 3;
+  if (mode == 1) { const unsigned d = q / per; c = (int)(xcd + 8u * (q - d * per)); bx = (int)d; }
+  else if (mode == 2 || nx < 2u) { const unsigned d = q / nx; c = (int)(xcd + 8u * d); bx = (int)(q - d * nx); }
+  else if (q < per) { c = (int)(xcd + 8u * q); bx = 0; }   // mode 3: every circuit's block 0 (the serial diagonal-tile factorisation) first,
+  else { const unsigned q2 = q - per, d = q2 / (nx - 1u); c = (int)(xcd + 8u * d); bx = 1 + (int)(q2 - d * (nx - 1u)); }   // then circuit-major
 }
 #endif
 

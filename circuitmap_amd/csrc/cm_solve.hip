@@ -16,11 +16,12 @@
 // Every kernel of the tiled solve serves one circuit (descriptor by value, active-set size `na_arg` known to the host) or a lock-step
 // batch (blockIdx.y = circuit): then each circuit reads its own active-set size from HBM, derives its own tile count and leading
 // dimension, and leaves at once if the tiled solve is not the solver of that size (cm_solve_kind) or if the block lies outside
-// its (smaller) matrix -- the grid is sized for the largest matrix of the batch.
+// its (smaller) matrix -- the grid is sized for the largest matrix of the batch.  (The size arrives through a vector load; readfirstlane
+// tells the compiler it is uniform, so the tile addresses derived from it are scalar.)
 #define CM_SOLVE_PROLOGUE(KIND) CM_SOLVE_PROLOGUE_AT(KIND, pa.get())
 #define CM_SOLVE_PROLOGUE_AT(KIND, PDEV)                                          \
   const cm_pdev& p = PDEV;                                                        \
-  const int na = BATCH ? p.n_act[0] : na_arg;                                     \
+  const int na = BATCH ? __builtin_amdgcn_readfirstlane(p.n_act[0]) : na_arg;     \
   if (BATCH && cm_solve_kind(na, p.small_cap, (skip_own & 1) != 0) != (KIND)) return;   \
   const int nblk = (na + TS - 1) / TS, nrow = nblk * TS, ld = nrow + CM_LD_PAD;  \
   (void)nblk; (void)nrow; (void)ld;
@@ -173,6 +174,14 @@ __global__ __launch_bounds__(64) void k_build_precision(cm_parg<BATCH> pa, int n
 // ------------------------------------------------------------------------------------------------
 // 32x32 tile helpers (256 threads, each owns a 2x2 patch)
 // ------------------------------------------------------------------------------------------------
+// Global-memory accesses as uniform base + 32-bit byte offset of the lane (`global_load v, v_off, s[base]`): the offsets of a
+// lane are the same for every tile of a kernel, where generic 64-bit addresses cost two registers per access in flight.
+__device__ __forceinline__ double cm_gload(const double* base, unsigned byte_off) {
+  return *(const __attribute__((address_space(1))) double*)((const __attribute__((address_space(1))) char*)base + byte_off);
+}
+__device__ __forceinline__ void cm_gstore(double* base, unsigned byte_off, double v) {
+  *(__attribute__((address_space(1))) double*)((__attribute__((address_space(1))) char*)base + byte_off) = v;
+}
 // A tile always moves as "every load in flight, then consume": the 1024 / NT elements of a thread go through registers, and a
 // kernel that needs several tiles fetches all of them before the first tile_put (a load-and-store loop per tile costs one memory
 // round trip per element and tile -- measured: 8 dependent round trips in front of a 0.2 us tile product).  NT = threads of the
@@ -180,7 +189,10 @@ __global__ __launch_bounds__(64) void k_build_precision(cm_parg<BATCH> pa, int n
 template <int NT = 256>
 __device__ __forceinline__ void tile_fetch(double (&r)[TS * TS / NT], const double* __restrict__ src, int ld) {
 #pragma unroll
-  for (int q = 0; q < TS * TS / NT; ++q) { const int i = threadIdx.x + NT * q; r[q] = src[(size_t)(i / TS) * ld + (i % TS)]; }
+  for (int q = 0; q < TS * TS / NT; ++q) {
+    const unsigned i = threadIdx.x + NT * q;
+    r[q] = cm_gload(src, ((i / TS) * (unsigned)ld + (i % TS)) * (unsigned)sizeof(double));    // (a tile spans < 32 rows: far below 4 GB)
+  }
 }
 template <int NT = 256>
 __device__ __forceinline__ void tile_put(double (*dst)[TP], const double (&r)[TS * TS / NT]) {
@@ -466,11 +478,12 @@ __global__ __launch_bounds__(256) void k_chol_bulk(cm_parg<BATCH> pa, int na_arg
   const double* __restrict__ Lf = p.Lf;
   double* __restrict__ Dinv = p.Dinv;
   int* __restrict__ flag = p.n_act + 1;
-  __shared__ double Sm[WIDE ? 4 : 3][TS][TP];
+  __shared__ double Sm[2][TS][TP];                   // two tiles (17 KB): LDS is not what limits the workgroups per CU
   const int t = bx;                                  // id 0 is the pass's diagonal tile
   int i, l;
   if (WIDE) {                                        // linear id -> (i, l), j + 2 <= l <= i
     int ip = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    ip = __builtin_amdgcn_readfirstlane(ip);        // (the square root runs on the vector unit; the result is uniform: scalar addresses below)
     while ((ip + 1) * (ip + 2) / 2 <= t) ++ip;
     while (ip * (ip + 1) / 2 > t) --ip;
     i = j + 2 + ip; l = j + 2 + (t - ip * (ip + 1) / 2);
@@ -479,7 +492,7 @@ __global__ __launch_bounds__(256) void k_chol_bulk(cm_parg<BATCH> pa, int na_arg
   double* out = A + (size_t)i * TS * ld + (size_t)l * TS;
   double o[4];
 #pragma unroll
-  for (int reg = 0; reg < 4; ++reg) o[reg] = out[(size_t)BLK_ROW(rb, lane, reg) * ld + BLK_COL(cb, lane)];
+  for (int reg = 0; reg < 4; ++reg) o[reg] = cm_gload(out, ((unsigned)BLK_ROW(rb, lane, reg) * (unsigned)ld + (unsigned)BLK_COL(cb, lane)) * 8u);
   // every load of the workgroup is issued before the first one is consumed (one memory round trip, not one per tile): the panel
   // tiles go through registers, and a diagonal output tile (l == i) simply fetches its panel tile twice -- no branch between loads
   double rx[WIDE ? 4 : 2][4];
@@ -489,8 +502,8 @@ __global__ __launch_bounds__(256) void k_chol_bulk(cm_parg<BATCH> pa, int na_arg
     tile_fetch(rx[2], Lf + (size_t)i * TS * ld + (size_t)(j + 1) * TS, ld);
     tile_fetch(rx[3], Lf + (size_t)l * TS * ld + (size_t)(j + 1) * TS, ld);
   }
-#pragma unroll
-  for (int q = 0; q < (WIDE ? 4 : 2); ++q) tile_put(Sm[q], rx[q]);
+  tile_put(Sm[0], rx[0]);
+  tile_put(Sm[1], rx[1]);
   __syncthreads();
   {
     cm_d4 c = {0.0, 0.0, 0.0, 0.0};
@@ -498,15 +511,19 @@ __global__ __launch_bounds__(256) void k_chol_bulk(cm_parg<BATCH> pa, int na_arg
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) o[reg] -= c[reg];
   }
-  if (WIDE) {
+  if (WIDE) {                                        // the second panel's tiles (waiting in registers) take the same two LDS tiles
+    __syncthreads();
+    tile_put(Sm[0], rx[2]);
+    tile_put(Sm[1], rx[3]);
+    __syncthreads();
     cm_d4 c = {0.0, 0.0, 0.0, 0.0};
-    c = blk_mfma_nt(c, Sm[2], Sm[3], rb, cb, lane);
+    c = blk_mfma_nt(c, Sm[0], Sm[1], rb, cb, lane);
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) o[reg] -= c[reg];
   }
   if (t != 0) {
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) out[(size_t)BLK_ROW(rb, lane, reg) * ld + BLK_COL(cb, lane)] = o[reg];
+    for (int reg = 0; reg < 4; ++reg) cm_gstore(out, ((unsigned)BLK_ROW(rb, lane, reg) * (unsigned)ld + (unsigned)BLK_COL(cb, lane)) * 8u, o[reg]);
     return;
   }
   // block 0: the updated diagonal tile never goes back to HBM -- factor it here, next to the bulk of the update, and

@@ -177,6 +177,8 @@ __device__ __forceinline__ double row_gate_small(bool valid, int g, double est, 
   return (iso >= thresh && total >= min_count) ? 1.0 : 0.0;                // caviar.py:220
 }
 
+// LEAN: the caller guarantees P <= 8 (no literal pool walk in the instantiation: its registers would set the wavefronts per SIMD)
+template <bool LEAN = false>
 __device__ __forceinline__ double row_gate(bool valid, int g, double est, int P, double thresh, double min_count, double* scr) {
   switch (P) {
     case 1: return row_gate_small<1>(valid, g, est, P, thresh, min_count);
@@ -185,7 +187,7 @@ __device__ __forceinline__ double row_gate(bool valid, int g, double est, int P,
     case 4: return row_gate_small<4>(valid, g, est, P, thresh, min_count);
     default: break;
   }
-  if (P <= 8) return row_gate_small<0>(valid, g, est, P, thresh, min_count);
+  if (LEAN || P <= 8) return row_gate_small<0>(valid, g, est, P, thresh, min_count);
   // many powers: rates and pool stacks in the wave's LDS scratch (3 x 64 doubles), literal pool walk
   const double total = cm_wave_sum(est);
   double* sr = scr;
@@ -301,12 +303,14 @@ __device__ __forceinline__ double row_gate_half(bool valid, int g, double est, i
 
 // rows with mu == 0: arg = sigma * beta^2 does not involve R and mu * lam contributes nothing to R, so these rows are
 // independent of the chain and of each other -> one wave each over the whole chip
+// LEAN: the caller guarantees rows of at most 64 trials and at most 8 powers
+template <bool LEAN = false>
 __device__ __forceinline__ void sweep_indep_row(const SweepArgs& a, int n, int lane, double* scr) {
   if (a.mu[n] != 0.0) return;
   const double sig = a.scal[CM_S_SHAPE] / a.scal[CM_S_RATE];
   const double thresh = a.msrmp + a.scal[CM_S_SPONT_RATE];
   const int beg = a.row_ptr[n], len = a.row_ptr[n + 1] - beg;
-  if (len > CM_WAVE) { sweep_step_long<false>(a, n, (double*)nullptr, sig, thresh, lane, scr); return; }
+  if (!LEAN && len > CM_WAVE) { sweep_step_long<false>(a, n, (double*)nullptr, sig, thresh, lane, scr); return; }
   const bool valid = lane < len;
   const double be = a.beta[n];
   const double arg = sig * (be * be);                // mu == 0: caviar.py:205-206 reduces to sigma * beta^2
@@ -318,20 +322,21 @@ __device__ __forceinline__ void sweep_indep_row(const SweepArgs& a, int n, int l
     if (a.mask[a.col[e]]) est = cm_sigmoid(a.mcE[(size_t)n * CM_MAX_VALS + g] - 0.5 * arg);
   }
   double pava = 1.0;
-  if (a.gated) pava = row_gate(valid, g, est, a.V - 1, thresh, a.min_count, scr);
+  if (a.gated) pava = row_gate<LEAN>(valid, g, est, a.V - 1, thresh, a.min_count, scr);
   if (valid) a.lam[beg + lane] = est * pava;
 }
 
 // Rows n0 and n0 + 1 in one wavefront (batches: half the wavefronts of the one-row-per-wave launch, whose duration is set by their
 // number).  Falls back to one row after the other when a row is longer than 32 trials or there are more than 8 powers.
+template <bool LEAN>
 __device__ __forceinline__ void sweep_indep_pair(const SweepArgs& a, int n0, int N, int lane, double* scr) {
   const int sub = lane & 31, n = n0 + (lane >> 5);
   const bool row_on = n < N && a.mu[n < N ? n : 0] == 0.0;
   const int beg = row_on ? a.row_ptr[n] : 0, len = row_on ? a.row_ptr[n + 1] - beg : 0;
   const int P = a.V - 1;
-  if (__any(len > 32) || P > 8) {
-    sweep_indep_row(a, n0, lane, scr);
-    if (n0 + 1 < N) sweep_indep_row(a, n0 + 1, lane, scr);
+  if (__any(len > 32) || (!LEAN && P > 8)) {
+    sweep_indep_row<LEAN>(a, n0, lane, scr);
+    if (n0 + 1 < N) sweep_indep_row<LEAN>(a, n0 + 1, lane, scr);
     return;
   }
   const double sig = a.scal[CM_S_SHAPE] / a.scal[CM_S_RATE];
@@ -438,7 +443,10 @@ __device__ __forceinline__ void seq_scan_body(const int* __restrict__ order, con
 //   blocks [nbI, nbI+nbC)  R_k = sum_n mu_n lam_nk per trial (= lam.T @ mu), 16 lanes per trial.  Rows handled by the
 //                          first role have mu == 0, so whichever of their old/new lam is read contributes exactly 0.
 //   last block             ordered compaction of the mu != 0 rows + record offsets + chunk table of the chain
-template <bool BATCH>
+// LEAN (batches whose rows hold at most 64 trials and whose stimuli take at most 8 powers -- the host checks): the instantiation has
+// neither the long-row walk nor the literal pool walk, so that its register count allows two workgroups per CU; the launch is
+// latency-bound and as long as its wavefronts take turns.
+template <bool BATCH, bool LEAN>
 __global__ __launch_bounds__(1024) void k_presweep(cm_parg<BATCH> pa, int it, int gated, double msrmp, double min_count, int nbI, int nbC,
                                                     int roles, int gran) {
   __shared__ double scr_all[16][3 * CM_MAX_VALS];
@@ -452,10 +460,10 @@ __global__ __launch_bounds__(1024) void k_presweep(cm_parg<BATCH> pa, int it, in
     if (!(roles & 1)) return;
     if (BATCH) {                                     // two rows per wavefront: the launch is as long as its number of wavefronts
       const int n0 = 2 * (b * 16 + threadIdx.x / CM_WAVE);
-      if (n0 < N) sweep_indep_pair(a, n0, N, threadIdx.x % CM_WAVE, scr_all[threadIdx.x / CM_WAVE]);
+      if (n0 < N) sweep_indep_pair<LEAN>(a, n0, N, threadIdx.x % CM_WAVE, scr_all[threadIdx.x / CM_WAVE]);
     } else {
       const int n = b * 16 + threadIdx.x / CM_WAVE;
-      if (n < N) sweep_indep_row(a, n, threadIdx.x % CM_WAVE, scr_all[threadIdx.x / CM_WAVE]);
+      if (n < N) sweep_indep_row<LEAN>(a, n, threadIdx.x % CM_WAVE, scr_all[threadIdx.x / CM_WAVE]);
     }
   } else if (b < nbI + nbC) {
     if (!(roles & 2)) return;
@@ -772,8 +780,13 @@ int cm_launch_sweep(cm_ctx* ctx, cm_set& s, int it, const cm_options* o, hipEven
   const int gran = cap - CM_WAVE - 1;                              // chunking granule: a chunk spans < gran + 65 <= cap records
   const size_t lds_par = (par == 2) ? (size_t)p->K * 9 + 16 : (size_t)p->K * 12;
   static const bool split = getenv("CAVIAR_HIP_SPLIT_PRESWEEP") != nullptr;     // diagnostic: one launch per role (profiling only)
-  for (int pass = 0; pass < (split ? 3 : 1); ++pass)
-    CM_LAUNCH_SET(k_presweep, s, nbI + nbC + 1, 1024, 0, st, (table_it < 0 ? it : table_it), gated, msrmp, min_count, nbI, nbC, split ? (1 << pass) : 7, gran);
+  int v_max = 0;
+  for (const cm_problem* q : s.ps) v_max = std::max(v_max, q->V);
+  const bool lean = s.max_row_len_max <= CM_WAVE && v_max - 1 <= 8;     // every circuit of the set: rows of at most 64 trials, at most 8 powers
+  for (int pass = 0; pass < (split ? 3 : 1); ++pass) {
+    if (lean) CM_LAUNCH_SET_T(k_presweep, (true), s, nbI + nbC + 1, 1024, 0, st, (table_it < 0 ? it : table_it), gated, msrmp, min_count, nbI, nbC, split ? (1 << pass) : 7, gran);
+    else CM_LAUNCH_SET_T(k_presweep, (false), s, nbI + nbC + 1, 1024, 0, st, (table_it < 0 ? it : table_it), gated, msrmp, min_count, nbI, nbC, split ? (1 << pass) : 7, gran);
+  }
   static const bool bad_ticket = getenv("CAVIAR_HIP_TEST_BAD_TICKET") != nullptr;   // test hook: exercises the bounded wait + error report of the ticketed chain
   CM_LAUNCH_SET(k_seq_pack, s, (N + 3) / 4, 256, 0, st, gated, msrmp, min_count, par ? (bad_ticket ? 2 : 1) : 0);
   if (mid) CM_HIP(hipEventRecord(mid, st));
