@@ -673,15 +673,18 @@ __device__ __forceinline__ void mc_logit_body(int n, int lane, double mean0, dou
 #pragma unroll
     for (int q = 0; q < 2; ++q) { const int item = q * CM_WAVE + lane; if (item < tail_items) mc[item] = vt[q]; }
     __builtin_amdgcn_wave_barrier();
+    double tot = 0.0;                                // lane k: the sum of power k -- ONE division serves the (up to four) means
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (k < P) {
         double a = acc[k];
         if (lane < Tn) a += mc[k * Tn + lane];
         a = cm_wave_sum(a);
-        if (lane == 0) mcE[(size_t)n * CM_MAX_VALS + gi[k]] = a / (double)S;
+        if (lane == k) tot = a;
       }
     }
+    const double mean = tot / (double)S;
+    if (lane < P) mcE[(size_t)n * CM_MAX_VALS + (lane == 0 ? gi[0] : (lane == 1 ? gi[1] : (lane == 2 ? gi[2] : gi[3])))] = mean;
     __builtin_amdgcn_wave_barrier();                 // (a caller's next row rewrites the scratch)
     return;
   }

@@ -416,7 +416,7 @@ inline void cm_threefry2x32(uint32_t k0, uint32_t k1, uint32_t& x0, uint32_t& x1
 // lower bounds of that table (valid because the table never decreases), so the common launch pays no lock and no runtime call.
 enum cm_lds_slot { CM_LDS_ITER = 0 /* 7 x 2 x 2 template variants */, CM_LDS_SOLVE_SMALL = 28, CM_LDS_SWEEP_PAR, CM_LDS_SWEEP_PAR2, CM_LDS_SWEEP_SEQ,
                    CM_LDS_NWD, CM_LDS_SIM_SORT, CM_LDS_BUILD_PREC, CM_LDS_SWEEP_PAR_B, CM_LDS_SWEEP_PAR2_B, CM_LDS_SWEEP_SEQ_B,
-                   CM_LDS_SOLVE_SMALL_B, CM_LDS_BUILD_PREC_B, CM_LDS_SLOTS = 48 };
+                   CM_LDS_SOLVE_SMALL_B, CM_LDS_BUILD_PREC_B, CM_LDS_ITER_LISTED /* 7 SEG variants */, CM_LDS_SLOTS = 48 };
 // table update: returns the value hipFuncSetAttribute has to be called with (0 = the value in force already covers `bytes`)
 size_t cm_lds_table_request(int device, const void* fn, size_t bytes, size_t floor_bytes);
 inline int cm_raise_lds(cm_ctx* ctx, int slot, const void* fn, size_t bytes, size_t floor_bytes) {

@@ -65,7 +65,10 @@ __global__ __launch_bounds__(256) void k_mc_dead(cm_parg<BATCH> pa, IterDyn a) {
   }
 }
 
-template <bool BATCH, int SEG, bool FULLMC>
+// LISTED (batches, steady state): the per-neuron role walks the list of rows with lam != 0 in a stride loop -- its own instantiation,
+// because the loop costs the role ~100 registers (232 against 126: two wavefronts per SIMD instead of three), which the early
+// iterations, where every row is alive and the role is one wavefront per row, must not pay.
+template <bool BATCH, int SEG, bool FULLMC, bool LISTED = false>
 __global__ __launch_bounds__(CM_ITER_THREADS) void k_iter_mid(cm_parg<BATCH> pa, IterDyn a) {
   extern __shared__ double sm[];
   const cm_pdev& p = pa.get();
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(CM_ITER_THREADS) void k_iter_mid(cm_parg<BATCH> pa,
   __syncthreads();                                   // (before any wavefront leaves)
   const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE;
   const int N = p.N;
-  if (BATCH && a.skip_dead) {
+  if (BATCH && LISTED) {
     // Batches: the rows with lam != 0 -- listed by k_stats, a few percent of the rows in the steady state -- are spread over a grid
     // sized for them (the host knows the previous active-set sizes; the stride loop covers whatever else turns up), instead of
     // N wavefronts per circuit of which most leave at once: that launch was bound by the number of wavefronts, not by its work.
@@ -164,10 +167,16 @@ static int launch_iter2(cm_ctx* ctx, cm_set& s, const IterDyn& a0, size_t lds, i
     CM_HIP(hipGetLastError());
     return CM_OK;
   }
-  CM_LAUNCH_SET_T(k_iter_mid, (SEG, FULLMC), s, blocks, threads, lds, ctx->stream, a0);
-  if (a0.skip_dead) {                                // batches: the all-zero rows, in their lean kernel (after the mailboxes are on their way)
+  if (a0.skip_dead && !FULLMC && s.B > 1) {
+    // batches, steady state: the rows with lam != 0 from the list; the all-zero rows in their lean kernel (after the mailboxes are on their way)
+    const int slot_l = CM_LDS_ITER_LISTED + (31 - __builtin_clz((unsigned)SEG));
+    CM_TRY(cm_raise_lds(ctx, slot_l, reinterpret_cast<const void*>(k_iter_mid<true, SEG, false, true>), lds, 48 * 1024));
+    hipLaunchKernelGGL((k_iter_mid<true, SEG, false, true>), dim3(blocks, s.B), dim3(threads), lds, ctx->stream, cm_parg<true>{s.d_arr}, a0);
     if (between) CM_HIP(hipEventRecord(between, ctx->stream));
     CM_LAUNCH_SET(k_mc_dead, s, (s.lead->N + 3) / 4, 256, 4 * lds_waves, ctx->stream, a0);
+  } else {
+    CM_LAUNCH_SET_T(k_iter_mid, (SEG, FULLMC), s, blocks, threads, lds, ctx->stream, a0);
+    if (between) CM_HIP(hipEventRecord(between, ctx->stream));
   }
   CM_HIP(hipGetLastError());
   return CM_OK;
@@ -191,7 +200,9 @@ int cm_launch_iter_mid(cm_ctx* ctx, cm_set& s, int it, int iters, int S, int rng
   a.do_phi = do_phi; a.do_mc = nxt < iters; a.S = S;
   a.nx = a.do_mc ? nxt : 0;
   a.explicit_rng = rng_mode == CM_RNG_EXPLICIT;
-  a.skip_dead = (s.B > 1 && do_phi && it >= 0 && roles == 3) ? 1 : 0;
+  // batches: listed rows + k_mc_dead once fewer than half of the rows were active when the iteration began (any choice is correct: the
+  // plain form handles all-zero rows itself); the early iterations, with every row alive, run one wavefront per row
+  a.skip_dead = (s.B > 1 && do_phi && it >= 0 && roles == 3 && 2 * s.na_max < N) ? 1 : 0;
   a.dbg = (ctx->dbg_block0 && it >= 0 && it < 64) ? ctx->dbg_block0 + 8 * it : nullptr;
   const int threads = s.B == 1 ? CM_ITER_THREADS : CM_ITER_THREADS_BATCH;
   const int waves = threads / CM_WAVE;
