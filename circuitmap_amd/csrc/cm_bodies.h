@@ -37,6 +37,44 @@ __device__ __forceinline__ void cm_col_dot16(int t, int K, const double* __restr
   if (ok && j == 0) { R[k] = s; if (colany) colany[k] = (uint8_t)(any != 0); }
 }
 
+// Two trial columns per 16-lane segment (batches: the launch is latency-bound at full occupancy -- half the wavefronts, each with the
+// three load levels of both of its columns in flight together).  Column k and column k + ceil(K / 2); every column is summed exactly
+// as cm_col_dot16 sums it (same entries per lane, same segment reduction, same 0.0 + x), so R is bit for bit the same.
+__device__ __forceinline__ void cm_col_dot16x2(int t, int K, const double* __restrict__ mu, const double* __restrict__ lam,
+                                               const int* __restrict__ col_ptr, const int* __restrict__ csc_row,
+                                               const int* __restrict__ csc_pos, double orth, double* __restrict__ R,
+                                               uint8_t* __restrict__ colany) {
+  const int Kh = (K + 1) >> 1;
+  const int k0 = t >> 4, j = t & 15, k1 = k0 + Kh;
+  const bool ok0 = k0 < Kh, ok1 = ok0 && k1 < K;
+  const int beg0 = ok0 ? col_ptr[k0] : 0, end0 = ok0 ? col_ptr[k0 + 1] : 0;
+  const int beg1 = ok1 ? col_ptr[k1] : 0, end1 = ok1 ? col_ptr[k1 + 1] : 0;
+  if (end0 - beg0 > 16 || end1 - beg1 > 16) {        // (uniform over the segment) long columns: one after the other, the plain way
+    cm_col_dot16(t, Kh, mu, lam, col_ptr, csc_row, csc_pos, orth, R, colany);
+    if (ok1) cm_col_dot16((k1 << 4) | j, K, mu, lam, col_ptr, csc_row, csc_pos, orth, R, colany);   // (DPP sources lie inside the segment)
+    return;
+  }
+  const int ce0 = beg0 + j, ce1 = beg1 + j;
+  const bool in0 = ce0 < end0, in1 = ce1 < end1;
+  const int p0 = in0 ? csc_pos[ce0] : 0, r0 = in0 ? csc_row[ce0] : 0;
+  const int p1 = in1 ? csc_pos[ce1] : 0, r1 = in1 ? csc_row[ce1] : 0;
+  const double l0 = in0 ? lam[p0] : 0.0, m0 = in0 ? mu[r0] : 0.0;
+  const double l1 = in1 ? lam[p1] : 0.0, m1 = in1 ? mu[r1] : 0.0;
+  double s0 = 0.0, s1 = 0.0;
+  if (end0 > beg0) s0 += cm_seg_sum<16>(in0 ? m0 * l0 : 0.0);          // (a column without entries adds nothing: s stays +0.0)
+  if (end1 > beg1) s1 += cm_seg_sum<16>(in1 ? m1 * l1 : 0.0);
+  int any0 = in0 && (l0 >= orth), any1 = in1 && (l1 >= orth);
+  int any = any0 | (any1 << 1);
+  any |= __builtin_amdgcn_update_dpp(0, any, CM_DPP_XOR1, 0xf, 0xf, true);
+  any |= __builtin_amdgcn_update_dpp(0, any, CM_DPP_XOR2, 0xf, 0xf, true);
+  any |= __builtin_amdgcn_update_dpp(0, any, CM_DPP_HALF_MIRROR, 0xf, 0xf, true);
+  any |= __builtin_amdgcn_update_dpp(0, any, CM_DPP_MIRROR, 0xf, 0xf, true);
+  if (j == 0) {
+    if (ok0) { R[k0] = s0; if (colany) colany[k0] = (uint8_t)((any & 1) != 0); }
+    if (ok1) { R[k1] = s1; if (colany) colany[k1] = (uint8_t)((any & 2) != 0); }
+  }
+}
+
 // The single-workgroup phases run on the first CM_POST_THREADS threads of their workgroup, whatever its launch size (the other
 // waves have retired; a retired wave no longer counts at s_barrier): the strided partial sums and their combination order are
 // then the same in every kernel that embeds these bodies, so a batched launch reproduces the single-circuit results bit for bit.

@@ -47,49 +47,66 @@ __global__ __launch_bounds__(256) void k_stats(cm_parg<BATCH> pa, int nbR, doubl
   const cm_pdev& p = pa.get();
   const double* __restrict__ lam = p.lam;
   if (BATCH && (int)blockIdx.x < nbR) {
-    // batches: two rows per wavefront (one per 32-lane half) when both fit -- the launch is as long as its number of wavefronts;
-    // cm_half_sum gives each row bitwise the sums cm_wave_sum gives it alone in a wavefront
-    const int lane = threadIdx.x % CM_WAVE, sub = lane & 31;
-    const int n0 = 2 * (int)((blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE), N = p.N;
-    if (n0 >= N) return;
+    // batches: FOUR rows per wavefront -- two pairs (one row per 32-lane half), the load levels of both pairs in flight together: the
+    // launch is latency-bound at full occupancy, so its duration is its number of wavefronts times the length of their dependent
+    // load chain; cm_half_sum gives each row bitwise the sums cm_wave_sum gives it alone in a wavefront
+    const int lane = threadIdx.x % CM_WAVE, sub = lane & 31, N = p.N;
+    const int npairs = (N + 1) >> 1, W = (npairs + 1) >> 1;          // W wavefronts: pair w and pair w + W
+    const int w = (int)((blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE);
+    if (w >= W) return;
     const int* __restrict__ row_ptr = p.row_ptr;
-    const int n = n0 + (lane >> 5);
-    const bool row_on = n < N;
-    const int beg = row_on ? row_ptr[n] : 0, len = row_on ? row_ptr[n + 1] - beg : 0;
-    if (!__any(len > 32)) {
+    const int nA = 2 * w + (lane >> 5), nB = 2 * (w + W) + (lane >> 5);
+    const bool onA = nA < N, onB = nB < N;
+    const int begA = onA ? row_ptr[nA] : 0, lenA = onA ? row_ptr[nA + 1] - begA : 0;
+    const int begB = onB ? row_ptr[nB] : 0, lenB = onB ? row_ptr[nB + 1] - begB : 0;
+    if (!__any(lenA > 32 || lenB > 32)) {
       const int* __restrict__ col = p.col;
       const double* __restrict__ y = p.y;
-      double s1 = 0.0, s2 = 0.0, sy = 0.0, d = 0.0;
-      bool nz = false;
-      if (sub < len) {
-        const double l = lam[beg + sub];
-        s1 += l;
-        s2 = fma(l, l, s2);
-        sy = fma(y[col[beg + sub]], l, sy);
-        d = fma(l, 1.0 - l, d);
-        nz = l != 0.0;
-      }
-      s1 = cm_half_sum(s1); s2 = cm_half_sum(s2); sy = cm_half_sum(sy); d = cm_half_sum(d);
-      const bool any = ((__ballot(nz) >> (lane & 32)) & 0xFFFFFFFFull) != 0ull;
-      if (sub == 0 && row_on) {
-        double* __restrict__ rs = p.rs;
-        rs[(size_t)n * 4 + 0] = s1;
-        rs[(size_t)n * 4 + 1] = s2;
-        rs[(size_t)n * 4 + 2] = sy;
-        rs[(size_t)n * 4 + 3] = any ? d : -1.0;
-        if (any) { const int pos = atomicAdd(&p.alive[0], 1); if (pos < N) p.alive[1 + pos] = n; }
+      const bool inA = sub < lenA, inB = sub < lenB;
+      const double lA = inA ? lam[begA + sub] : 0.0, lB = inB ? lam[begB + sub] : 0.0;
+      const int cA = inA ? col[begA + sub] : 0, cB = inB ? col[begB + sub] : 0;
+      const double yA = inA ? y[cA] : 0.0, yB = inB ? y[cB] : 0.0;
+      double* __restrict__ rs = p.rs;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const bool in = h ? inB : inA, row_on = h ? onB : onA;
+        const double l = h ? lB : lA, yy = h ? yB : yA;
+        const int n = h ? nB : nA;
+        double s1 = 0.0, s2 = 0.0, sy = 0.0, d = 0.0;
+        bool nz = false;
+        if (in) {
+          s1 += l;
+          s2 = fma(l, l, s2);
+          sy = fma(yy, l, sy);
+          d = fma(l, 1.0 - l, d);
+          nz = l != 0.0;
+        }
+        s1 = cm_half_sum(s1); s2 = cm_half_sum(s2); sy = cm_half_sum(sy); d = cm_half_sum(d);
+        const bool any = ((__ballot(nz) >> (lane & 32)) & 0xFFFFFFFFull) != 0ull;
+        if (sub == 0 && row_on) {
+          rs[(size_t)n * 4 + 0] = s1;
+          rs[(size_t)n * 4 + 1] = s2;
+          rs[(size_t)n * 4 + 2] = sy;
+          rs[(size_t)n * 4 + 3] = any ? d : -1.0;
+          if (any) { const int pos = atomicAdd(&p.alive[0], 1); if (pos < N) p.alive[1 + pos] = n; }
+        }
       }
       return;
     }
-    // a long row in the pair: one row after the other, a full wavefront each
-    for (int r = 0; r < 2 && n0 + r < N; ++r) stats_row<BATCH>(p, lam, n0 + r, lane);
+    // a long row among the four: one row after the other, a full wavefront each
+    for (int r = 0; r < 2; ++r) {
+      if (2 * w + r < N) stats_row<BATCH>(p, lam, 2 * w + r, lane);
+      if (2 * (w + W) + r < N) stats_row<BATCH>(p, lam, 2 * (w + W) + r, lane);
+    }
   } else if ((int)blockIdx.x < nbR) {
     const int n = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE;
     const int lane = threadIdx.x % CM_WAVE;
     if (n >= p.N) return;
     stats_row<BATCH>(p, lam, n, lane);
   } else {
-    cm_col_dot16(((int)blockIdx.x - nbR) * blockDim.x + threadIdx.x, p.K, p.mu, lam, p.col_ptr, p.csc_row, p.csc_pos, orth, p.R, p.colany);
+    const int t = ((int)blockIdx.x - nbR) * blockDim.x + threadIdx.x;
+    if (BATCH) cm_col_dot16x2(t, p.K, p.mu, lam, p.col_ptr, p.csc_row, p.csc_pos, orth, p.R, p.colany);
+    else cm_col_dot16(t, p.K, p.mu, lam, p.col_ptr, p.csc_row, p.csc_pos, orth, p.R, p.colany);
   }
 }
 
@@ -104,8 +121,8 @@ __global__ __launch_bounds__(CM_POST_THREADS) void k_post_single(cm_parg<false> 
 // Row + column statistics of the current lam.
 int cm_launch_stats(cm_ctx* ctx, cm_set& s, double spont_orthogonality) {
   const cm_problem* p = s.lead;
-  const int nbR = s.B > 1 ? (p->N + 7) / 8 : (p->N + 3) / 4;        // one wave per row (batches: per two rows)
-  const int nbC = (p->K * 16 + 255) / 256;                           // 16 lanes per trial column
+  const int nbR = s.B > 1 ? (p->N + 15) / 16 : (p->N + 3) / 4;      // one wave per row (batches: per four rows)
+  const int nbC = ((s.B > 1 ? (p->K + 1) / 2 : p->K) * 16 + 255) / 256;   // 16 lanes per trial column (batches: per two columns)
   CM_LAUNCH_SET(k_stats, s, nbR + nbC, 256, 0, ctx->stream, nbR, spont_orthogonality);
   CM_HIP(hipGetLastError());
   return CM_OK;
