@@ -6,11 +6,11 @@
 `--workload nwd` benchmarks the upstream NWD demixer forward pass instead (its own metric, traces/s; see bench_nwd).
 
 A "step" is one pass of the hot path over one batch of synthetic input: B independent circuits of the BASELINE shape (N=1000
-neurons, K=2000 trials, T=900 samples; default B = 64) fitted per GPU as ONE lock-step batch -- `iters` (50) CAVIaR iterations each plus
+neurons, K=2000 trials, T=900 samples; default B = 128) fitted per GPU as ONE lock-step batch -- `iters` (50) CAVIaR iterations each plus
 the false-negative scan and final phi update (reference circuitmap/optimise/caviar.py:79-98) -- through the C ABI's
 cm_caviar_run_batch: the circuit is the outer grid dimension of every kernel launch.  (`--batch-streams G` splits the B circuits into G
 lock-step batches on G contexts / HIP streams, one host thread each, so that the serial phases of one overlap the wide phases of the
-others: ~15 % more throughput, reported by the default run as the extra leg `interleaved_streams`; the headline keeps one batch per
+others: ~13 % more throughput, reported by the default run as the extra leg `interleaved_streams`; the headline keeps one batch per
 step so that every per-kernel figure -- HIP events, rocprof, PMC -- describes a kernel that had the GPU to itself.)  A single fit is a latency chain (N sequential
 Gauss-Seidel steps, 31 dependent Cholesky panels, 10 dependent Newton steps) that occupies a few percent of an MI355X; the batch is
 what fills it, and it is the reference's own scale-out unit (independent circuits, one process each:
@@ -635,17 +635,20 @@ def _kb(fetch_kb, write_kb):
 
 
 PMC_TRAFFIC = {
-    # one lock-step batch of 64 circuits (profiles/r02_a_cfg3_B64_pmc_{fetch,write}_size.csv), KB per launch: k_iter_mid 8150.6 fetched /
-    # 1922.8 written; k_mc_dead 9950.4 / 4667.9; per panel k_chol_bulk 52160.3 + k_chol_trsm 5158.8 fetched, 71869.5 + 6817.1 written
-    ("cfg3", 64, "k_iter_mid"): _kb(8150.6, 1922.8),
-    ("cfg3", 64, "k_mc_dead"): _kb(9950.4, 4667.9),
-    ("cfg3", 64, "k_chol_bulk+k_chol_trsm"): _kb(52160.3 + 5158.8, 71869.5 + 6817.1),
+    # one lock-step batch of 128 circuits (profiles/r02_a_cfg3_B128_pmc_{fetch,write}_size.csv), KB per launch:
+    #   k_iter_mid   16 plain launches 35736.6 fetched / 12885.2 written, 184 listed launches 10794.0 / 3301.6 -> average 12789.4 / 4068.3
+    #   k_mc_dead    14536.5 / 9828.0
+    #   per panel-pair step (260 steps: 236 rank-64 k_chol_bulk 85738.1 / 142648.7, 260 thin k_chol_bulk 13553.5 / 13385.0,
+    #   496 k_chol_trsm 10241.6 / 13546.1):  110915.1 fetched, 168707.9 written
+    ("cfg3", 128, "k_iter_mid"): _kb(12789.4, 4068.3),
+    ("cfg3", 128, "k_mc_dead"): _kb(14536.5, 9828.0),
+    ("cfg3", 128, "k_chol_bulk+k_chol_trsm"): _kb(110915.1, 168707.9),
     # one circuit at a time (profiles/r02_b_cfg3_B1_pmc_{fetch,write}_size.csv)
-    ("cfg3", 1, "k_iter_mid"): _kb(1801.6, 101.8),
-    ("cfg3", 1, "k_chol_panel"): _kb(1108.9, 1317.2),
+    ("cfg3", 1, "k_iter_mid"): _kb(1877.0, 101.8),
+    ("cfg3", 1, "k_chol_panel"): _kb(1110.3, 1317.2),
     ("cfg3", 1, "k_sweep_par"): _kb(57.7, 13.0),
 }
-PMC_SOURCE = {k: ("profiles/r02_a_cfg3_B64_pmc_fetch_size.csv + _pmc_write_size.csv" if k[1] == 64 else "profiles/r02_b_cfg3_B1_pmc_fetch_size.csv + _pmc_write_size.csv")
+PMC_SOURCE = {k: ("profiles/r02_a_cfg3_B128_pmc_fetch_size.csv + _pmc_write_size.csv" if k[1] == 128 else "profiles/r02_b_cfg3_B1_pmc_fetch_size.csv + _pmc_write_size.csv")
               + " (separate --pmc passes; traffic = 2 x FETCH_SIZE + WRITE_SIZE per the MI355X guide's gfx950 correction)" for k in PMC_TRAFFIC}
 
 

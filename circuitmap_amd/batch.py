@@ -97,7 +97,7 @@ def _fit_lockstep(circuits, mine, priors, fit_options, device_id, max_group, str
     return [out[ci] for ci in mine]
 
 
-def fit_batch(circuits, priors=None, fit_options=None, fit_fn=None, device=None, group=None, circuits_per_launch=16, streams=4):
+def fit_batch(circuits, priors=None, fit_options=None, fit_fn=None, device=None, group=None, circuits_per_launch=32, streams=4):
     """Fit a list of circuits [(psc K x T, stim N x K), ...] across the ranks of the default process group.
 
     Rank 0's `priors` / `fit_options` are broadcast to every rank.  Returns, on rank 0, a list of result dicts

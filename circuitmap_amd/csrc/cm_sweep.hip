@@ -326,77 +326,42 @@ __device__ __forceinline__ void sweep_indep_row(const SweepArgs& a, int n, int l
   if (valid) a.lam[beg + lane] = est * pava;
 }
 
-// FOUR rows in one wavefront (batches): two pairs -- pair w (rows 2 w, 2 w + 1) and pair w + W -- one row per 32-lane half, the load
-// levels of both pairs in flight together.  The launch is latency-bound at full occupancy: its duration is the number of wavefronts
-// times the length of their dependent load chain (mu -> row_ptr -> grp, col -> mask, logit), so each wavefront carries two chains.
-// Per row the operations and their order are those of the one-row path (row_gate_half: bit for bit row_gate_small).  Falls back to
-// one row after the other when a row is longer than 32 trials or there are more than 8 powers.
+// Rows n0 and n0 + 1 in one wavefront (batches: half the wavefronts of the one-row-per-wave launch, whose duration is set by their
+// number).  Falls back to one row after the other when a row is longer than 32 trials or there are more than 8 powers.
 template <bool LEAN>
-__device__ __forceinline__ void sweep_indep_quad(const SweepArgs& a, int w, int W, int N, int lane, double* scr) {
-  const int sub = lane & 31, hi = lane >> 5;
-  const int n_[2] = {2 * w + hi, 2 * (w + W) + hi};
-  bool on_[2];
-  int beg_[2], len_[2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int n = n_[h];
-    on_[h] = n < N && a.mu[n < N ? n : 0] == 0.0;
-  }
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int n = n_[h] < N ? n_[h] : 0;
-    const int b0 = a.row_ptr[n], b1 = a.row_ptr[n + 1];              // (loaded whether or not the row takes part: no branch between loads)
-    beg_[h] = on_[h] ? b0 : 0; len_[h] = on_[h] ? b1 - b0 : 0;
-  }
+__device__ __forceinline__ void sweep_indep_pair(const SweepArgs& a, int n0, int N, int lane, double* scr) {
+  const int sub = lane & 31, n = n0 + (lane >> 5);
+  const bool row_on = n < N && a.mu[n < N ? n : 0] == 0.0;
+  const int beg = row_on ? a.row_ptr[n] : 0, len = row_on ? a.row_ptr[n + 1] - beg : 0;
   const int P = a.V - 1;
-  if (__any(len_[0] > 32 || len_[1] > 32) || (!LEAN && P > 8)) {
-    for (int r = 0; r < 2; ++r) {
-      if (2 * w + r < N) sweep_indep_row<LEAN>(a, 2 * w + r, lane, scr);
-      if (2 * (w + W) + r < N) sweep_indep_row<LEAN>(a, 2 * (w + W) + r, lane, scr);
-    }
+  if (__any(len > 32) || (!LEAN && P > 8)) {
+    sweep_indep_row<LEAN>(a, n0, lane, scr);
+    if (n0 + 1 < N) sweep_indep_row<LEAN>(a, n0 + 1, lane, scr);
     return;
   }
   const double sig = a.scal[CM_S_SHAPE] / a.scal[CM_S_RATE];
   const double thresh = a.msrmp + a.scal[CM_S_SPONT_RATE];
-  bool valid_[2];
-  int g_[2], k_[2];
-  double be_[2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    valid_[h] = sub < len_[h];
-    const int e = beg_[h] + sub;
-    g_[h] = valid_[h] ? (int)a.grp[e] : -1;
-    k_[h] = valid_[h] ? a.col[e] : 0;
-    be_[h] = valid_[h] ? a.beta[n_[h]] : 0.0;
+  const bool valid = sub < len;
+  int g = -1;
+  double est = 0.0;
+  if (valid) {
+    const double be = a.beta[n];
+    const double arg = sig * (be * be);              // mu == 0: caviar.py:205-206 reduces to sigma * beta^2
+    const int e = beg + sub;
+    g = a.grp[e];
+    if (a.mask[a.col[e]]) est = cm_sigmoid(a.mcE[(size_t)n * CM_MAX_VALS + g] - 0.5 * arg);
   }
-  uint8_t mk_[2];
-  double lg_[2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    mk_[h] = valid_[h] ? a.mask[k_[h]] : (uint8_t)0;
-    lg_[h] = valid_[h] ? a.mcE[(size_t)n_[h] * CM_MAX_VALS + g_[h]] : 0.0;
-  }
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const bool valid = valid_[h];
-    const int g = g_[h];
-    double est = 0.0;
-    if (valid) {
-      const double arg = sig * (be_[h] * be_[h]);    // mu == 0: caviar.py:205-206 reduces to sigma * beta^2
-      if (mk_[h]) est = cm_sigmoid(lg_[h] - 0.5 * arg);
+  double pava = 1.0;
+  if (a.gated) {
+    switch (P) {
+      case 1: pava = row_gate_half<1>(valid, g, est, P, thresh, a.min_count); break;
+      case 2: pava = row_gate_half<2>(valid, g, est, P, thresh, a.min_count); break;
+      case 3: pava = row_gate_half<3>(valid, g, est, P, thresh, a.min_count); break;
+      case 4: pava = row_gate_half<4>(valid, g, est, P, thresh, a.min_count); break;
+      default: pava = row_gate_half<0>(valid, g, est, P, thresh, a.min_count); break;
     }
-    double pava = 1.0;
-    if (a.gated) {
-      switch (P) {
-        case 1: pava = row_gate_half<1>(valid, g, est, P, thresh, a.min_count); break;
-        case 2: pava = row_gate_half<2>(valid, g, est, P, thresh, a.min_count); break;
-        case 3: pava = row_gate_half<3>(valid, g, est, P, thresh, a.min_count); break;
-        case 4: pava = row_gate_half<4>(valid, g, est, P, thresh, a.min_count); break;
-        default: pava = row_gate_half<0>(valid, g, est, P, thresh, a.min_count); break;
-      }
-    }
-    if (valid) a.lam[beg_[h] + sub] = est * pava;
   }
+  if (valid) a.lam[beg + sub] = est * pava;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -493,9 +458,9 @@ __global__ __launch_bounds__(1024) void k_presweep(cm_parg<BATCH> pa, int it, in
   const int b = blockIdx.x;
   if (b < nbI) {
     if (!(roles & 1)) return;
-    if (BATCH) {                                     // four rows per wavefront: the launch is as long as its number of wavefronts
-      const int npairs = (N + 1) >> 1, W = (npairs + 1) >> 1, w = b * 16 + threadIdx.x / CM_WAVE;
-      if (w < W) sweep_indep_quad<LEAN>(a, w, W, N, threadIdx.x % CM_WAVE, scr_all[threadIdx.x / CM_WAVE]);
+    if (BATCH) {                                     // two rows per wavefront (four were measured slower here, unlike in k_stats)
+      const int n0 = 2 * (b * 16 + threadIdx.x / CM_WAVE);
+      if (n0 < N) sweep_indep_pair<LEAN>(a, n0, N, threadIdx.x % CM_WAVE, scr_all[threadIdx.x / CM_WAVE]);
     } else {
       const int n = b * 16 + threadIdx.x / CM_WAVE;
       if (n < N) sweep_indep_row<LEAN>(a, n, threadIdx.x % CM_WAVE, scr_all[threadIdx.x / CM_WAVE]);
@@ -806,7 +771,7 @@ int cm_launch_sweep(cm_ctx* ctx, cm_set& s, int it, const cm_options* o, hipEven
   const double msrmp = o->msrmp, min_count = o->minimum_spike_count;
   hipStream_t st = ctx->stream;
   const int N = p->N;
-  const int nbI = s.B > 1 ? (N + 63) / 64 : (N + 15) / 16;          // 16 rows per block (batches: 64, four rows per wavefront)
+  const int nbI = s.B > 1 ? (N + 31) / 32 : (N + 15) / 16;          // 16 rows per block (batches: 32, two rows per wavefront)
   const int nbC = ((s.B > 1 ? (p->K + 1) / 2 : p->K) * 16 + 1023) / 1024;   // 16 lanes per trial column (batches: per two columns)
   // multi-wave chain when the ticket encoding fits (see k_sweep_par): variant 1 = 1024-record buffers + 32-bit tickets,
   // variant 2 = 512-record buffers + 8-bit tickets (larger K); 0 = single-consumer kernel.  Whichever kernel walks the chain,

@@ -15,7 +15,7 @@
  * one ctx must be serialised by the caller, distinct ctxs are independent (one process per GPU, or several ctxs
  * per process).
  *
- * Limits (also in INTEGRATION.md): N >= 2; at most CM_MAX_VALS distinct stimulus values; active sets of more than 19 200 neurons
+ * Limits (also in INTEGRATION.md): N >= 2; at most CM_MAX_VALS distinct stimulus values; active sets of more than 18 000 neurons
  * are refused (CM_ERR_INVALID: the row accumulator of the precision build lives in LDS); at most 1024 circuits per lock-step group.
  */
 #ifndef CAVIAR_HIP_H
