@@ -68,6 +68,35 @@ def test_unit_phases_vs_golden(ctx):
     assert rel_err(rb, g["rec_beta"]) < 1e-14
 
 
+@pytest.mark.parametrize("case", ["long_rows", "wide_trials", "short"])
+def test_block_update_mu_precision_build_paths(ctx, case):
+    """cm_k_block_update_mu vs the oracle on shapes that drive the precision-matrix build (k_build_precision) through its other paths:
+    rows of more than 64 trials (several 64-trial chunks per row), trials with more than 256 targeted neurons (a trial walked directly
+    instead of staged: CM_BP_ITEMS), and the plain case; every active set is well above the in-LDS solver's cap, so the tiled
+    factorisation (panel family, 2-5 tile rows) runs behind the build.  Some rows are all zero (they leave the active set)."""
+    from circuitmap_amd import _lib
+    from oracle import caviar_oracle as co
+    N, K, H = {"long_rows": (96, 700, 12), "wide_trials": (400, 60, 300), "short": (150, 300, 6)}[case]
+    rng = np.random.default_rng({"long_rows": 3, "wide_trials": 4, "short": 5}[case])
+    stim = np.zeros((N, K))
+    for k in range(K):
+        stim[rng.choice(N, H, replace=False), k] = rng.choice([40.0, 55.0, 70.0])
+    lam = rng.random((N, K)) * (stim > 0) * (rng.random((N, K)) < 0.7)
+    lam[rng.choice(N, N // 6, replace=False)] = 0.0                   # rows outside the active set
+    y = rng.gamma(2.0, 1.0, K)
+    pri = default_priors(N)
+    mu0 = _lib.f64(rng.normal(0.0, 0.1, N))
+    if case == "long_rows":
+        assert (stim > 0).sum(axis=1).max() > 64
+    if case == "wide_trials":
+        assert (stim > 0).sum(axis=0).max() > 256
+    mu, beta = np.empty(N), np.empty(N)
+    _lib.check(ctx.lib.cm_k_block_update_mu(ctx.handle, N, K, _lib.dptr(_lib.f64(stim)), _lib.dptr(_lib.f64(lam)), _lib.dptr(_lib.f64(y)), 3.0, 0.7,
+                                            _lib.dptr(mu0), _lib.dptr(pri["beta"]), _lib.dptr(mu), _lib.dptr(beta)))
+    rmu, rbeta = co.block_update_mu(y, lam, 3.0, 0.7, mu0, pri["beta"], literal=True)
+    assert rel_err(mu, rmu) < 1e-9 and rel_err(beta, rbeta) < 1e-9, (case, rel_err(mu, rmu), rel_err(beta, rbeta))
+
+
 @pytest.mark.parametrize("name", ["caviar_tiny", "caviar_tiny_noscan", "caviar_cfg1"])
 def test_caviar_vs_golden(name):
     """Seeded threefry stream generated ON DEVICE; outputs and all per-iteration histories vs the reference-source fixtures."""
@@ -368,6 +397,34 @@ def test_run_batch_bit_identical_to_serial(ctx):
             np.testing.assert_array_equal(a[9 + i], b[9 + i])
         q1.close()
     for q in probs:
+        q.close()
+
+
+@pytest.mark.parametrize("case", ["wide_trials", "long_rows", "odd_counts"])
+def test_run_batch_rare_shapes_bit_identical(ctx, case):
+    """Lock-step batches on shapes that take the batch kernels' other paths -- trials with more than 16 targeted neurons (the
+    two-columns-per-segment column sums fall back to one column after the other), rows of more than 32 / 64 trials (rows one per
+    wavefront; the general pre-sweep instantiation), odd N and K (unpaired last row / column) -- every circuit bit-identical to its
+    own single fit, and the single fit within 1e-7 of the literal oracle."""
+    from circuitmap_amd.optimise.caviar import Problem, run_batch
+    from circuitmap_amd.optimise import caviar
+    from oracle import caviar_oracle as co
+    cfg = {"wide_trials": dict(N=60, K=90, T=40, H=20, powers=[40.0, 55.0, 70.0]),
+           "long_rows": dict(N=30, K=400, T=40, H=6, powers=[40.0, 55.0, 70.0]),
+           "odd_counts": dict(N=41, K=121, T=40, H=5, powers=[45.0, 65.0])}[case]
+    opts = dict(iters=8, num_mc_samples=9, seed=5, minimum_spike_count=2, msrmp=0.15)
+    probs_in = [_edge_problem(21 + i, **cfg) for i in range(3)]
+    pri = default_priors(cfg["N"])
+    singles = [caviar(psc, stim, *prior_args(pri), **opts) for psc, stim in probs_in]
+    ref = co.caviar(probs_in[0][0], probs_in[0][1], *prior_args(pri), literal=True, **opts)
+    for i, nm in enumerate(OUT_NAMES):
+        assert rel_err(singles[0][i], ref[i]) < 1e-7, (case, nm)
+    probs = [Problem(ctx, psc, stim) for psc, stim in probs_in]
+    run_batch(probs, pri, **opts)
+    for q, single in zip(probs, singles):
+        got = q.fetch()
+        for i, nm in enumerate(OUT_NAMES):
+            np.testing.assert_array_equal(np.asarray(got[i], dtype=float), np.asarray(single[i], dtype=float), err_msg="%s %s" % (case, nm))
         q.close()
 
 
