@@ -184,7 +184,10 @@ static int launch_iter2(cm_ctx* ctx, cm_set& s, const IterDyn& a0, size_t lds, i
 template <int SEG>
 static int launch_iter(cm_ctx* ctx, cm_set& s, const IterDyn& a, size_t lds, int blocks, int threads, hipEvent_t between) {
   const size_t lw = 2 * (size_t)a.S * sizeof(double);
-  return a.it < 0 ? launch_iter2<SEG, true>(ctx, s, a, lds, blocks, lw, threads, between) : launch_iter2<SEG, false>(ctx, s, a, lds, blocks, lw, threads, between);
+  // state init (it < 0): the quantile of every draw is needed (phi is the prior: c is not small).  One circuit: the instantiation with
+  // the quantile function inlined (shortest path).  Batches: the out-of-line call -- inlined it makes the kernel a 424-register one-
+  // wavefront-per-SIMD launch, and at 128 circuits that launch is throughput-bound.  Same function, same arguments: same logits.
+  return (a.it < 0 && s.B == 1) ? launch_iter2<SEG, true>(ctx, s, a, lds, blocks, lw, threads, between) : launch_iter2<SEG, false>(ctx, s, a, lds, blocks, lw, threads, between);
 }
 
 // it = -1: state init (no sigma / phi; MC logit and solve for iteration 0).  Otherwise the middle of iteration `it`.
