@@ -102,9 +102,11 @@ __global__ __launch_bounds__(CM_ITER_THREADS) void k_iter_mid(cm_parg<BATCH> pa,
     // Batches: the rows with lam != 0 -- listed by k_stats, a few percent of the rows in the steady state -- are spread over a grid
     // sized for them (the host knows the previous active-set sizes; the stride loop covers whatever else turns up), instead of
     // N wavefronts per circuit of which most leave at once: that launch was bound by the number of wavefronts, not by its work.
-    const int total = ((int)gridDim.x - 2) * (int)(blockDim.x / CM_WAVE);
+    // (no loop here: one listed row per wavefront -- a stride loop around this body costs the kernel 100 registers, i.e. two
+    // wavefronts per SIMD instead of four; rows beyond the grid, if the list ever outgrows it, are taken by k_iter_overflow)
     const int n_alive = min(p.alive[0], N);
-    for (int i = ((int)blockIdx.x - 2) * (int)(blockDim.x / CM_WAVE) + wave; i < n_alive; i += total) {
+    const int i = ((int)blockIdx.x - 2) * (int)(blockDim.x / CM_WAVE) + wave;
+    if (i < n_alive) {
       const int n = p.alive[1 + i];
       double pc[4];
       phi_body<SEG>(n, lane, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, pc);
@@ -142,6 +144,32 @@ __global__ __launch_bounds__(CM_ITER_THREADS) void k_iter_mid(cm_parg<BATCH> pa,
   }
 }
 
+// Listed rows beyond the grid of the LISTED k_iter_mid (`first` = the rows that launch covers): a stride loop over whatever is left.
+// The list holds the rows with lam != 0 after the sweep; the host sizes the main grid for twice the active set the iteration began
+// with, so this kernel normally finds nothing and leaves at once -- it exists so that no growth of the list can lose a row.
+template <int SEG>
+__global__ __launch_bounds__(CM_ITER_THREADS) void k_iter_overflow(cm_parg<true> pa, IterDyn a, int first) {
+  extern __shared__ double sm[];
+  __shared__ double etab[64];
+  cm_exptab_init(etab);
+  __syncthreads();
+  const cm_pdev& p = pa.get();
+  const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE;
+  const int N = p.N;
+  const int n_alive = min(p.alive[0], N);
+  const int total = (int)gridDim.x * (int)(blockDim.x / CM_WAVE);
+  for (int i = first + (int)blockIdx.x * (int)(blockDim.x / CM_WAVE) + wave; i < n_alive; i += total) {
+    const int n = p.alive[1 + i];
+    double pc[4];
+    phi_body<SEG>(n, lane, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, pc);
+    if (a.do_mc) {
+      const int m = p.inv_all[(size_t)a.nx * N + n];
+      const size_t off = ((size_t)a.nx * N + m) * 2 * a.S;
+      mc_logit_body<false>(n, lane, pc[0], pc[1], pc[2], pc[3], (const double2*)p.wtab + off, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE, etab);
+    }
+  }
+}
+
 // largest active set the fused kernel may solve in LDS (0 = never): A (n x (n+1)) + staged rows must fit beside the statics
 int cm_small_cap(const cm_problem* p) {
   int cap = 0;
@@ -172,6 +200,11 @@ static int launch_iter2(cm_ctx* ctx, cm_set& s, const IterDyn& a0, size_t lds, i
     const int slot_l = CM_LDS_ITER_LISTED + (31 - __builtin_clz((unsigned)SEG));
     CM_TRY(cm_raise_lds(ctx, slot_l, reinterpret_cast<const void*>(k_iter_mid<true, SEG, false, true>), lds, 48 * 1024));
     hipLaunchKernelGGL((k_iter_mid<true, SEG, false, true>), dim3(blocks, s.B), dim3(threads), lds, ctx->stream, cm_parg<true>{s.d_arr}, a0);
+    {
+      const int waves = threads / CM_WAVE, covered = (blocks - 2) * waves;
+      if (covered < s.lead->N)                           // (a grid that already covers N rows cannot be outgrown)
+        hipLaunchKernelGGL((k_iter_overflow<SEG>), dim3(8, s.B), dim3(threads), (size_t)waves * lds_waves, ctx->stream, cm_parg<true>{s.d_arr}, a0, covered);
+    }
     if (between) CM_HIP(hipEventRecord(between, ctx->stream));
     CM_LAUNCH_SET(k_mc_dead, s, (s.lead->N + 3) / 4, 256, 4 * lds_waves, ctx->stream, a0);
   } else {
@@ -217,7 +250,8 @@ int cm_launch_iter_mid(cm_ctx* ctx, cm_set& s, int it, int iters, int S, int rng
   if (a.skip_dead) {
     // rows with lam != 0 after this sweep: at most a few more than the active set the iteration started with (rows can be revived);
     // twice that, at least 64 wavefronts per circuit -- the kernel's stride loop takes care of the rest
-    const int want = std::min(N, std::max(64, 2 * s.na_max));
+    int want = std::min(N, std::max(64, 2 * s.na_max));
+    if (const char* e = getenv("CAVIAR_HIP_TEST_LISTED_ROWS")) want = std::min(N, std::max(1, atoi(e)));   // test hook: a grid the list outgrows (k_iter_overflow)
     blocks = 2 + (want + waves - 1) / waves;
   }
   const int V = p->V;

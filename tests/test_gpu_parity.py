@@ -428,6 +428,25 @@ def test_run_batch_rare_shapes_bit_identical(ctx, case):
         q.close()
 
 
+def test_run_batch_listed_rows_overflow(ctx, monkeypatch):
+    """The steady-state per-neuron role of a batch covers the rows with lam != 0 with a grid sized from the previous active set; rows
+    beyond it are taken by k_iter_overflow.  CAVIAR_HIP_TEST_LISTED_ROWS=4 makes the grid four rows, so nearly every listed row goes
+    through the overflow kernel: results must still equal the single fits bit for bit."""
+    from circuitmap_amd.optimise.caviar import Problem, run_batch
+    from circuitmap_amd.optimise import caviar
+    sims = [_sim_case(120, 400, 900 + i)[0] for i in range(3)]
+    pri = default_priors(120)
+    opts = dict(iters=14, seed=3)
+    singles = [caviar(sim["psc"], sim["stim_matrix"], *prior_args(pri), **opts) for sim in sims]
+    monkeypatch.setenv("CAVIAR_HIP_TEST_LISTED_ROWS", "4")
+    probs = [Problem(ctx, sim["psc"], sim["stim_matrix"]) for sim in sims]
+    run_batch(probs, pri, **opts)
+    monkeypatch.delenv("CAVIAR_HIP_TEST_LISTED_ROWS")
+    for q, single in zip(probs, singles):
+        _assert_same_fit(q.fetch(), single, "listed-rows overflow")
+        q.close()
+
+
 def test_run_batch_explicit_streams_and_argument_checks(ctx):
     """A batch fed explicit RNG streams (shared by its circuits) equals the seeded batch bit for bit; argument errors come back as
     error codes (problems of another context, a problem listed twice, NULL priors), not as faults."""
