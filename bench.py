@@ -636,15 +636,15 @@ def _kb(fetch_kb, write_kb):
 
 PMC_TRAFFIC = {
     # one lock-step batch of 128 circuits (profiles/r02_a_cfg3_B128_pmc_{fetch,write}_size.csv), KB per launch:
-    #   k_iter_mid   16 plain launches 35736.6 fetched / 12885.2 written, 184 listed launches 10794.0 / 3301.6 -> average 12789.4 / 4068.3
-    #   k_mc_dead    14536.5 / 9828.0
-    #   per panel-pair step (260 steps: 236 rank-64 k_chol_bulk 85738.1 / 142648.7, 260 thin k_chol_bulk 13553.5 / 13385.0,
-    #   496 k_chol_trsm 10241.6 / 13546.1):  110915.1 fetched, 168707.9 written
-    ("cfg3", 128, "k_iter_mid"): _kb(12789.4, 4068.3),
-    ("cfg3", 128, "k_mc_dead"): _kb(14536.5, 9828.0),
-    ("cfg3", 128, "k_chol_bulk+k_chol_trsm"): _kb(110915.1, 168707.9),
+    #   k_iter_mid   20 plain launches (state init + early iterations) 30529.4 fetched / 11308.4 written, 184 listed launches 10869.9 / 3336.4 -> average 12797.3 / 4118.0
+    #   k_mc_dead    14540.8 / 9828.0
+    #   per panel-pair step (260 steps: 236 rank-64 k_chol_bulk 85738.6 / 142648.7, 260 thin k_chol_bulk 13559.3 / 13385.0,
+    #   496 k_chol_trsm 10241.1 / 13546.1):  110920.4 fetched, 168707.9 written
+    ("cfg3", 128, "k_iter_mid"): _kb(12797.3, 4118.0),
+    ("cfg3", 128, "k_mc_dead"): _kb(14540.8, 9828.0),
+    ("cfg3", 128, "k_chol_bulk+k_chol_trsm"): _kb(110920.4, 168707.9),
     # one circuit at a time (profiles/r02_b_cfg3_B1_pmc_{fetch,write}_size.csv)
-    ("cfg3", 1, "k_iter_mid"): _kb(1877.0, 101.8),
+    ("cfg3", 1, "k_iter_mid"): _kb(1881.0, 101.8),
     ("cfg3", 1, "k_chol_panel"): _kb(1110.3, 1317.2),
     ("cfg3", 1, "k_sweep_par"): _kb(57.7, 13.0),
 }
