@@ -165,7 +165,7 @@ extern "C" int cm_problem_destroy(cm_problem* p) {
   hipSetDevice(p->ctx->device);
   hipStreamSynchronize(p->ctx->stream);
   void* ptrs[] = {p->y, p->ss, p->sum_y, p->vals, p->row_ptr, p->col, p->grp, p->rowcnt, p->col_ptr, p->csc_row, p->csc_pos,
-                  p->mask, p->slab, p->pslab, p->phi, p->phi_cov, p->phi_dead,
+                  p->mask, p->ye, p->me, p->slab, p->pslab, p->phi, p->phi_cov, p->phi_dead,
                   p->R, p->colany, p->mcE, p->rs, p->act_idx, p->act_inv, p->n_act, p->alive, p->orders_all, p->orders_tmp, p->inv_all, p->wtab,
                   p->keys, p->uexp, p->A, p->X, p->Lf, p->Dinv, p->rhs, p->seq_n, p->seq_off, p->seq_pos, p->chunk_first,
                   p->seq_meta, p->packed};
@@ -204,7 +204,8 @@ extern "C" int cm_problem_create(cm_ctx* ctx, int32_t N, int32_t K, int32_t T, c
 
   p->ld = ((N + CM_TILE - 1) / CM_TILE) * CM_TILE;
   const size_t ld = p->ld;
-  if ((rc = dmalloc(&p->mask, K)) || (rc = dmalloc(&p->slab, 2 * (size_t)N + K + (size_t)p->nnz)) ||
+  if ((rc = dmalloc(&p->mask, K)) || (rc = dmalloc(&p->ye, (size_t)p->nnz + 1)) || (rc = dmalloc(&p->me, (size_t)p->nnz + 1)) ||
+      (rc = dmalloc(&p->slab, 2 * (size_t)N + K + (size_t)p->nnz)) ||
       (rc = dmalloc(&p->pslab, 8 * (size_t)N + CM_S_COUNT)) || (rc = dmalloc(&p->phi, 2 * (size_t)N)) ||
       (rc = dmalloc(&p->phi_cov, 4 * (size_t)N)) || (rc = dmalloc(&p->phi_dead, 8 * (size_t)N)) || (rc = dmalloc(&p->R, K)) ||
       (rc = dmalloc(&p->colany, K)) || (rc = dmalloc(&p->mcE, (size_t)N * CM_MAX_VALS)) ||
@@ -257,7 +258,7 @@ void cm_fill_pdev(const cm_problem* p, const cm_problem* r, int* mailbox, cm_pde
   memset(d, 0, sizeof(*d));
   d->N = p->N; d->K = p->K; d->V = p->V; d->small_cap = p->small_cap; d->max_row_len = p->max_row_len; d->ld_alloc = p->ld; d->nnz = p->nnz;
   d->y = p->y; d->ss = p->ss; d->sum_y = p->sum_y; d->vals = p->vals; d->row_ptr = p->row_ptr; d->col = p->col; d->grp = p->grp;
-  d->rowcnt = p->rowcnt; d->col_ptr = p->col_ptr; d->csc_row = p->csc_row; d->csc_pos = p->csc_pos; d->mask = p->mask; d->colany = p->colany;
+  d->rowcnt = p->rowcnt; d->col_ptr = p->col_ptr; d->csc_row = p->csc_row; d->csc_pos = p->csc_pos; d->mask = p->mask; d->colany = p->colany; d->ye = p->ye; d->me = p->me;
   d->lam = p->lam; d->mu = p->mu; d->beta = p->beta; d->phi = p->phi; d->phi_cov = p->phi_cov; d->scal = p->scal; d->R = p->R; d->z = p->z;
   d->mcE = p->mcE; d->rs = p->rs; d->phi_dead = p->phi_dead; d->phi_cov_dead = p->phi_dead ? p->phi_dead + 2 * (size_t)p->N : nullptr; d->phi_c_dead = p->phi_dead ? p->phi_dead + 6 * (size_t)p->N : nullptr; d->pslab = p->pslab; d->mu_prior = p->mu_prior; d->beta_prior = p->beta_prior; d->phi_prior = p->phi_prior;
   d->phi_cov_prior = p->phi_cov_prior; d->act_idx = p->act_idx; d->act_inv = p->act_inv; d->n_act = p->n_act; d->alive = p->alive; d->seq_n = p->seq_n;
@@ -920,6 +921,7 @@ extern "C" int cm_k_block_update_mu(cm_ctx* ctx, int32_t N, int32_t K, const dou
   int na = 0;
   cm_set set;
   if (!rc) rc = cm_set_single(ctx, p, &set);
+  if (!rc) rc = cm_launch_entry_copies(ctx, set);              // per-entry y / mask from what the hook uploaded
   if (!rc) rc = cm_launch_stats(ctx, set, 0.1);
   if (!rc) rc = cm_launch_post_single(ctx, set, -1, nullptr, 0);
   if (!rc) rc = cm_solve_mu(ctx, set, &na);
@@ -943,6 +945,7 @@ extern "C" int cm_k_update_phi(cm_ctx* ctx, int32_t N, int32_t K, const double* 
       hipMemcpy(p->phi_cov_prior, phi_cov_prior, (size_t)N * 32, hipMemcpyHostToDevice) != hipSuccess) { cm_set_error("upload failed"); rc = CM_ERR_HIP; }
   cm_set set;
   if (!rc) rc = cm_set_single(ctx, p, &set);
+  if (!rc) rc = cm_launch_entry_copies(ctx, set);              // per-entry y / mask from what the hook uploaded
   if (!rc) rc = cm_launch_update_phi(ctx, set, st);
   if (!rc && (hipMemcpyAsync(phi, p->phi, (size_t)N * 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
               hipMemcpyAsync(phi_cov, p->phi_cov, (size_t)N * 32, hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -971,6 +974,7 @@ static int post_hook(cm_ctx* ctx, int N, int K, const double* stim, const double
       hipMemset(p->n_act, 0, 4 * sizeof(int)) != hipSuccess) { cm_set_error("upload failed"); rc = CM_ERR_HIP; }
   cm_set set;
   if (!rc) rc = cm_set_single(ctx, p, &set);
+  if (!rc) rc = cm_launch_entry_copies(ctx, set);              // per-entry y / mask from what the hook uploaded
   if (!rc) rc = cm_launch_sum_y(ctx, set);
   if (!rc) rc = cm_launch_stats(ctx, set, o->spont_orthogonality);
   if (!rc) rc = cm_launch_post_single(ctx, set, it, o, 1);
@@ -1049,6 +1053,7 @@ extern "C" int cm_k_lam_sweep(cm_ctx* ctx, int32_t N, int32_t K, const double* s
   if (!rc) rc = cm_launch_rng(ctx, p, 0, 1, st);
   if (!rc) rc = cm_launch_ndtri_table(ctx, p, 0, 1, S, CM_RNG_THREEFRY, st);
   if (!rc) rc = cm_set_single(ctx, p, &set);
+  if (!rc) rc = cm_launch_entry_copies(ctx, set);              // per-entry y / mask from what the hook uploaded
   if (!rc) rc = cm_launch_iter_mid(ctx, set, -1, 1, S, CM_RNG_THREEFRY, &o, 0, 0, 2);   // per-neuron role only: MC logit from phi / phi_cov
   ctx->mb_n = N;
   if (!rc) rc = cm_launch_sweep(ctx, set, it, &o, nullptr, 0);

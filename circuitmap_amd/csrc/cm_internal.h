@@ -145,6 +145,8 @@ struct cm_problem {
   std::vector<uint32_t> h_keys;   // host copy of the threefry key schedule (source of asynchronous uploads)
   // --- CAVIaR state ---
   uint8_t* mask = nullptr;    // [K] lam_mask
+  double* ye = nullptr;       // [nnz] y[col[e]]: per-entry copy of the trial's response (y is constant during a run) -- the row kernels
+  uint8_t* me = nullptr;      // [nnz] mask[col[e]]                 read it contiguously instead of gathering 8 (1) bytes per 64-byte line
   double* slab = nullptr;     // one allocation: mu | beta | z | lam (so the false-negative scan moves them in one copy each way)
   double* pslab = nullptr;    // one allocation: mu_prior | beta_prior | phi_prior | phi_cov_prior | scal
   double* lam = nullptr;      // [nnz] CSR order
@@ -214,6 +216,7 @@ struct cm_pdev {
   const uint8_t* grp;
   const int *rowcnt, *col_ptr, *csc_row, *csc_pos;
   uint8_t *mask, *colany;
+  const double* ye; const uint8_t* me;      // per-entry copies of y and mask (refreshed by k_init_state / cm_launch_entry_copies)
   double *lam, *mu, *beta, *phi, *phi_cov, *scal, *R, *z, *mcE, *rs;
   double *phi_dead, *phi_cov_dead, *phi_c_dead;   // update_phi of an all-zero row, per neuron, and ndtr(-mean / sdev) of it: constants of a run (k_phi_dead)
   const double *pslab, *mu_prior, *beta_prior, *phi_prior, *phi_cov_prior;
@@ -432,6 +435,7 @@ inline int cm_raise_lds(cm_ctx* ctx, int slot, const void* fn, size_t bytes, siz
 // ------------------------------------------------------------------------------------------------
 int cm_launch_psc_prologue(cm_ctx* ctx, int K, int T, const double* d_psc, double* d_y, double* d_ss);
 int cm_encode_stim(cm_ctx* ctx, cm_problem* p, const double* d_stim);               // syncs (sizes nnz)
+int cm_launch_entry_copies(cm_ctx* ctx, cm_set& s);                                  // ye / me from the current y / mask (after a test hook uploaded either)
 int cm_launch_init_state(cm_ctx* ctx, cm_set& s, double y_xcorr_thresh);             // state from the uploaded priors, lam0, mask, z, counters
 int cm_launch_scatter_dense_lam(cm_ctx* ctx, cm_problem* p, const double* d_lam_dense);
 int cm_launch_expand_lam(cm_ctx* ctx, cm_problem* p, const double* d_lam_sparse, double* d_dense);

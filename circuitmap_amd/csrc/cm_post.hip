@@ -16,15 +16,14 @@
 template <bool BATCH>
 __device__ __forceinline__ void stats_row(const cm_pdev& p, const double* __restrict__ lam, int n, int lane) {
     const int* __restrict__ row_ptr = p.row_ptr;
-  const int* __restrict__ col = p.col;
-  const double* __restrict__ y = p.y;
+  const double* __restrict__ ye = p.ye;               // y[col[e]], entry by entry: contiguous like lam
   double s1 = 0.0, s2 = 0.0, sy = 0.0, d = 0.0;
   int any = 0;
   for (int e = row_ptr[n] + lane; e < row_ptr[n + 1]; e += CM_WAVE) {
     const double l = lam[e];
     s1 += l;
     s2 = fma(l, l, s2);
-    sy = fma(y[col[e]], l, sy);
+    sy = fma(ye[e], l, sy);
     d = fma(l, 1.0 - l, d);
     any |= (l != 0.0);
   }
@@ -60,12 +59,10 @@ __global__ __launch_bounds__(256) void k_stats(cm_parg<BATCH> pa, int nbR, doubl
     const int begA = onA ? row_ptr[nA] : 0, lenA = onA ? row_ptr[nA + 1] - begA : 0;
     const int begB = onB ? row_ptr[nB] : 0, lenB = onB ? row_ptr[nB + 1] - begB : 0;
     if (!__any(lenA > 32 || lenB > 32)) {
-      const int* __restrict__ col = p.col;
-      const double* __restrict__ y = p.y;
+      const double* __restrict__ ye = p.ye;           // y[col[e]], entry by entry: contiguous like lam -- no gather level
       const bool inA = sub < lenA, inB = sub < lenB;
       const double lA = inA ? lam[begA + sub] : 0.0, lB = inB ? lam[begB + sub] : 0.0;
-      const int cA = inA ? col[begA + sub] : 0, cB = inB ? col[begB + sub] : 0;
-      const double yA = inA ? y[cA] : 0.0, yB = inB ? y[cB] : 0.0;
+      const double yA = inA ? ye[begA + sub] : 0.0, yB = inB ? ye[begB + sub] : 0.0;
       double* __restrict__ rs = p.rs;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {

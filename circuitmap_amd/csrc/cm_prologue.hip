@@ -301,7 +301,13 @@ __global__ __launch_bounds__(256) void k_init_state(cm_parg<BATCH> pa, double th
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int N = p.N, K = p.K;
   if (i < K) { p.mask[i] = p.ss[i] > thresh; p.z[i] = 0.0; }
-  if (i < p.nnz) p.lam[i] = 0.95 * (double)(p.ss[p.col[i]] > thresh);
+  if (i < p.nnz) {
+    const int c = p.col[i];
+    const bool on = p.ss[c] > thresh;
+    p.lam[i] = 0.95 * (double)on;
+    const_cast<uint8_t*>(p.me)[i] = (uint8_t)on;             // per-entry copies of mask and y for the row kernels
+    const_cast<double*>(p.ye)[i] = p.y[c];
+  }
   const double* __restrict__ pslab = p.pslab;              // mu_prior | beta_prior | phi_prior | phi_cov_prior | scalars
   if (i < N) { p.mu[i] = pslab[i]; p.beta[i] = pslab[N + i]; }
   if (i < 2 * (long long)N) p.phi[i] = pslab[2 * (size_t)N + i];
@@ -318,6 +324,18 @@ __global__ __launch_bounds__(1024) void k_sum_y_set(cm_parg<BATCH> pa) {
 
 int cm_launch_sum_y(cm_ctx* ctx, cm_set& s) {
   CM_LAUNCH_SET(k_sum_y_set, s, 1, 1024, 0, ctx->stream);
+  CM_HIP(hipGetLastError());
+  return CM_OK;
+}
+
+template <bool BATCH>
+__global__ __launch_bounds__(256) void k_entry_copies(cm_parg<BATCH> pa) {
+  const cm_pdev& p = pa.get();
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < p.nnz) { const int c = p.col[i]; const_cast<uint8_t*>(p.me)[i] = p.mask[c]; const_cast<double*>(p.ye)[i] = p.y[c]; }
+}
+int cm_launch_entry_copies(cm_ctx* ctx, cm_set& s) {
+  CM_LAUNCH_SET(k_entry_copies, s, (unsigned)((std::max<long long>(s.nnz_max, 1) + 255) / 256), 256, 0, ctx->stream);
   CM_HIP(hipGetLastError());
   return CM_OK;
 }

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64) void k_ndtri_table(const uint32_t* __restrict__
 // ------------------------------------------------------------------------------------------------
 struct SweepArgs {
   const int* row_ptr; const int* col; const uint8_t* grp; const int* rowcnt;
-  const double* y; const uint8_t* mask; const double* mu; const double* beta; const double* mcE; const double* scal;
+  const double* y; const uint8_t* mask; const double* ye; const uint8_t* me; const double* mu; const double* beta; const double* mcE; const double* scal;
   double* lam;
   int V, gated;
   double msrmp, min_count;
@@ -115,7 +115,7 @@ struct SweepArgs {
 __device__ __forceinline__ SweepArgs sweep_args(const cm_pdev& p, int gated, double msrmp, double min_count) {
   SweepArgs a;
   a.row_ptr = p.row_ptr; a.col = p.col; a.grp = p.grp; a.rowcnt = p.rowcnt;
-  a.y = p.y; a.mask = p.mask; a.mu = p.mu; a.beta = p.beta; a.mcE = p.mcE; a.scal = p.scal;
+  a.y = p.y; a.mask = p.mask; a.ye = p.ye; a.me = p.me; a.mu = p.mu; a.beta = p.beta; a.mcE = p.mcE; a.scal = p.scal;
   a.lam = p.lam; a.V = p.V; a.gated = gated; a.msrmp = msrmp; a.min_count = min_count;
   return a;
 }
@@ -319,7 +319,7 @@ __device__ __forceinline__ void sweep_indep_row(const SweepArgs& a, int n, int l
   if (valid) {
     const int e = beg + lane;
     g = a.grp[e];
-    if (a.mask[a.col[e]]) est = cm_sigmoid(a.mcE[(size_t)n * CM_MAX_VALS + g] - 0.5 * arg);
+    if (a.me[e]) est = cm_sigmoid(a.mcE[(size_t)n * CM_MAX_VALS + g] - 0.5 * arg);     // me[e] = mask[col[e]]
   }
   double pava = 1.0;
   if (a.gated) pava = row_gate<LEAN>(valid, g, est, a.V - 1, thresh, a.min_count, scr);
@@ -349,7 +349,7 @@ __device__ __forceinline__ void sweep_indep_pair(const SweepArgs& a, int n0, int
     const double arg = sig * (be * be);              // mu == 0: caviar.py:205-206 reduces to sigma * beta^2
     const int e = beg + sub;
     g = a.grp[e];
-    if (a.mask[a.col[e]]) est = cm_sigmoid(a.mcE[(size_t)n * CM_MAX_VALS + g] - 0.5 * arg);
+    if (a.me[e]) est = cm_sigmoid(a.mcE[(size_t)n * CM_MAX_VALS + g] - 0.5 * arg);     // me[e] = mask[col[e]]
   }
   double pava = 1.0;
   if (a.gated) {
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256) void k_seq_pack(cm_parg<BATCH> pa, int gated, 
     const int e = beg + lane;
     const int k = a.col[e], g = a.grp[e];
     SeqRec r;
-    r.a = (uint32_t)k | ((uint32_t)g << 24) | ((uint32_t)(a.mask[k] != 0) << 31);
+    r.a = (uint32_t)k | ((uint32_t)g << 24) | ((uint32_t)(a.me[e] != 0) << 31);
     int turn = 0;
     if (turns)     // (gathering four neurons at a time was measured slower than this plain loop: 28.3 vs 26.8 us at 128 circuits, 6.6 vs 5.4 us for one)
       for (int ce = col_ptr[k]; ce < col_ptr[k + 1]; ++ce) { const int q = seq_pos[csc_row[ce]]; turn += (q >= 0 && q < j); }
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256) void k_seq_pack(cm_parg<BATCH> pa, int gated, 
     r.b = e | (turn << 24);
     r.x = a.lam[e];
     r.y = a.mcE[(size_t)n * CM_MAX_VALS + g];
-    r.z = -2.0 * sig * a.y[k] * mu;                                                       // caviar.py:205, first term
+    r.z = -2.0 * sig * a.ye[e] * mu;                                                      // caviar.py:205, first term (ye[e] = y[k])
     packed[off + 1 + lane] = r;
   }
 }
