@@ -459,8 +459,8 @@ __global__ __launch_bounds__(256) void k_chol_trsm(cm_parg<BATCH> pa, int na_arg
 
 // Large matrices (more than 48 tiles) and every batch: the trailing update is bandwidth-bound -- every pass re-reads and re-writes
 // the trailing matrix -- so the panels go in PAIRS (j, j + 1) and the trailing matrix is read and rewritten once per pair:
-//   k_chol_trsm(j)        X^j_i   = A[i][j] L_jj^-T                                   i > j
-//   k_chol_bulk<thin>(j)  A[i][j+1] -= X^j_i X^j_{j+1}^T                              i >= j + 1   (one tile column; block 0 factors the diagonal tile (j+1, j+1))
+//   k_chol_bulk<thin>(j)  X^j_i   = A[i][j] L_jj^-T  (-> Lf[i][j]),  A[i][j+1] -= X^j_i X^j_{j+1}^T      i >= j + 1   (one tile column: the panel
+//                         solve of column j and the update of column j + 1 in one launch; block 0 factors the diagonal tile (j+1, j+1))
 //   k_chol_trsm(j + 1)    X^{j+1}_i = A[i][j+1] L_{j+1,j+1}^-T                        i > j + 1
 //   k_chol_bulk<wide>(j)  A[i][l] = (A[i][l] - X^j_i X^j_l^T) - X^{j+1}_i X^{j+1}_l^T   i >= l >= j + 2  (block 0 factors the diagonal tile (j+2, j+2))
 // Each product is its own matrix-core accumulation from zero and the two subtractions happen in panel order, so every tile holds
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256) void k_chol_bulk(cm_parg<BATCH> pa, int na_arg
   const double* __restrict__ Lf = p.Lf;
   double* __restrict__ Dinv = p.Dinv;
   int* __restrict__ flag = p.n_act + 1;
-  __shared__ double Sm[2][TS][TP];                   // two tiles (17 KB): LDS is not what limits the workgroups per CU
+  __shared__ double Sm[WIDE ? 2 : 3][TS][TP];        // two tiles (17 KB; the thin pass also stages L_jj^-1): LDS is not what limits the workgroups per CU
   const int t = bx;                                  // id 0 is the pass's diagonal tile
   int i, l;
   if (WIDE) {                                        // linear id -> (i, l), j + 2 <= l <= i
@@ -495,16 +495,38 @@ __global__ __launch_bounds__(256) void k_chol_bulk(cm_parg<BATCH> pa, int na_arg
   for (int reg = 0; reg < 4; ++reg) o[reg] = cm_gload(out, ((unsigned)BLK_ROW(rb, lane, reg) * (unsigned)ld + (unsigned)BLK_COL(cb, lane)) * 8u);
   // every load of the workgroup is issued before the first one is consumed (one memory round trip, not one per tile): the panel
   // tiles go through registers, and a diagonal output tile (l == i) simply fetches its panel tile twice -- no branch between loads
-  double rx[WIDE ? 4 : 2][4];
-  tile_fetch(rx[0], Lf + (size_t)i * TS * ld + (size_t)j * TS, ld);
-  tile_fetch(rx[1], Lf + (size_t)l * TS * ld + (size_t)j * TS, ld);
+  double rx[WIDE ? 4 : 3][4];
   if (WIDE) {
+    tile_fetch(rx[0], Lf + (size_t)i * TS * ld + (size_t)j * TS, ld);
+    tile_fetch(rx[1], Lf + (size_t)l * TS * ld + (size_t)j * TS, ld);
     tile_fetch(rx[2], Lf + (size_t)i * TS * ld + (size_t)(j + 1) * TS, ld);
     tile_fetch(rx[3], Lf + (size_t)l * TS * ld + (size_t)(j + 1) * TS, ld);
+    tile_put(Sm[0], rx[0]);
+    tile_put(Sm[1], rx[1]);
+    __syncthreads();
+  } else {
+    // thin pass: the panel solve of column j rides along (no launch of its own) -- X_i = A[i][j] L_jj^-T and X_{j+1} are formed here
+    // from the unsolved panel tiles, exactly as k_chol_trsm / k_chol_panel form them, and X_i is the tile of the factor this
+    // workgroup owns (Lf[i][j], read by the rank-64 pass and the inverse)
+    tile_fetch(rx[0], A + (size_t)i * TS * ld + (size_t)j * TS, ld);
+    tile_fetch(rx[1], A + (size_t)l * TS * ld + (size_t)j * TS, ld);
+    tile_fetch(rx[2], Dinv + (size_t)j * TS * TS, TS);
+    tile_put(Sm[0], rx[0]);
+    tile_put(Sm[1], rx[1]);
+    tile_put(Sm[2], rx[2]);
+    __syncthreads();
+    cm_d4 xi = {0.0, 0.0, 0.0, 0.0}, xl = {0.0, 0.0, 0.0, 0.0};
+    xi = blk_mfma_nt(xi, Sm[0], Sm[2], rb, cb, lane);   // X_i = P_i Linv^T
+    xl = blk_mfma_nt(xl, Sm[1], Sm[2], rb, cb, lane);   // X_{j+1}
+    __syncthreads();                                     // every wave has read the unsolved tiles: the solved ones replace them
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      Sm[0][BLK_ROW(rb, lane, reg)][BLK_COL(cb, lane)] = xi[reg];
+      Sm[1][BLK_ROW(rb, lane, reg)][BLK_COL(cb, lane)] = xl[reg];
+    }
+    __syncthreads();
+    tile_store(const_cast<double*>(Lf) + (size_t)i * TS * ld + (size_t)j * TS, ld, Sm[0]);
   }
-  tile_put(Sm[0], rx[0]);
-  tile_put(Sm[1], rx[1]);
-  __syncthreads();
   {
     cm_d4 c = {0.0, 0.0, 0.0, 0.0};
     c = blk_mfma_nt(c, Sm[0], Sm[1], rb, cb, lane);
@@ -846,7 +868,7 @@ int cm_solve_launch(cm_ctx* ctx, cm_set& s, int skip_mode, hipEvent_t fact_begin
       for (int j = 0; j + 1 < nb; j += 2) {          // panel pair: two panel solves, the thin column, the rank-64 update
         const long long t = nb - j - 1;
         s.fact_tile_updates += t + (t - 1) * t / 2;
-        s.fact_panel_tiles += (2 * t + 1) + t;                             // k_chol_trsm(j): t in, t out, L^-1; thin pass: the t solved panel tiles
+        s.fact_panel_tiles += (2 * t + 1);                                 // thin pass: t unsolved panel tiles in, t solved out, L^-1
         if (t >= 2) s.fact_panel_tiles += (2 * (t - 1) + 1) + 2 * (t - 1);  // k_chol_trsm(j + 1); rank-64 pass: both panels' tiles
       }
     } else {
@@ -896,8 +918,7 @@ int cm_solve_launch(cm_ctx* ctx, cm_set& s, int skip_mode, hipEvent_t fact_begin
     if (large_g) {                                     // panels in pairs: panel solve, thin column, panel solve, rank-64 trailing update
       for (int j = 0; j + 1 < nblk; j += 2) {
         const int t = nblk - j - 1;
-        CM_LAUNCH_G(k_chol_trsm, t, 256, 0, na1, skip_le, j, large_min);
-        CM_LAUNCH_GT(k_chol_bulk, false, t, 256, 0, na1, xflags, j, large_min);
+        CM_LAUNCH_GT(k_chol_bulk, false, t, 256, 0, na1, xflags, j, large_min);        // (carries the panel solve of column j)
         if (t < 2) break;
         CM_LAUNCH_G(k_chol_trsm, t - 1, 256, 0, na1, skip_le, j + 1, large_min);
         CM_LAUNCH_GT(k_chol_bulk, true, (t - 1) * t / 2, 256, 0, na1, xflags, j, large_min);
