@@ -472,7 +472,7 @@ def main():
         rows = float(np.mean([t["sum_seq_rows"] for t in tms])) / its
         chain_bytes = Bl * (recs * 32 + (recs - rows) * 8 + K * 12)               # records + lam writes + R and ticket vectors
         # (3) the passes of the tiled Cholesky over the trailing matrix: k_chol_panel (one panel per launch; one circuit up to 48 tile rows), or
-        #     panel-pair steps k_chol_trsm + thin k_chol_bulk + k_chol_trsm + rank-64 k_chol_bulk (batches, larger matrices), timed as a
+        #     panel-pair steps thin k_chol_bulk (incl. the panel solve of its column) + k_chol_trsm + rank-64 k_chol_bulk (batches, larger matrices), timed as a
         #     group by one event pair per factorisation.  Algorithmic bytes of a pass: every trailing 32 x 32 fp64 tile
         #     read and rewritten once (16 KB), plus the 8 KB tiles no blocking of this width avoids, each counted once per launch however many
         #     workgroups share it -- panel tiles read, solved panel tiles written, the diagonal tile's inverse
@@ -636,13 +636,13 @@ def _kb(fetch_kb, write_kb):
 
 PMC_TRAFFIC = {
     # one lock-step batch of 128 circuits (profiles/r02_a_cfg3_B128_pmc_{fetch,write}_size.csv), KB per launch:
-    #   k_iter_mid   20 plain launches (state init + early iterations) 30528.8 fetched / 11308.7 written, 184 listed launches 10894.3 / 3335.9 -> average 12819.3 / 4117.5
+    #   k_iter_mid   20 plain launches (state init + early iterations) 30526.2 fetched / 11309.7 written, 184 listed launches 10877.8 / 3335.2 -> average 12804.1 / 4117.0
     #   k_mc_dead    14554.5 / 9828.0
-    #   per panel-pair step (260 steps: 236 rank-64 k_chol_bulk 85732.3 / 142648.7, 260 thin k_chol_bulk 13547.0 / 13385.0,
-    #   496 k_chol_trsm 10217.5 / 13546.1):  110857.4 fetched, 168707.9 written
-    ("cfg3", 128, "k_iter_mid"): _kb(12819.3, 4117.5),
+    #   per panel-pair step (260 steps: 236 rank-64 k_chol_bulk 85728.9 / 142648.7, 260 thin k_chol_bulk (with the panel solve of
+    #   their column) 14194.5 / 26770.0, 236 k_chol_trsm 10391.7 / 13723.5):  101442.4 fetched, 168707.8 written
+    ("cfg3", 128, "k_iter_mid"): _kb(12804.1, 4117.0),
     ("cfg3", 128, "k_mc_dead"): _kb(14554.5, 9828.0),
-    ("cfg3", 128, "k_chol_bulk+k_chol_trsm"): _kb(110857.4, 168707.9),
+    ("cfg3", 128, "k_chol_bulk+k_chol_trsm"): _kb(101442.4, 168707.8),
     # one circuit at a time (profiles/r02_b_cfg3_B1_pmc_{fetch,write}_size.csv)
     ("cfg3", 1, "k_iter_mid"): _kb(1884.7, 101.8),
     ("cfg3", 1, "k_chol_panel"): _kb(1110.3, 1317.2),
