@@ -1,4 +1,4 @@
-"""HIP path vs the running-residual oracle on BASELINE's configurations: max relative error of mu / lam (and every other output), gate
+"""Test infrastructure (a checker, like the rest of tests/): HIP path vs the running-residual oracle on BASELINE's configurations: max relative error of mu / lam (and every other output), gate
 flips (rows whose lam support differs), for BASELINE.md section 6.  Needs an MI355X; the oracle runs on the host (about 2 minutes)."""
 import sys, time, numpy as np
 sys.path.insert(0, '.')
