@@ -138,10 +138,9 @@ def bench_nwd(a):
         ge.build()
     if dist is not None:
         dist.barrier()
-    from circuitmap_amd.neural_waveform_demixing import NeuralDemixer
-    from oracle import nwd_oracle as no          # parameter generator + the CPU baseline (checker / baseline only)
+    from circuitmap_amd.neural_waveform_demixing import NeuralDemixer, random_parameters
     K, T = 2000, 900
-    state = no.random_state(seed=0)
+    state = random_parameters(seed=0)
     rng = np.random.default_rng(3000 + rank)
     traces = rng.normal(0, 0.05, (K, T)) + np.exp(-np.abs(np.arange(T)[None, :] - rng.uniform(100, 500, (K, 1))) / 60.0) * rng.uniform(0.5, 4, (K, 1))
     dm = NeuralDemixer(state=state, device=local_rank)
@@ -185,6 +184,7 @@ def bench_nwd(a):
                             "algorithmic_flops_per_launch": int(flops),
                             "hbm_bytes_per_launch": int(K * T * 16)}}
         if world == 1 and not a.no_cpu_baseline:
+            from oracle import nwd_oracle as no      # the CPU baseline leg only (checker / baseline)
             nb = 256
             nthreads = torch.get_num_threads()
             t = time.time()
@@ -446,6 +446,7 @@ def main():
         dt = float(t.item())
         n_ranks_seen = dist.get_world_size()
 
+    exit_code = 0
     if rank == 0:
         its = a.iters
         value = world * B * a.steps * its / dt
@@ -553,6 +554,10 @@ def main():
                                        "k_iter_mid_avg_launch_ms": btms[-1]["mid_ms"] / its, "k_sweep_par_avg_launch_ms": btms[-1]["sweep_seq_ms"] / its,
                                        "fact_ms_per_step": btms[-1]["fact_ms"],
                                        "note": "every circuit bit-identical to its single fit (tests/test_gpu_parity.py::test_fit_batch_baseline_config3)"}
+        batch_res0 = None
+        if B > 1:
+            # self-check of the launch configuration that was just timed: circuit 0's results as the lock-step batch left them ...
+            batch_res0 = sets[0][0].fetch()
         if world == 1 and B > 1 and not a.no_single_leg:
             # the same path one circuit at a time: the latency of a fit (what round 1's bench line reported)
             q = sets[0][0]
@@ -570,6 +575,17 @@ def main():
                                      "fact_ms_per_fit": float(np.mean([t["fact_ms"] for t in sk])),
                                      "batch_x_single": value / (8 * its / sdt),
                                      "note": "one circuit per step on the same GPU: a latency chain occupying a few percent of the chip"}
+        if batch_res0 is not None:
+            # ... against the same problem object fitted alone (cm_caviar_run): bit for bit, all eight outputs (mu, beta, lam, shape,
+            # rate, phi, phi_cov, z).  A mismatch makes the run fail (exit code 1 after the line is printed).
+            q = sets[0][0]
+            q.run(*run_args, **opts)
+            single_res0 = q.fetch()
+            out["batch_equals_single"] = bool(all(np.array_equal(np.asarray(x, dtype=float), np.asarray(y_, dtype=float), equal_nan=True)
+                                                  for x, y_ in zip(batch_res0[:8], single_res0[:8])))
+            out["batch_equals_single_note"] = ("circuit 0 of the timed lock-step batch vs its own single fit on the same problem object, "
+                                               "bitwise over mu, beta, lam, shape, rate, phi, phi_cov, z")
+            del batch_res0, single_res0
         if world == 1 and B > 1 and a.streams_leg and a.streams_leg > 1 and G == 1:
             # the same B circuits as several lock-step batches in flight on separate contexts (HIP streams), one host thread each
             for probs_ in sets:                              # (the main measurement's circuits are released first)
@@ -619,13 +635,16 @@ def main():
         if world == 1 and not a.no_cpu_baseline and sims:
             out["cpu_baseline"] = cpu_baseline(sims[0], pri, wl)
         emit(json.dumps(out))
+        if out.get("batch_equals_single") is False:
+            print("bench.py: circuit 0 of the batch differs from its single fit", file=sys.stderr)
+            exit_code = 1
     for probs in sets:
         for q in probs:
             q.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    return 0
+    return exit_code
 
 
 # HBM bytes per launch from committed rocprofv3 PMC summaries, keyed (workload, circuits per GPU, kernel): filled in when a profile of

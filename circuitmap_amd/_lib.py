@@ -16,6 +16,7 @@ CM_OK = 0
 CM_MEM_HOST, CM_MEM_DEVICE = 0, 1
 CM_RNG_THREEFRY, CM_RNG_EXPLICIT = 0, 1
 CM_MAX_VALS = 64
+CM_ABI_VERSION = 3          # include/caviar_hip.h; checked against the library at load()
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -26,7 +27,7 @@ class CmPriors(C.Structure):
 
 
 class CmOptions(C.Structure):
-    _fields_ = [("iters", C.c_int32), ("num_mc_samples", C.c_int32), ("seed", C.c_uint64), ("y_xcorr_thresh", C.c_double),
+    _fields_ = [("abi_version", C.c_int32), ("iters", C.c_int32), ("num_mc_samples", C.c_int32), ("seed", C.c_uint64), ("y_xcorr_thresh", C.c_double),
                 ("minimum_spike_count", C.c_double), ("delay_spont_est", C.c_int32), ("msrmp", C.c_double),
                 ("scale_factor", C.c_double), ("penalty", C.c_double), ("save_histories", C.c_int32),
                 ("max_backtrack_iters", C.c_int32), ("tol", C.c_double), ("spont_orthogonality", C.c_double),
@@ -86,6 +87,7 @@ class CmSimResult(C.Structure):
 SYMBOLS = {
     "cm_last_error": (C.c_char_p, []),
     "cm_version": (C.c_char_p, []),
+    "cm_abi_version": (C.c_int, []),
     "cm_device_count": (C.c_int, []),
     "cm_options_default": (None, [C.POINTER(CmOptions)]),
     "cm_ctx_create": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
@@ -117,6 +119,7 @@ SYMBOLS = {
     "cm_k_rng_streams": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, _ip, _dp]),
     "cm_k_event_pair_overhead": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float)]),
     "cm_test_lds_request": (C.c_int64, [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "cm_test_lds_race": (C.c_int, [C.c_uint64, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     # include/nwd_hip.h
     "cm_nwd_create": (C.c_int, [C.c_void_p, C.POINTER(CmNwdParams), C.POINTER(C.c_void_p)]),
     "cm_nwd_destroy": (None, [C.c_void_p]),
@@ -155,6 +158,8 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        if lib.cm_abi_version() != CM_ABI_VERSION:
+            raise CaviarHipError("%s is ABI %d, this binding expects %d: rebuild the library" % (LIB_PATH, lib.cm_abi_version(), CM_ABI_VERSION))
         _lib = lib
     return _lib
 
@@ -185,30 +190,37 @@ class Context:
         check(self.lib.cm_ctx_create(int(device_id), C.c_void_p(stream) if stream else None, C.byref(self.handle)))
 
     def synchronize(self):
-        check(self.lib.cm_ctx_synchronize(self.handle))
+        with self.lock:
+            check(self.lib.cm_ctx_synchronize(self.handle))
 
-    # device buffers without torch (cm_mem_*): addresses are plain ints
+    # device buffers without torch (cm_mem_*): addresses are plain ints.  Every entry into the library on this context takes the
+    # context's lock (caviar_hip.h: calls on one cm_ctx must be serialised; contexts are shared with worker threads in fit_batch / bench).
     def alloc(self, nbytes):
         p = C.c_void_p()
-        check(self.lib.cm_mem_alloc(self.handle, int(nbytes), C.byref(p)))
+        with self.lock:
+            check(self.lib.cm_mem_alloc(self.handle, int(nbytes), C.byref(p)))
         return p.value or 0
 
     def free(self, ptr):
-        check(self.lib.cm_mem_free(self.handle, C.c_void_p(ptr)))
+        with self.lock:
+            check(self.lib.cm_mem_free(self.handle, C.c_void_p(ptr)))
 
     def upload(self, ptr, array):
         a = np.ascontiguousarray(array)
-        check(self.lib.cm_mem_copy(self.handle, C.c_void_p(ptr), a.ctypes.data_as(C.c_void_p), a.nbytes, 1))
+        with self.lock:
+            check(self.lib.cm_mem_copy(self.handle, C.c_void_p(ptr), a.ctypes.data_as(C.c_void_p), a.nbytes, 1))
 
     def download(self, ptr, array):
         assert array.flags["C_CONTIGUOUS"]
-        check(self.lib.cm_mem_copy(self.handle, array.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), array.nbytes, 2))
+        with self.lock:
+            check(self.lib.cm_mem_copy(self.handle, array.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), array.nbytes, 2))
         return array
 
     def close(self):
-        if self.handle:
-            self.lib.cm_ctx_destroy(self.handle)
-            self.handle = C.c_void_p()
+        with self.lock:
+            if self.handle:
+                self.lib.cm_ctx_destroy(self.handle)
+                self.handle = C.c_void_p()
 
     def __del__(self):
         try:

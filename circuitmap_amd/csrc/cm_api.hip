@@ -34,19 +34,66 @@ extern "C" const char* cm_last_error(void) { return g_err; }
 // dynamic-LDS caps in force, per (device, kernel): only ever raised (see cm_raise_lds, cm_internal.h)
 static std::mutex g_lds_mu;
 static std::map<std::pair<int, const void*>, size_t> g_lds_table;
-size_t cm_lds_table_request(int device, const void* fn, size_t bytes, size_t floor_bytes) {
+int cm_lds_table_raise(int device, const void* fn, size_t bytes, size_t floor_bytes, cm_lds_setter set, void* user, size_t* applied) {
   std::lock_guard<std::mutex> lk(g_lds_mu);
   size_t& slot = g_lds_table[std::make_pair(device, fn)];
   const size_t cur = slot > floor_bytes ? slot : floor_bytes;
-  if (bytes <= cur) return 0;
-  slot = bytes;
-  return bytes;
+  if (applied) *applied = 0;
+  if (bytes <= cur) return CM_OK;
+  const int rc = set(fn, bytes, user);                   // the runtime call happens under the lock ...
+  if (rc != CM_OK) return rc;
+  slot = bytes;                                          // ... and the table only records what the runtime accepted
+  if (applied) *applied = bytes;
+  return CM_OK;
+}
+int cm_lds_set_attribute(const void* fn, size_t bytes, void*) {
+  CM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return CM_OK;
+}
+// test hooks (no GPU needed): a recording setter stands in for the runtime.  Keys of these hooks live in their own range of the table:
+// odd addresses, which no kernel has.
+struct lds_fake { std::atomic<size_t> in_force{0}; std::atomic<int> calls{0}; int fail_above = 0; int delay_us = 0; };
+static int lds_fake_set(const void*, size_t bytes, void* user) {
+  lds_fake* f = (lds_fake*)user;
+  if (f->fail_above && bytes > (size_t)f->fail_above) return CM_ERR_HIP;
+  if (f->delay_us) std::this_thread::sleep_for(std::chrono::microseconds(f->delay_us));   // widens the window a race would need
+  f->in_force.store(bytes);                              // like the runtime: the new value REPLACES the old one
+  f->calls.fetch_add(1);
+  return CM_OK;
 }
 extern "C" int64_t cm_test_lds_request(int32_t device, uint64_t kernel_key, uint64_t bytes, uint64_t floor_bytes) {
-  // keys of this hook live in their own range of the table: odd addresses, which no kernel has
-  return (int64_t)cm_lds_table_request(device, reinterpret_cast<const void*>((uintptr_t)(2 * kernel_key + 1)), (size_t)bytes, (size_t)floor_bytes);
+  lds_fake f;
+  size_t applied = 0;
+  if (cm_lds_table_raise(device, reinterpret_cast<const void*>((uintptr_t)(2 * kernel_key + 1)), (size_t)bytes, (size_t)floor_bytes, lds_fake_set, &f, &applied) != CM_OK) return -1;
+  return (int64_t)applied;
 }
-extern "C" const char* cm_version(void) { return "caviar_hip 0.1 (gfx950)"; }
+// n_threads host threads issue `reps` requests each for ONE (device, kernel) with interleaved sizes (thread t asks for base + (r * n_threads + t)
+// * step); out[0] = value the fake runtime holds at the end, out[1] = largest request, out[2] = setter calls.  A correct table
+// leaves out[0] == out[1].  fail_above > 0: requests above it are refused by the setter (the table must not record them): then out[0] is
+// the largest accepted request.
+extern "C" int cm_test_lds_race(uint64_t kernel_key, int32_t n_threads, int32_t reps, uint64_t base, uint64_t step, uint64_t fail_above, uint64_t* out) {
+  if (n_threads < 1 || reps < 1 || !out) return CM_ERR_INVALID;
+  lds_fake f;
+  f.fail_above = (int)fail_above; f.delay_us = 20;
+  const void* fn = reinterpret_cast<const void*>((uintptr_t)(2 * kernel_key + 1));
+  std::vector<std::thread> th;
+  std::atomic<int> go{0};
+  for (int t = 0; t < n_threads; ++t)
+    th.emplace_back([&, t]() {
+      while (!go.load()) std::this_thread::yield();
+      for (int r = 0; r < reps; ++r) cm_lds_table_raise(7, fn, (size_t)(base + (uint64_t)(r * n_threads + t) * step), 0, lds_fake_set, &f, nullptr);
+    });
+  go.store(1);
+  for (auto& x : th) x.join();
+  out[0] = f.in_force.load(); out[1] = base + (uint64_t)(reps * n_threads - 1) * step; out[2] = (uint64_t)f.calls.load();
+  // what the table believes is in force: a further request for exactly that much must be a no-op, one byte more must call the setter
+  size_t applied = 0;
+  cm_lds_table_raise(7, fn, (size_t)out[0], 0, lds_fake_set, &f, &applied);
+  out[3] = applied;
+  return CM_OK;
+}
+extern "C" const char* cm_version(void) { return "caviar_hip 0.3 (gfx950, ABI 3)"; }
+extern "C" int cm_abi_version(void) { return CM_ABI_VERSION; }
 
 extern "C" int cm_device_count(void) {
   int n = 0;
@@ -56,6 +103,7 @@ extern "C" int cm_device_count(void) {
 
 extern "C" void cm_options_default(cm_options* o) {   // caviar.py:21-23
   memset(o, 0, sizeof(*o));
+  o->abi_version = CM_ABI_VERSION;
   o->iters = 50; o->num_mc_samples = 100; o->seed = 0; o->y_xcorr_thresh = 1e-2; o->minimum_spike_count = 3;
   o->delay_spont_est = 1; o->msrmp = 0.3; o->scale_factor = 0.75; o->penalty = 5e0; o->save_histories = 0;
   o->max_backtrack_iters = 20; o->tol = 0.05; o->spont_orthogonality = 0.1; o->fn_scan = 1;
@@ -432,6 +480,10 @@ static int run_guarded(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_op
 
 static int check_run_args(const char* who, cm_ctx* ctx, const cm_priors* pr, int n, const cm_options* o) {
   if (!ctx || !pr || !o) { cm_set_error("%s: NULL argument", who); return CM_ERR_INVALID; }
+  if (o->abi_version != CM_ABI_VERSION) {
+    cm_set_error("%s: cm_options.abi_version is %d, this library is ABI %d (build the caller against this library's caviar_hip.h and fill cm_options with cm_options_default)", who, o->abi_version, CM_ABI_VERSION);
+    return CM_ERR_INVALID;
+  }
   for (int c = 0; c < n; ++c)
     if (!pr[c].mu || !pr[c].beta || !pr[c].phi || !pr[c].phi_cov) { cm_set_error("%s: NULL prior array (circuit %d)", who, c); return CM_ERR_INVALID; }
   if (o->iters < 0 || o->num_mc_samples < 1) { cm_set_error("%s: iters >= 0 and num_mc_samples >= 1 required", who); return CM_ERR_INVALID; }

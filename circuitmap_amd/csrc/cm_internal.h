@@ -107,7 +107,7 @@ struct cm_ctx {
   int num_cus = 256;
   void* h_stage = nullptr;        // pinned staging buffer (priors upload, fn_scan round trip), grown on demand
   size_t h_stage_bytes = 0;
-  size_t lds_attr[48] = {};       // dynamic-LDS caps already raised for this context's device, by kernel slot (cm_raise_lds)
+  size_t lds_attr[64] = {};       // dynamic-LDS caps already raised for this context's device, by kernel slot (cm_raise_lds)
   long long* dbg_block0 = nullptr; // diagnostic buffer (CAVIAR_HIP_TRACE_BLOCK0): 64 launches x 8 device-clock stamps
   cm_host_pool* pool_host = nullptr; // host threads for the per-circuit host work of batches (created with the first batch)
   void* d_pdev = nullptr;         // descriptors of the current batch (device) and their pinned source
@@ -419,13 +419,19 @@ inline void cm_threefry2x32(uint32_t k0, uint32_t k1, uint32_t& x0, uint32_t& x1
 // lower bounds of that table (valid because the table never decreases), so the common launch pays no lock and no runtime call.
 enum cm_lds_slot { CM_LDS_ITER = 0 /* 7 x 2 x 2 template variants */, CM_LDS_SOLVE_SMALL = 28, CM_LDS_SWEEP_PAR, CM_LDS_SWEEP_PAR2, CM_LDS_SWEEP_SEQ,
                    CM_LDS_NWD, CM_LDS_SIM_SORT, CM_LDS_BUILD_PREC, CM_LDS_SWEEP_PAR_B, CM_LDS_SWEEP_PAR2_B, CM_LDS_SWEEP_SEQ_B,
-                   CM_LDS_SOLVE_SMALL_B, CM_LDS_BUILD_PREC_B, CM_LDS_ITER_LISTED /* 7 SEG variants */, CM_LDS_SLOTS = 48 };
-// table update: returns the value hipFuncSetAttribute has to be called with (0 = the value in force already covers `bytes`)
-size_t cm_lds_table_request(int device, const void* fn, size_t bytes, size_t floor_bytes);
+                   CM_LDS_SOLVE_SMALL_B, CM_LDS_BUILD_PREC_B, CM_LDS_ITER_LISTED /* 7 SEG variants */, CM_LDS_MC_DEAD = 47, CM_LDS_MC_DEAD_B, CM_LDS_ITER_OVERFLOW /* 7 SEG variants */, CM_LDS_SLOTS = 56 };
+static_assert(CM_LDS_SLOTS <= 64, "cm_ctx::lds_attr");
+// Table update AND runtime call under ONE lock: `set(fn, bytes, user)` is invoked while the table's mutex is held, and the table takes
+// the new value only after the setter succeeded -- two host threads (contexts on one GPU) can therefore never apply their values in
+// the opposite order of their table updates (the smaller request landing last would leave the attribute below what the table and both
+// per-context caches claim, for the rest of the process).  Returns CM_OK, or the setter's error with the table unchanged.
+// *applied (optional): the value the setter was called with, 0 if the value in force already covered the request.
+typedef int (*cm_lds_setter)(const void* fn, size_t bytes, void* user);
+int cm_lds_table_raise(int device, const void* fn, size_t bytes, size_t floor_bytes, cm_lds_setter set, void* user, size_t* applied);
+int cm_lds_set_attribute(const void* fn, size_t bytes, void*);      // the real setter: hipFuncSetAttribute(MaxDynamicSharedMemorySize)
 inline int cm_raise_lds(cm_ctx* ctx, int slot, const void* fn, size_t bytes, size_t floor_bytes) {
   if (bytes <= floor_bytes || bytes <= ctx->lds_attr[slot]) return CM_OK;
-  const size_t set = cm_lds_table_request(ctx->device, fn, bytes, floor_bytes);
-  if (set) CM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)set));
+  CM_TRY(cm_lds_table_raise(ctx->device, fn, bytes, floor_bytes, cm_lds_set_attribute, nullptr, nullptr));
   ctx->lds_attr[slot] = bytes;
   return CM_OK;
 }

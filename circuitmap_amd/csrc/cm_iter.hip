@@ -202,10 +202,13 @@ static int launch_iter2(cm_ctx* ctx, cm_set& s, const IterDyn& a0, size_t lds, i
     hipLaunchKernelGGL((k_iter_mid<true, SEG, false, true>), dim3(blocks, s.B), dim3(threads), lds, ctx->stream, cm_parg<true>{s.d_arr}, a0);
     {
       const int waves = threads / CM_WAVE, covered = (blocks - 2) * waves;
-      if (covered < s.lead->N)                           // (a grid that already covers N rows cannot be outgrown)
+      if (covered < s.lead->N) {                         // (a grid that already covers N rows cannot be outgrown)
+        CM_TRY(cm_raise_lds(ctx, CM_LDS_ITER_OVERFLOW + (31 - __builtin_clz((unsigned)SEG)), reinterpret_cast<const void*>(k_iter_overflow<SEG>), (size_t)waves * lds_waves, 48 * 1024));
         hipLaunchKernelGGL((k_iter_overflow<SEG>), dim3(8, s.B), dim3(threads), (size_t)waves * lds_waves, ctx->stream, cm_parg<true>{s.d_arr}, a0, covered);
+      }
     }
     if (between) CM_HIP(hipEventRecord(between, ctx->stream));
+    CM_TRY(cm_raise_lds(ctx, CM_LDS_MC_DEAD_B, reinterpret_cast<const void*>(k_mc_dead<true>), 4 * lds_waves, 48 * 1024));   // (num_mc_samples > 768)
     CM_LAUNCH_SET(k_mc_dead, s, (s.lead->N + 3) / 4, 256, 4 * lds_waves, ctx->stream, a0);
   } else {
     CM_LAUNCH_SET_T(k_iter_mid, (SEG, FULLMC), s, blocks, threads, lds, ctx->stream, a0);

@@ -929,7 +929,7 @@ int cm_solve_launch(cm_ctx* ctx, cm_set& s, int skip_mode, hipEvent_t fact_begin
         CM_LAUNCH_G(k_chol_panel, tp * (tp + 1) / 2, 1024, 0, na1, skip_le, j, large_min);
       }
     }
-    if (c0 + G >= s.B && fact_end) CM_HIP(hipEventRecord(fact_end, st));
+    if (fact_end) CM_HIP(hipEventRecord(fact_end, st));   // after EVERY group that factorised (a group without tiled circuits skips the loop body above): the last record stands
     // inverse of the factor (strictly-upper tiles of X are never read: no clearing needed)
     CM_LAUNCH_G(k_inv_seed, nblk, 256, 0, na1, skip_le);
     for (int b = 1; b < nblk; b *= 2) {

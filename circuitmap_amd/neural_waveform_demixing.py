@@ -40,6 +40,29 @@ def load_checkpoint_state(path):
     return {k: v.detach().cpu().numpy() for k, v in sd.items() if hasattr(v, "detach")}
 
 
+def random_parameters(seed=0):
+    """Seeded random parameters under the reference's names and shapes (NumPy only): inputs for benchmarks and smoke runs when no
+    trained checkpoint is at hand (PyTorch-style uniform(-1/sqrt(fan_in), 1/sqrt(fan_in)) weights, non-trivial BatchNorm statistics;
+    the single output channel is kept alive so the last ReLU does not return all zeros)."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+    for conv, shape in _SHAPES.items():
+        block = conv.split(".")[0]
+        is_conv = conv.endswith(".conv")
+        cout = shape[0] if is_conv else shape[1]
+        fan_in = shape[1] * shape[2]                      # Conv1d [out, in, k] -> in * k; ConvTranspose1d [in, out, k] -> out * k
+        bound = 1.0 / np.sqrt(fan_in)
+        sd[conv + ".weight"] = rng.uniform(-bound, bound, shape).astype(np.float32)
+        sd[conv + ".bias"] = rng.uniform(-bound, bound, cout).astype(np.float32)
+        sd[block + ".bn.weight"] = rng.uniform(0.75, 1.25, cout).astype(np.float32)
+        sd[block + ".bn.bias"] = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+        sd[block + ".bn.running_mean"] = (0.2 * rng.standard_normal(cout)).astype(np.float32)
+        sd[block + ".bn.running_var"] = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sd["conv.bn.bias"] = np.abs(sd["conv.bn.bias"]) + np.float32(0.25)
+    sd["conv.bn.running_mean"] = np.zeros(1, dtype=np.float32)
+    return sd
+
+
 class NeuralDemixer:
     """Mirror of the reference class (:17-34).  `path` = checkpoint; alternatively `state` = dict of parameter arrays under
     the reference's names.  `device` = 'cuda', 'cuda:<i>' or an int; anything that is not a GPU raises (no CPU path)."""
@@ -68,7 +91,8 @@ class NeuralDemixer:
             self._fill(prm.ublock[i], state, name, name + ".deconv")
         self._fill(prm.conv, state, "conv", "conv.conv")
         prm.bn_eps = BN_EPS
-        _lib.check(self.lib.cm_nwd_create(self.ctx.handle, C.byref(prm), C.byref(self.handle)))
+        with self.ctx.lock:
+            _lib.check(self.lib.cm_nwd_create(self.ctx.handle, C.byref(prm), C.byref(self.handle)))
         self._keep = []             # the library has copied (and folded) everything
 
     def _fill(self, blk, state, block, conv):
@@ -103,9 +127,10 @@ class NeuralDemixer:
         out = np.empty((K, T), dtype=np.float64)
         raw = np.empty((K, T), dtype=np.float32) if return_raw else None
         ms = C.c_float(0.0)
-        _lib.check(self.lib.cm_nwd_demix(self.ctx.handle, self.handle, K, T, traces.ctypes.data_as(C.c_void_p), _lib.CM_MEM_HOST,
-                                         int(monotone_filter_start), out.ctypes.data_as(C.c_void_p),
-                                         raw.ctypes.data_as(C.c_void_p) if return_raw else None, _lib.CM_MEM_HOST, C.byref(ms)))
+        with self.ctx.lock:
+            _lib.check(self.lib.cm_nwd_demix(self.ctx.handle, self.handle, K, T, traces.ctypes.data_as(C.c_void_p), _lib.CM_MEM_HOST,
+                                             int(monotone_filter_start), out.ctypes.data_as(C.c_void_p),
+                                             raw.ctypes.data_as(C.c_void_p) if return_raw else None, _lib.CM_MEM_HOST, C.byref(ms)))
         self.last_kernel_ms = float(ms.value)
         t2 = time.time()
         if verbose:
@@ -117,9 +142,10 @@ class NeuralDemixer:
         ``tensor.data_ptr()``); the result can be handed to ``cm_problem_create(..., CM_MEM_DEVICE)`` without touching
         the host.  Returns the kernel time in ms."""
         ms = C.c_float(0.0)
-        _lib.check(self.lib.cm_nwd_demix(self.ctx.handle, self.handle, int(K), int(T), C.c_void_p(traces_ptr), _lib.CM_MEM_DEVICE,
-                                         int(monotone_filter_start), C.c_void_p(out_ptr),
-                                         C.c_void_p(raw_ptr) if raw_ptr else None, _lib.CM_MEM_DEVICE, C.byref(ms)))
+        with self.ctx.lock:
+            _lib.check(self.lib.cm_nwd_demix(self.ctx.handle, self.handle, int(K), int(T), C.c_void_p(traces_ptr), _lib.CM_MEM_DEVICE,
+                                             int(monotone_filter_start), C.c_void_p(out_ptr),
+                                             C.c_void_p(raw_ptr) if raw_ptr else None, _lib.CM_MEM_DEVICE, C.byref(ms)))
         return float(ms.value)
 
     def train(self, *args, **kwargs):
@@ -129,7 +155,8 @@ class NeuralDemixer:
 
     def close(self):
         if getattr(self, "handle", None):
-            self.lib.cm_nwd_destroy(self.handle)
+            with self.ctx.lock:
+                self.lib.cm_nwd_destroy(self.handle)
             self.handle = C.c_void_p()
 
     def __del__(self):

@@ -207,7 +207,8 @@ def simulate_device(powers=(45, 55, 65), design="blockwise", device_id=0, keep_o
         for k, p in dsmall.items():
             setattr(res, k, p)
         try:
-            _lib.check(lib.cm_simulate(ctx.handle, C.byref(o), dcode, C.byref(res), _lib.CM_MEM_DEVICE, C.byref(ms)))
+            with ctx.lock:
+                _lib.check(lib.cm_simulate(ctx.handle, C.byref(o), dcode, C.byref(res), _lib.CM_MEM_DEVICE, C.byref(ms)))
             for k, v in small.items():
                 ctx.download(dsmall[k], v)
         except Exception:
@@ -223,7 +224,8 @@ def simulate_device(powers=(45, 55, 65), design="blockwise", device_id=0, keep_o
         big.update(spks=np.empty((N, K)), spk_times=np.empty((N, K)), gp_noise=np.empty((K, T)), spont_pscs=np.empty((K, T)))
     for k, v in list(small.items()) + list(big.items()):
         setattr(res, k, v.ctypes.data)
-    _lib.check(lib.cm_simulate(ctx.handle, C.byref(o), dcode, C.byref(res), _lib.CM_MEM_HOST, C.byref(ms)))
+    with ctx.lock:
+        _lib.check(lib.cm_simulate(ctx.handle, C.byref(o), dcode, C.byref(res), _lib.CM_MEM_HOST, C.byref(ms)))
     out = dict(small)
     out.update(big)
     out.update(sigma=o.sigma, kernel=None, mult_noise=None, device_ms=float(ms.value))

@@ -39,6 +39,12 @@ typedef enum cm_status {
 
 #define CM_MAX_VALS 64        /* distinct values of the stimulus matrix (0 and the laser powers) */
 
+/* ABI handshake.  Bumped whenever the layout of a struct of this header changes (history: 1 = round 1; 2 = cm_timings re-laid out
+ * in round 2; 3 = this field + cm_timings.scan_*).  cm_options_default() writes it into cm_options.abi_version and every entry point
+ * that takes a cm_options refuses (CM_ERR_INVALID) a value other than the library's own: a caller compiled against another header
+ * gets an error code instead of silently mis-read fields or an overrun cm_timings.  cm_abi_version() returns the library's value. */
+#define CM_ABI_VERSION 3
+
 typedef enum cm_mem_kind { CM_MEM_HOST = 0, CM_MEM_DEVICE = 1 } cm_mem_kind;
 typedef enum cm_rng_mode {
   CM_RNG_THREEFRY = 0,        /* counter-based Threefry-2x32-20 keyed by `seed`, jax.random conventions
@@ -61,6 +67,7 @@ typedef struct cm_priors {
 
 /* Mirrors every keyword of caviar() (caviar.py:21-23), same names and defaults (see cm_options_default). */
 typedef struct cm_options {
+  int32_t abi_version;             /* CM_ABI_VERSION of the header the caller was compiled against (set by cm_options_default) */
   int32_t iters;
   int32_t num_mc_samples;
   uint64_t seed;
@@ -135,6 +142,7 @@ typedef struct cm_timings {
 
 const char* cm_last_error(void);
 const char* cm_version(void);
+int cm_abi_version(void);                 /* CM_ABI_VERSION the library was built with */
 int cm_device_count(void);
 
 void cm_options_default(cm_options* o);   /* defaults of caviar.py:21-23 */
@@ -231,6 +239,11 @@ int cm_k_event_pair_overhead(cm_ctx* ctx, int32_t reps, int32_t blocks, int32_t 
  * force for a (kernel, device), so the library keeps one process-wide table and only ever raises it.  Returns the value the runtime
  * would be called with for this request (0 = the value in force already covers it).  `kernel_key` is an arbitrary test key. */
 int64_t cm_test_lds_request(int32_t device, uint64_t kernel_key, uint64_t bytes, uint64_t floor_bytes);
+/* The same bookkeeping under contention: n_threads host threads issue interleaved, growing requests for one (device, kernel) against a
+ * recording stand-in for the runtime call, which the library invokes while holding the table's lock.  out[0] = value the stand-in holds at
+ * the end, out[1] = largest request issued, out[2] = calls made, out[3] = value applied by a repeat of out[0] (must be 0).  fail_above > 0:
+ * the stand-in refuses larger values and the table must not record them. */
+int cm_test_lds_race(uint64_t kernel_key, int32_t n_threads, int32_t reps, uint64_t base, uint64_t step, uint64_t fail_above, uint64_t* out);
 
 #ifdef __cplusplus
 }

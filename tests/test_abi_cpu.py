@@ -153,3 +153,29 @@ def test_dynamic_lds_caps_are_only_ever_raised(lib):
     assert lib.cm_test_lds_request(0, key, 150 * 1024, 48 * 1024) == 150 * 1024   # genuine growth
     assert lib.cm_test_lds_request(1, key, 110 * 1024, 48 * 1024) == 110 * 1024   # another device has its own value
     assert lib.cm_test_lds_request(0, key + 1, 60 * 1024, 0) == 60 * 1024         # another kernel too
+
+
+def test_dynamic_lds_raise_is_atomic_under_contention(lib):
+    """the runtime call that raises a kernel's dynamic-LDS cap happens UNDER the table's lock, so that two host threads
+    (contexts on one GPU) cannot apply their values in the opposite order of their table updates.  8 threads x 50 interleaved, growing
+    requests against a recording stand-in for hipFuncSetAttribute (20 us per call, to widen any window): the value in force at the end is
+    the largest request, and the table agrees with it (a repeat of that request applies nothing)."""
+    out = (C.c_uint64 * 4)()
+    assert lib.cm_test_lds_race(777, 8, 50, 50 * 1024, 64, 0, out) == 0
+    assert out[0] == out[1] == 50 * 1024 + (8 * 50 - 1) * 64
+    assert 1 <= out[2] <= 400 and out[3] == 0
+    # a value the runtime refuses is not recorded: the table keeps the last accepted one
+    assert lib.cm_test_lds_race(778, 4, 20, 10 * 1024, 1024, 40 * 1024, out) == 0
+    assert out[0] == 40 * 1024 and out[3] == 0
+
+
+def test_abi_version_handshake(lib):
+    """cm_options carries the ABI version of the header the caller was built against; the library refuses any other (the
+    cm_timings layout changed without a version bump)."""
+    from circuitmap_amd import _lib
+    text = header_text()
+    assert int(re.search(r"#define CM_ABI_VERSION (\d+)", text).group(1)) == _lib.CM_ABI_VERSION == lib.cm_abi_version()
+    o = _lib.CmOptions()
+    lib.cm_options_default(C.byref(o))
+    assert o.abi_version == _lib.CM_ABI_VERSION
+    assert b"ABI %d" % _lib.CM_ABI_VERSION in lib.cm_version()

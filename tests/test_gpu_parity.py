@@ -598,3 +598,98 @@ def test_caviar_vs_golden_cfg2():
             hist = hist[:, 0]
         assert rel_err(got, g["out_" + nm]) < TOL_FINAL * 100, nm             # 12 iterations: still inside the amplified early phase
         assert rel_err(hist, g["out_hist_" + nm]) < TOL_HIST, "hist " + nm
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The launch configuration bench.py times: lock-step batches with SEVERAL circuits per XCD (B = 16, 128), the listed-rows grid at
+# that size, the host scan pool, and the same circuits as 4 x 32 on four contexts.  (Unit of scale-out this replaces: one process
+# per circuit, reference scripts/generate_loho_cv_slurm_scripts.py:8-36.)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _device_circuits(cx, N, K, B, seed0, T=900, host_copy_of=()):
+    """B circuits generated on the device (include/sim_hip.h) as Problems of context `cx`; host copies (psc, stim) of the listed ones"""
+    from circuitmap_amd.optimise.caviar import Problem
+    from circuitmap_amd.simulation import simulate_device
+    probs, host = [], {}
+    for c in range(B):
+        d = simulate_device(N=N, T=T, H=10, trials=K, seed=seed0 + c, keep_on_device=True, ctx=cx)
+        if c in host_copy_of:
+            host[c] = (cx.download(d["psc_ptr"], np.empty((K, T))), cx.download(d["stim_ptr"], np.empty((N, K))))
+        probs.append(Problem(cx, None, None, device_ptrs=(N, K, T, d["psc_ptr"], d["stim_ptr"])))
+        cx.free(d["psc_ptr"]); cx.free(d["stim_ptr"])
+    return probs, host
+
+
+@pytest.mark.parametrize("N,K,B,iters", [(200, 400, 16, 14), (200, 400, 128, 14), (1000, 2000, 16, 50), (1000, 2000, 128, 50)])
+def test_run_batch_many_per_xcd(ctx, N, K, B, iters):
+    """cm_caviar_run_batch with 2 and 16 circuits per XCD (cm_xcd_remap mode 3 with per > 1, which needs gridDim.y % 8 == 0): every
+    circuit bit-identical to its own cm_caviar_run; circuit 0 within 1e-6 of the running-residual oracle (the small shape; the
+    N = 1000 oracle trajectory is test_caviar_vs_oracle_bench_sizes).  N = 200 / K = 400 starts with a 7-tile-row tiled solve;
+    (1000, 2000, 128) is bench.py's default step."""
+    from circuitmap_amd.optimise.caviar import run_batch
+    from oracle import caviar_oracle as co
+    pri = default_priors(N)
+    opts = dict(iters=iters, seed=0)
+    probs, host = _device_circuits(ctx, N, K, B, 4000, host_copy_of=(0,) if N <= 200 else ())
+    tms = run_batch(probs, pri, **opts)
+    assert all(t.batch == B for t in tms)
+    batch = [q.fetch() for q in probs]
+    for c, q in enumerate(probs):
+        q.run(*prior_args(pri), **opts)
+        _assert_same_fit(batch[c], q.fetch(), "B=%d circuit %d" % (B, c))
+    if host:
+        ref = co.caviar(host[0][0], host[0][1], *prior_args(pri), literal=False, **opts)
+        for i, nm in enumerate(OUT_NAMES):
+            assert rel_err(batch[0][i], ref[i]) < 1e-6, nm
+    assert np.count_nonzero(batch[0][0]) > 0
+    for q in probs:
+        q.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_run_batch_xcd_placement_never_matters(ctx, monkeypatch, mode):
+    """CAVIAR_HIP_XCD_MODE = 0 (plain grid), 1 (interleaved), 2 (circuit-major) give bitwise the results of the default mode 3:
+    the workgroup -> (tile, circuit) map is a speed heuristic only."""
+    from circuitmap_amd import _lib
+    from circuitmap_amd.optimise.caviar import run_batch
+    N, K, B = 200, 400, 16
+    pri = default_priors(N)
+    opts = dict(iters=8, seed=0)
+    probs, _ = _device_circuits(ctx, N, K, B, 4000)
+    run_batch(probs, pri, **opts)
+    ref = [q.fetch() for q in probs]
+    for q in probs:
+        q.close()
+    monkeypatch.setenv("CAVIAR_HIP_XCD_MODE", str(mode))
+    other = _lib.Context(0)                                   # the mode is read when a context is created
+    monkeypatch.delenv("CAVIAR_HIP_XCD_MODE")
+    probs, _ = _device_circuits(other, N, K, B, 4000)
+    run_batch(probs, pri, **opts)
+    for c, q in enumerate(probs):
+        _assert_same_fit(q.fetch(), ref[c], "xcd mode %d circuit %d" % (mode, c))
+        q.close()
+    other.close()
+
+
+def test_fit_batch_128_as_4x32_streams(ctx):
+    """bench.py's `interleaved_streams` leg and fit_batch's default: 128 circuits of the headline shape as 4 lock-step batches of 32 on
+    four contexts (HIP streams + mailboxes), one host thread each -- every circuit bit-identical to its own single fit."""
+    from circuitmap_amd import batch
+    from circuitmap_amd.optimise.caviar import Problem
+    from circuitmap_amd.simulation import simulate_device
+    N, K, B = 1000, 2000, 128
+    pri = default_priors(N)
+    opts = dict(iters=50, seed=0)
+    circuits = []
+    for c in range(B):
+        d = simulate_device(N=N, T=900, H=10, trials=K, seed=2000 + c, full=False, ctx=ctx)
+        circuits.append((d["psc"], d["stim_matrix"]))
+    got = batch.fit_batch(circuits, priors=pri, fit_options=opts, circuits_per_launch=32, streams=4)
+    assert len(got) == B
+    for c, (psc, stim) in enumerate(circuits):
+        q = Problem(ctx, psc, stim)
+        q.run(*prior_args(pri), **opts)
+        res = q.fetch(want_lam=False)
+        q.close()
+        for i, nm in enumerate(OUT_NAMES):
+            if nm != "lam":
+                np.testing.assert_array_equal(np.asarray(res[i], dtype=float), np.asarray(got[c][nm], dtype=float), err_msg="circuit %d %s" % (c, nm))
