@@ -122,6 +122,7 @@ static int ctx_init(cm_ctx* c, int device_id, void* hip_stream) {
   c->use_mailbox = getenv("CAVIAR_HIP_NO_MAILBOX") == nullptr;
   if (const char* e = getenv("CAVIAR_HIP_SOLVE_GROUP")) c->solve_group = atoi(e);
   if (const char* e = getenv("CAVIAR_HIP_XCD_MODE")) c->xcd_mode = atoi(e);
+  if (const char* e = getenv("CAVIAR_HIP_CHOL_FAMILY")) c->chol_family = atoi(e);
   if (getenv("CAVIAR_HIP_TRACE_BLOCK0")) { CM_HIP(hipMalloc((void**)&c->dbg_block0, 64 * 8 * sizeof(long long))); CM_HIP(hipMemset(c->dbg_block0, 0, 64 * 8 * sizeof(long long))); }
   hipDeviceProp_t prop;
   CM_HIP(hipGetDeviceProperties(&prop, device_id));

@@ -104,6 +104,7 @@ struct cm_ctx {
   bool use_mailbox = true;
   int solve_group = 0;           // circuits per group of the tiled solve of a batch (0: the whole batch in lock-step); CAVIAR_HIP_SOLVE_GROUP
   int xcd_mode = 3;              // cm_xcd_remap mode of the bandwidth-bound solve kernels; CAVIAR_HIP_XCD_MODE
+  int chol_family = 1;           // tiled Cholesky of batches and large matrices: 1 = grouped (four panels per pass, 64 x 64 super-tiles), 0 = panel pairs; CAVIAR_HIP_CHOL_FAMILY (both give bitwise the same factor)
   int num_cus = 256;
   void* h_stage = nullptr;        // pinned staging buffer (priors upload, fn_scan round trip), grown on demand
   size_t h_stage_bytes = 0;
@@ -419,7 +420,8 @@ inline void cm_threefry2x32(uint32_t k0, uint32_t k1, uint32_t& x0, uint32_t& x1
 // lower bounds of that table (valid because the table never decreases), so the common launch pays no lock and no runtime call.
 enum cm_lds_slot { CM_LDS_ITER = 0 /* 7 x 2 x 2 template variants */, CM_LDS_SOLVE_SMALL = 28, CM_LDS_SWEEP_PAR, CM_LDS_SWEEP_PAR2, CM_LDS_SWEEP_SEQ,
                    CM_LDS_NWD, CM_LDS_SIM_SORT, CM_LDS_BUILD_PREC, CM_LDS_SWEEP_PAR_B, CM_LDS_SWEEP_PAR2_B, CM_LDS_SWEEP_SEQ_B,
-                   CM_LDS_SOLVE_SMALL_B, CM_LDS_BUILD_PREC_B, CM_LDS_ITER_LISTED /* 7 SEG variants */, CM_LDS_MC_DEAD = 47, CM_LDS_MC_DEAD_B, CM_LDS_ITER_OVERFLOW /* 7 SEG variants */, CM_LDS_SLOTS = 56 };
+                   CM_LDS_SOLVE_SMALL_B, CM_LDS_BUILD_PREC_B, CM_LDS_ITER_LISTED /* 7 SEG variants */, CM_LDS_MC_DEAD = 47, CM_LDS_MC_DEAD_B, CM_LDS_ITER_OVERFLOW /* 7 SEG variants */, CM_LDS_CHOL_DIAG = 56, CM_LDS_CHOL_GPANEL, CM_LDS_CHOL_WIDE,
+                   CM_LDS_CHOL_DIAG_B, CM_LDS_CHOL_GPANEL_B, CM_LDS_CHOL_WIDE_B, CM_LDS_SLOTS = 62 };
 static_assert(CM_LDS_SLOTS <= 64, "cm_ctx::lds_attr");
 // Table update AND runtime call under ONE lock: `set(fn, bytes, user)` is invoked while the table's mutex is held, and the table takes
 // the new value only after the setter succeeded -- two host threads (contexts on one GPU) can therefore never apply their values in

@@ -558,6 +558,257 @@ __global__ __launch_bounds__(256) void k_chol_bulk(cm_parg<BATCH> pa, int na_arg
   tile_store(Dinv + (size_t)(WIDE ? j + 2 : j + 1) * TS * TS, TS, Sm[1]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// GROUPED family (every batch, and single matrices above CM_LARGE_TILES tile rows): the panels go in groups of CM_GRP = 4 tile columns and
+// the trailing matrix is read and rewritten once per 128 columns, by workgroups that own a 64 x 64 SUPER-TILE of it:
+//   k_chol_diag(0)        factors the first 4 x 4 block of tiles on the diagonal (one workgroup; tiles in registers, operands through LDS)
+//   per group g (first tile column j0 = 4 g), while tile rows remain below the group:
+//     k_chol_gpanel(j0)   one workgroup per trailing tile row i: X^p_i = (A[i][j0+p] - sum_{p' < p} X^p'_i L[j0+p][j0+p']^T) L_pp^-T, p = 0..3
+//     k_chol_wide(j0)     one workgroup per super-tile (2 x 2 tiles, one 32 x 32 tile = four 16 x 16 matrix-core blocks per wavefront):
+//                         A[i][l] = (((A[i][l] - X^0_i X^0_l^T) - X^1_i X^1_l^T) - X^2_i X^2_l^T) - X^3_i X^3_l^T; the panel tiles of a super-tile
+//                         are staged once for its four output tiles (double-buffered in LDS, the next panel's loads in flight behind 32 matrix
+//                         instructions per wavefront) -- per tile product 12 KB move between L2 and a CU where the pair family moves 24 KB,
+//                         and the trailing matrix goes through HBM once per four panels instead of once per two.  Workgroup 0 takes the
+//                         three super-tiles that hold the NEXT group's diagonal block and then factors that block (chol_diag_block), so the
+//                         serial part of the next group runs beside the bulk of this one.
+// Every tile product is its own matrix-core accumulation from zero over the tile's 32 columns and the subtractions happen in panel order:
+// each tile holds bitwise what one rank-32 update per panel leaves (k_chol_panel, the pair family).
+// ------------------------------------------------------------------------------------------------
+#define CM_GRP 4
+#define CM_GSLOTS 8                                   // tile slots of dynamic LDS (TS x TP doubles each)
+static constexpr size_t CM_GROUP_LDS = (size_t)CM_GSLOTS * TS * TP * sizeof(double);
+typedef double (*cm_tile_t)[TP];
+__device__ __forceinline__ cm_tile_t cm_slot(double* sm, int s) { return reinterpret_cast<cm_tile_t>(sm + (size_t)s * TS * TP); }
+// a wavefront's 16 x 16 block (rb, cb) of a 32 x 32 tile <-> 4 registers (the matrix-core accumulator layout)
+__device__ __forceinline__ void blk_gload(double (&o)[4], const double* tile, int ld, int rb, int cb, int lane) {
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) o[reg] = cm_gload(tile, ((unsigned)BLK_ROW(rb, lane, reg) * (unsigned)ld + (unsigned)BLK_COL(cb, lane)) * 8u);
+}
+__device__ __forceinline__ void blk_gstore(double* tile, int ld, int rb, int cb, int lane, const double (&o)[4]) {
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) cm_gstore(tile, ((unsigned)BLK_ROW(rb, lane, reg) * (unsigned)ld + (unsigned)BLK_COL(cb, lane)) * 8u, o[reg]);
+}
+__device__ __forceinline__ void blk_put(cm_tile_t dst, int rb, int cb, int lane, const double (&o)[4]) {
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) dst[BLK_ROW(rb, lane, reg)][BLK_COL(cb, lane)] = o[reg];
+}
+__device__ __forceinline__ void blk_sub(double (&o)[4], const cm_d4& c) {
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) o[reg] -= c[reg];
+}
+
+// Factorisation of the gs x gs block of tiles (gs <= 4) on the diagonal at tile (j0, j0), whose tiles have received every update of the
+// earlier panels and are read from A: the right-looking sequence of the other families restricted to the block -- L_pp^-1 by the
+// register-resident elimination, X_q = A[q][p] L_pp^-T, A[q][r] -= X_q X_r^T -- by ONE 256-thread workgroup.  The (up to) ten tiles live in
+// registers in the accumulator layout (a 16 x 16 block of every tile per wavefront: the products subtract in place), matrix-core
+// operands go through five LDS slots.  Writes Dinv[j0 ..] and the block's tiles of Lf.
+__device__ __forceinline__ void chol_diag_block(const cm_pdev& p, double* sm, int j0, int gs, int ld) {
+  const double* __restrict__ A = p.A;
+  double* __restrict__ Lf = p.Lf;
+  double* __restrict__ Dinv = p.Dinv;
+  int* __restrict__ flag = p.n_act + 1;
+  const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE, rb = wave >> 1, cb = wave & 1;
+  cm_tile_t C = cm_slot(sm, 0), Li = cm_slot(sm, 1);
+  double D[10][4];                                                  // tile (q, r), r <= q, at index q (q + 1) / 2 + r
+#pragma unroll
+  for (int q = 0; q < CM_GRP; ++q)
+#pragma unroll
+    for (int r = 0; r <= q; ++r)
+      if (q < gs) blk_gload(D[q * (q + 1) / 2 + r], A + (size_t)(j0 + q) * TS * ld + (size_t)(j0 + r) * TS, ld, rb, cb, lane);
+#pragma unroll
+  for (int pp = 0; pp < CM_GRP; ++pp) {
+    if (pp >= gs) break;
+    blk_put(C, rb, cb, lane, D[pp * (pp + 1) / 2 + pp]);
+    __syncthreads();
+    tile_linv_reg(C, Li, flag);                                      // (ends on a barrier)
+    {
+      double* dst = Dinv + (size_t)(j0 + pp) * TS * TS;
+      for (int i = threadIdx.x; i < TS * TS; i += 256) dst[i] = Li[i / TS][i % TS];
+    }
+#pragma unroll
+    for (int q = pp + 1; q < CM_GRP; ++q)
+      if (q < gs) blk_put(cm_slot(sm, 2 + q - pp - 1), rb, cb, lane, D[q * (q + 1) / 2 + pp]);
+    __syncthreads();
+    double x[CM_GRP - 1][4];
+#pragma unroll
+    for (int q = pp + 1; q < CM_GRP; ++q)
+      if (q < gs) {
+        cm_d4 c = {0.0, 0.0, 0.0, 0.0};
+        c = blk_mfma_nt(c, cm_slot(sm, 2 + q - pp - 1), Li, rb, cb, lane);       // X_q = A[q][p] L_pp^-T
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) x[q - pp - 1][reg] = c[reg];
+      }
+    __syncthreads();                                                 // every wave has read the unsolved tiles: the solved ones replace them
+#pragma unroll
+    for (int q = pp + 1; q < CM_GRP; ++q)
+      if (q < gs) {
+        blk_put(cm_slot(sm, 2 + q - pp - 1), rb, cb, lane, x[q - pp - 1]);
+        blk_gstore(Lf + (size_t)(j0 + q) * TS * ld + (size_t)(j0 + pp) * TS, ld, rb, cb, lane, x[q - pp - 1]);
+      }
+    __syncthreads();
+#pragma unroll
+    for (int q = pp + 1; q < CM_GRP; ++q)
+#pragma unroll
+      for (int r = pp + 1; r <= q; ++r)
+        if (q < gs) {
+          cm_d4 c = {0.0, 0.0, 0.0, 0.0};
+          c = blk_mfma_nt(c, cm_slot(sm, 2 + q - pp - 1), cm_slot(sm, 2 + r - pp - 1), rb, cb, lane);
+          blk_sub(D[q * (q + 1) / 2 + r], c);
+        }
+    __syncthreads();                                                 // the solved tiles are dead: the next pivot tile may overwrite the slots
+  }
+}
+
+template <bool BATCH>
+__global__ __launch_bounds__(256) void k_chol_diag(cm_parg<BATCH> pa, int na_arg, int skip_own, int j0, int large_min) {
+  CM_SOLVE_PROLOGUE(2)
+  (void)large_min;                                   // (a one-tile matrix of a batch is factored here too: nothing else touches it)
+  if (na == 0 || j0 >= nblk) return;
+  extern __shared__ double sm_dyn[];
+  chol_diag_block(p, sm_dyn, j0, min(CM_GRP, nblk - j0), ld);
+}
+
+// Panel solve of a group for one trailing tile row (see above).  LDS slots: 0-2 the solved tiles X^0..X^2 of the row, 3 the tile being
+// solved, 4-6 the block's tiles L[j0+q][j0+p] of the current column q, 7 L_qq^-1.  All fourteen tiles are requested before the first is used.
+template <bool BATCH>
+__global__ __launch_bounds__(256, 2) void k_chol_gpanel(cm_parg<BATCH> pa, int na_arg, int skip_own, int j0, int large_min) {
+  int bx = (int)blockIdx.x, circ = 0;
+  if (BATCH) cm_xcd_remap(bx, circ, skip_own >> 8);
+  CM_SOLVE_PROLOGUE_AT(2, pa.get(circ))
+  const int t = nblk - j0 - CM_GRP;                  // trailing tile rows (a group with rows below it is CM_GRP panels wide)
+  if (nblk <= large_min || bx >= t) return;
+  const double* __restrict__ A = p.A;
+  double* __restrict__ Lf = p.Lf;
+  const double* __restrict__ Dinv = p.Dinv;
+  extern __shared__ double sm_dyn[];
+  const int i = j0 + CM_GRP + bx;
+  const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE, rb = wave >> 1, cb = wave & 1;
+  double a[CM_GRP][4], rl[CM_GRP * (CM_GRP - 1) / 2][4], rd[CM_GRP][4];
+#pragma unroll
+  for (int q = 0; q < CM_GRP; ++q) blk_gload(a[q], A + (size_t)i * TS * ld + (size_t)(j0 + q) * TS, ld, rb, cb, lane);
+#pragma unroll
+  for (int q = 0; q < CM_GRP; ++q) {
+    tile_fetch(rd[q], Dinv + (size_t)(j0 + q) * TS * TS, TS);
+#pragma unroll
+    for (int pp = 0; pp < q; ++pp) tile_fetch(rl[q * (q - 1) / 2 + pp], Lf + (size_t)(j0 + q) * TS * ld + (size_t)(j0 + pp) * TS, ld);
+  }
+  cm_tile_t P = cm_slot(sm_dyn, 3), Dv = cm_slot(sm_dyn, 7);
+#pragma unroll
+  for (int q = 0; q < CM_GRP; ++q) {
+#pragma unroll
+    for (int pp = 0; pp < q; ++pp) tile_put(cm_slot(sm_dyn, 4 + pp), rl[q * (q - 1) / 2 + pp]);
+    tile_put(Dv, rd[q]);
+    __syncthreads();
+#pragma unroll
+    for (int pp = 0; pp < q; ++pp) {                 // updates of tile (i, j0 + q) by the earlier panels of the group, in panel order
+      cm_d4 c = {0.0, 0.0, 0.0, 0.0};
+      c = blk_mfma_nt(c, cm_slot(sm_dyn, pp), cm_slot(sm_dyn, 4 + pp), rb, cb, lane);
+      blk_sub(a[q], c);
+    }
+    blk_put(P, rb, cb, lane, a[q]);
+    __syncthreads();
+    cm_d4 x = {0.0, 0.0, 0.0, 0.0};
+    x = blk_mfma_nt(x, P, Dv, rb, cb, lane);         // X^q_i = P L_qq^-T
+    double xr[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) xr[reg] = x[reg];
+    blk_gstore(Lf + (size_t)i * TS * ld + (size_t)(j0 + q) * TS, ld, rb, cb, lane, xr);
+    if (q + 1 < CM_GRP) blk_put(cm_slot(sm_dyn, q), rb, cb, lane, xr);
+    __syncthreads();                                 // X^q is in place; P, Dv and the L slots may be overwritten
+  }
+}
+
+// one super-tile (I, L) of the trailing matrix below group j0: see above.  Slots: stage s holds the row-side tiles (2 s', s' = 0, 1 ->
+// slots 4 s + s') and the column-side tiles (slots 4 s + 2 + s').
+__device__ __forceinline__ void chol_wide_supertile(const cm_pdev& p, double* sm, int j0, int nblk, int ld, int I, int L) {
+  double* __restrict__ A = p.A;
+  const double* __restrict__ Lf = p.Lf;
+  const int r0 = j0 + CM_GRP;
+  const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE, qi = wave >> 1, ql = wave & 1;
+  const int ti = r0 + 2 * I + qi, tl = r0 + 2 * L + ql;
+  const bool valid = ti < nblk && tl <= ti;          // the wavefront's tile exists and lies on or below the diagonal
+  // tile rows the stage loads read (a missing second row of the last super-row re-reads the last row: loaded, never used)
+  const int ri0 = r0 + 2 * I, ri1 = min(ri0 + 1, nblk - 1), rl0 = r0 + 2 * L, rl1 = min(rl0 + 1, nblk - 1);
+  double o[2][2][4];
+  double* out = A + (size_t)ti * TS * ld + (size_t)tl * TS;
+  if (valid) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) blk_gload(o[rb][cb], out, ld, rb, cb, lane);
+  }
+  double st[4][4];                                   // the stage in flight: 4 tiles x 4 elements per thread
+  auto fetch = [&](int pp) {
+    const size_t cj = (size_t)(j0 + pp) * TS;
+    tile_fetch(st[0], Lf + (size_t)ri0 * TS * ld + cj, ld);
+    tile_fetch(st[1], Lf + (size_t)ri1 * TS * ld + cj, ld);
+    tile_fetch(st[2], Lf + (size_t)rl0 * TS * ld + cj, ld);
+    tile_fetch(st[3], Lf + (size_t)rl1 * TS * ld + cj, ld);
+  };
+  auto put = [&](int s) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tile_put(cm_slot(sm, 4 * s + k), st[k]);
+  };
+  fetch(0);
+  put(0);
+#pragma unroll
+  for (int pp = 0; pp < CM_GRP; ++pp) {
+    if (pp + 1 < CM_GRP) fetch(pp + 1);              // in flight behind this panel's 32 matrix instructions
+    __syncthreads();
+    if (valid) {
+      const double (*Ai)[TP] = cm_slot(sm, 4 * (pp & 1) + qi);
+      const double (*Bl)[TP] = cm_slot(sm, 4 * (pp & 1) + 2 + ql);
+      const int r = lane & 15, kk = lane >> 4;
+      cm_d4 c00 = {0.0, 0.0, 0.0, 0.0}, c01 = c00, c10 = c00, c11 = c00;
+#pragma unroll
+      for (int ks = 0; ks < TS / 4; ++ks) {
+        const double a0 = Ai[r][4 * ks + kk], a1 = Ai[16 + r][4 * ks + kk], b0 = Bl[r][4 * ks + kk], b1 = Bl[16 + r][4 * ks + kk];
+        c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c00, 0, 0, 0);
+        c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, c01, 0, 0, 0);
+        c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, c10, 0, 0, 0);
+        c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c11, 0, 0, 0);
+      }
+      blk_sub(o[0][0], c00); blk_sub(o[0][1], c01); blk_sub(o[1][0], c10); blk_sub(o[1][1], c11);
+    }
+    if (pp + 1 < CM_GRP) put((pp + 1) & 1);          // (that buffer was last read before this iteration's barrier)
+  }
+  if (valid) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) blk_gstore(out, ld, rb, cb, lane, o[rb][cb]);
+  }
+}
+
+template <bool BATCH>
+__global__ __launch_bounds__(256, 2) void k_chol_wide(cm_parg<BATCH> pa, int na_arg, int skip_own, int j0, int large_min) {
+  int bx = (int)blockIdx.x, circ = 0;
+  if (BATCH) cm_xcd_remap(bx, circ, skip_own >> 8);  // all super-tiles of a circuit on one XCD: its panel tiles go through one L2
+  CM_SOLVE_PROLOGUE_AT(2, pa.get(circ))
+  const int t = nblk - j0 - CM_GRP;                  // trailing tile rows
+  if (nblk <= large_min || t <= 0) return;
+  const int ns = (t + 1) >> 1, nst = ns * (ns + 1) / 2;   // super-rows, super-tiles (lower triangle, row-major: id = I (I + 1) / 2 + L)
+  extern __shared__ double sm_dyn[];
+  if (bx > 0) {
+    const int id = bx + 2;                           // workgroup 0 owns super-tiles 0, 1, 2
+    if (id >= nst) return;
+    int I = (int)((sqrt(8.0 * (double)id + 1.0) - 1.0) * 0.5);
+    I = __builtin_amdgcn_readfirstlane(I);
+    while ((I + 1) * (I + 2) / 2 <= id) ++I;
+    while (I * (I + 1) / 2 > id) --I;
+    chol_wide_supertile(p, sm_dyn, j0, nblk, ld, I, id - I * (I + 1) / 2);
+    return;
+  }
+  // workgroup 0: the super-tiles (0, 0), (1, 0), (1, 1) hold the next group's diagonal block (tile rows j0 + 4 .. j0 + 7) ...
+  chol_wide_supertile(p, sm_dyn, j0, nblk, ld, 0, 0);
+  if (ns >= 2) {
+    chol_wide_supertile(p, sm_dyn, j0, nblk, ld, 1, 0);
+    chol_wide_supertile(p, sm_dyn, j0, nblk, ld, 1, 1);
+  }
+  __syncthreads();                                   // ... which this workgroup now factors (its stores are visible to itself)
+  chol_diag_block(p, sm_dyn, j0 + CM_GRP, min(CM_GRP, t), ld);
+}
+
 // Panel j in ONE launch (1024-thread workgroups, one per trailing tile (i, l), j < l <= i):
 //   X_i = A[i][j] L_jj^-T, X_l = A[l][j] L_jj^-T     (panel solve, recomputed per workgroup from the read-only panel tiles)
 //   A[i][l] -= X_i X_l^T                             (trailing update, in place: the tile is owned by this workgroup)
@@ -864,7 +1115,13 @@ int cm_solve_launch(cm_ctx* ctx, cm_set& s, int skip_mode, hipEvent_t fact_begin
   for (int c = 0; c < s.B; ++c) {                  // bookkeeping for cm_timings: trailing-update passes and the tiles they read and rewrote
     const int nb = (s.na[c] + TS - 1) / TS;
     if (cm_solve_kind(s.na[c], s.ps[c]->small_cap, skip_mode >= 0) != 2) continue;
-    if (nb > large_min) {
+    if (nb > large_min && ctx->chol_family == 1) {
+      for (int j0 = 0; j0 + CM_GRP < nb; j0 += CM_GRP) {   // group: panel solve of t rows x 4 columns, rank-128 update of the t (t + 1) / 2 trailing tiles
+        const long long t = nb - j0 - CM_GRP;
+        s.fact_tile_updates += t * (t + 1) / 2;
+        s.fact_panel_tiles += 12 * t + 10;             // k_chol_gpanel: 4 t unsolved tiles in, 4 t solved out, the block's 10 tiles; k_chol_wide: 4 t panel tiles
+      }
+    } else if (nb > large_min) {
       for (int j = 0; j + 1 < nb; j += 2) {          // panel pair: two panel solves, the thin column, the rank-64 update
         const long long t = nb - j - 1;
         s.fact_tile_updates += t + (t - 1) * t / 2;
@@ -913,9 +1170,25 @@ int cm_solve_launch(cm_ctx* ctx, cm_set& s, int skip_mode, hipEvent_t fact_begin
     // Cholesky
     if (first_group && fact_begin) CM_HIP(hipEventRecord(fact_begin, st));
     first_group = false;
-    s.fact_launches += large_g ? nblk / 2 : std::max(0, nblk - 1);
-    CM_LAUNCH_G(k_chol_first, 1, 256, 0, na1, skip_le);
-    if (large_g) {                                     // panels in pairs: panel solve, thin column, panel solve, rank-64 trailing update
+    s.fact_launches += large_g ? (ctx->chol_family == 1 ? (nblk - 1) / CM_GRP : nblk / 2) : std::max(0, nblk - 1);
+    if (large_g && ctx->chol_family == 1) {            // grouped family: four panels per pass over the trailing matrix, 64 x 64 super-tiles
+      if (s.B == 1) {
+        CM_TRY(cm_raise_lds(ctx, CM_LDS_CHOL_DIAG, reinterpret_cast<const void*>(k_chol_diag<false>), CM_GROUP_LDS, 48 * 1024));
+        CM_TRY(cm_raise_lds(ctx, CM_LDS_CHOL_GPANEL, reinterpret_cast<const void*>(k_chol_gpanel<false>), CM_GROUP_LDS, 48 * 1024));
+        CM_TRY(cm_raise_lds(ctx, CM_LDS_CHOL_WIDE, reinterpret_cast<const void*>(k_chol_wide<false>), CM_GROUP_LDS, 48 * 1024));
+      } else {
+        CM_TRY(cm_raise_lds(ctx, CM_LDS_CHOL_DIAG_B, reinterpret_cast<const void*>(k_chol_diag<true>), CM_GROUP_LDS, 48 * 1024));
+        CM_TRY(cm_raise_lds(ctx, CM_LDS_CHOL_GPANEL_B, reinterpret_cast<const void*>(k_chol_gpanel<true>), CM_GROUP_LDS, 48 * 1024));
+        CM_TRY(cm_raise_lds(ctx, CM_LDS_CHOL_WIDE_B, reinterpret_cast<const void*>(k_chol_wide<true>), CM_GROUP_LDS, 48 * 1024));
+      }
+      CM_LAUNCH_G(k_chol_diag, 1, 256, CM_GROUP_LDS, na1, skip_le, 0, large_min);
+      for (int j0 = 0; j0 + CM_GRP < nblk; j0 += CM_GRP) {
+        const int t = nblk - j0 - CM_GRP, ns = (t + 1) / 2, nst = ns * (ns + 1) / 2;
+        CM_LAUNCH_G(k_chol_gpanel, t, 256, CM_GROUP_LDS, na1, xflags, j0, large_min);
+        CM_LAUNCH_G(k_chol_wide, ns >= 2 ? nst - 2 : 1, 256, CM_GROUP_LDS, na1, xflags, j0, large_min);
+      }
+    } else if (large_g) {                              // panels in pairs: panel solve, thin column, panel solve, rank-64 trailing update
+      CM_LAUNCH_G(k_chol_first, 1, 256, 0, na1, skip_le);
       for (int j = 0; j + 1 < nblk; j += 2) {
         const int t = nblk - j - 1;
         CM_LAUNCH_GT(k_chol_bulk, false, t, 256, 0, na1, xflags, j, large_min);        // (carries the panel solve of column j)
@@ -924,6 +1197,7 @@ int cm_solve_launch(cm_ctx* ctx, cm_set& s, int skip_mode, hipEvent_t fact_begin
         CM_LAUNCH_GT(k_chol_bulk, true, (t - 1) * t / 2, 256, 0, na1, xflags, j, large_min);
       }
     } else {                                           // small / medium (one circuit): one launch per panel
+      CM_LAUNCH_G(k_chol_first, 1, 256, 0, na1, skip_le);
       for (int j = 0; j + 1 < nblk; ++j) {
         const int tp = nblk - j - 1;
         CM_LAUNCH_G(k_chol_panel, tp * (tp + 1) / 2, 1024, 0, na1, skip_le, j, large_min);

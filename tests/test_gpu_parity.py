@@ -693,3 +693,32 @@ def test_fit_batch_128_as_4x32_streams(ctx):
         for i, nm in enumerate(OUT_NAMES):
             if nm != "lam":
                 np.testing.assert_array_equal(np.asarray(res[i], dtype=float), np.asarray(got[c][nm], dtype=float), err_msg="circuit %d %s" % (c, nm))
+
+
+@pytest.mark.parametrize("N,K,B,iters", [(200, 400, 8, 6), (330, 700, 3, 5), (1000, 2000, 8, 6), (1700, 3400, 1, 3)])
+def test_cholesky_families_bitwise_equal(ctx, monkeypatch, N, K, B, iters):
+    """The grouped Cholesky family (four panels per pass over the trailing matrix, 64 x 64 super-tiles, next diagonal block factored by
+    workgroup 0 of the pass; default for batches and above 48 tile rows) leaves bitwise the factor of the panel-pair family
+    (CAVIAR_HIP_CHOL_FAMILY=0): every tile product is its own matrix-core accumulation and the subtractions happen in panel order.
+    Shapes: 7 tile rows (one full group + 3), 11 (odd super-row), 32 (the bench shape), 54 (one circuit above CM_LARGE_TILES)."""
+    from circuitmap_amd import _lib
+    from circuitmap_amd.optimise.caviar import run_batch
+    pri = default_priors(N)
+    opts = dict(iters=iters, seed=0, fn_scan=False)
+    res = []
+    for fam in (1, 0):
+        monkeypatch.setenv("CAVIAR_HIP_CHOL_FAMILY", str(fam))
+        cx = _lib.Context(0)
+        monkeypatch.delenv("CAVIAR_HIP_CHOL_FAMILY")
+        probs, _ = _device_circuits(cx, N, K, B, 5000)
+        if B == 1:
+            probs[0].run(*prior_args(pri), **opts)
+        else:
+            run_batch(probs, pri, **opts)
+        res.append([q.fetch() for q in probs])
+        for q in probs:
+            q.close()
+        cx.close()
+    for c in range(B):
+        _assert_same_fit(res[0][c], res[1][c], "family 1 vs 0, circuit %d" % c)
+    assert np.count_nonzero(res[0][0][0]) > 0
