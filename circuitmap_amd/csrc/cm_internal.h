@@ -14,7 +14,10 @@
 
 #define CM_WAVE 64
 #define CM_TILE 32          // tile edge of the blocked SPD solve
-#define CM_LD_PAD 0         // doubles added to the row stride of the solve matrices (8 was measured: no gain -- the trailing update is not channel-conflict bound)
+#ifndef CM_LD_PAD
+#define CM_LD_PAD 0
+#endif
+//                  CM_LD_PAD: doubles added to the row stride of the solve matrices (8 was measured: no gain -- the trailing update is not channel-conflict bound)
 #define CM_EV_PER_IT 10
 #define CM_MAX_BATCH 1024      // circuits in one lock-step group
 #define CM_MAILBOX_BATCH0 32   // 64-bit word index of the first per-circuit mailbox of a batch

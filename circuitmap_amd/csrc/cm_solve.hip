@@ -9,6 +9,11 @@
 // blocked Cholesky on 32x32 tiles; L^-1 comes from recursive doubling of triangular blocks (GEMM-shaped),
 // and mu, diag(Sigma) are column reductions of L^-1.  Everything fp64: the early iterations are
 // ill-conditioned enough (SURVEY 8c / tests) that fp32 would not hold the 1e-4 parity target.
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
 #include "cm_bodies.h"
 
 #define TS CM_TILE
@@ -1067,6 +1072,144 @@ int cm_solve_mu(cm_ctx* ctx, cm_set& s, int* n_active_out) {
   return cm_solve_launch(ctx, s, -1);
 }
 
+// One group of circuits through the tiled solve; `parts`: 1 = precision matrices, 2 = Cholesky, 4 = inverse of the factor, 8 = mu / beta.
+struct cm_solve_sub { int B; bool single; cm_pdev h0; const cm_pdev* d_arr; };
+static int cm_solve_group_launch(cm_ctx* ctx, const cm_solve_sub& g, int nblk, int na_g, int na1, int skip_le, int xflags, int large_min, int parts,
+                                 hipEvent_t fact_begin, hipEvent_t fact_end) {
+  hipStream_t st = ctx->stream;
+  const bool large_g = nblk > large_min;
+  const int ld = nblk * TS;                        // rows (the row stride is ld + CM_LD_PAD)
+  const unsigned gy = g.single ? 1u : (unsigned)g.B;
+#define CM_LAUNCH_G(KERN, gridx, block, lds, ...)                                                                                           \
+  do {                                                                                                                                    \
+    if (g.single) hipLaunchKernelGGL((KERN<false>), dim3(gridx), dim3(block), lds, st, cm_parg<false>{g.h0}, ##__VA_ARGS__);                \
+    else hipLaunchKernelGGL((KERN<true>), dim3(gridx, gy), dim3(block), lds, st, cm_parg<true>{g.d_arr}, ##__VA_ARGS__);                    \
+  } while (0)
+#define CM_LAUNCH_GT(KERN, TARG, gridx, block, lds, ...)                                                                                    \
+  do {                                                                                                                                    \
+    if (g.single) hipLaunchKernelGGL((KERN<false, TARG>), dim3(gridx), dim3(block), lds, st, cm_parg<false>{g.h0}, ##__VA_ARGS__);          \
+    else hipLaunchKernelGGL((KERN<true, TARG>), dim3(gridx, gy), dim3(block), lds, st, cm_parg<true>{g.d_arr}, ##__VA_ARGS__);              \
+  } while (0)
+  if (parts & 1) CM_LAUNCH_G(k_build_precision, ld, 64, build_prec_lds(ld + CM_LD_PAD), na1, skip_le);
+  if (parts & 2) {
+    if (fact_begin) CM_HIP(hipEventRecord(fact_begin, st));
+    if (large_g && ctx->chol_family == 1) {            // grouped family: four panels per pass over the trailing matrix, 64 x 64 super-tiles
+      if (g.single) {
+        CM_TRY(cm_raise_lds(ctx, CM_LDS_CHOL_DIAG, reinterpret_cast<const void*>(k_chol_diag<false>), CM_GROUP_LDS, 48 * 1024));
+        CM_TRY(cm_raise_lds(ctx, CM_LDS_CHOL_GPANEL, reinterpret_cast<const void*>(k_chol_gpanel<false>), CM_GROUP_LDS, 48 * 1024));
+        CM_TRY(cm_raise_lds(ctx, CM_LDS_CHOL_WIDE, reinterpret_cast<const void*>(k_chol_wide<false>), CM_GROUP_LDS, 48 * 1024));
+      } else {
+        CM_TRY(cm_raise_lds(ctx, CM_LDS_CHOL_DIAG_B, reinterpret_cast<const void*>(k_chol_diag<true>), CM_GROUP_LDS, 48 * 1024));
+        CM_TRY(cm_raise_lds(ctx, CM_LDS_CHOL_GPANEL_B, reinterpret_cast<const void*>(k_chol_gpanel<true>), CM_GROUP_LDS, 48 * 1024));
+        CM_TRY(cm_raise_lds(ctx, CM_LDS_CHOL_WIDE_B, reinterpret_cast<const void*>(k_chol_wide<true>), CM_GROUP_LDS, 48 * 1024));
+      }
+      CM_LAUNCH_G(k_chol_diag, 1, 256, CM_GROUP_LDS, na1, skip_le, 0, large_min);
+      for (int j0 = 0; j0 + CM_GRP < nblk; j0 += CM_GRP) {
+        const int t = nblk - j0 - CM_GRP, ns = (t + 1) / 2, nst = ns * (ns + 1) / 2;
+        CM_LAUNCH_G(k_chol_gpanel, t, 256, CM_GROUP_LDS, na1, xflags, j0, large_min);
+        CM_LAUNCH_G(k_chol_wide, ns >= 2 ? nst - 2 : 1, 256, CM_GROUP_LDS, na1, xflags, j0, large_min);
+      }
+    } else if (large_g) {                              // panels in pairs: panel solve, thin column, panel solve, rank-64 trailing update
+      CM_LAUNCH_G(k_chol_first, 1, 256, 0, na1, skip_le);
+      for (int j = 0; j + 1 < nblk; j += 2) {
+        const int t = nblk - j - 1;
+        CM_LAUNCH_GT(k_chol_bulk, false, t, 256, 0, na1, xflags, j, large_min);        // (carries the panel solve of column j)
+        if (t < 2) break;
+        CM_LAUNCH_G(k_chol_trsm, t - 1, 256, 0, na1, skip_le, j + 1, large_min);
+        CM_LAUNCH_GT(k_chol_bulk, true, (t - 1) * t / 2, 256, 0, na1, xflags, j, large_min);
+      }
+    } else {                                           // small / medium (one circuit): one launch per panel
+      CM_LAUNCH_G(k_chol_first, 1, 256, 0, na1, skip_le);
+      for (int j = 0; j + 1 < nblk; ++j) {
+        const int tp = nblk - j - 1;
+        CM_LAUNCH_G(k_chol_panel, tp * (tp + 1) / 2, 1024, 0, na1, skip_le, j, large_min);
+      }
+    }
+    if (fact_end) CM_HIP(hipEventRecord(fact_end, st));   // after EVERY group that factorised: the last record stands
+  }
+  if (parts & 4) {
+    // inverse of the factor (strictly-upper tiles of X are never read: no clearing needed)
+    CM_LAUNCH_G(k_inv_seed, nblk, 256, 0, na1, skip_le);
+    for (int b = 1; b < nblk; b *= 2) {
+      const int npairs = (nblk + 2 * b - 1) / (2 * b);
+      CM_LAUNCH_G(k_inv_T, npairs * b * b, 256, 0, na1, xflags, b);
+      CM_LAUNCH_G(k_inv_X21, npairs * b * b, 256, 0, na1, xflags, b);
+    }
+  }
+  if (parts & 8) {
+    CM_LAUNCH_G(k_tri_matvec, (na_g + 3) / 4, 256, 0, na1, skip_le);
+    const int nchunks = (na_g + CM_COLCHUNK - 1) / CM_COLCHUNK, nbx = (ld + 63) / 64;
+    CM_LAUNCH_G(k_colsum_partial, nbx * nchunks, 64, 0, na1, skip_le, nbx);
+    CM_LAUNCH_G(k_colsum_final, (na_g + 255) / 256, 256, 0, na1, skip_le);
+  }
+#undef CM_LAUNCH_G
+#undef CM_LAUNCH_GT
+  CM_HIP(hipGetLastError());
+  return CM_OK;
+}
+
+// Measurement aid (include/caviar_hip.h): B synthetic SPD matrices of n rows through the tiled Cholesky (and, separately timed, the
+// inverse of the factor) exactly as a lock-step batch of B circuits with n active rows each launches them; no CAVIaR state involved.
+__global__ __launch_bounds__(256) void k_bench_fill_spd(double* __restrict__ A, int n, int ld, double shift) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)ld * ld) return;
+  const int r = (int)(i / ld), c = (int)(i % ld);
+  double v = 0.0;
+  if (r < n && c < n) { const int lo = r < c ? r : c, hi = r < c ? c : r; v = (r == c) ? 2.0 + shift + 0.001 * (r % 7) : (0.1 + (double)((lo * 7 + hi * 13) % 11) / 11.0) / (double)n; }   // diagonally dominant
+  else if (r == c) v = 1.0;
+  A[i] = v;
+}
+extern "C" int cm_k_solve_bench(cm_ctx* ctx, int32_t n, int32_t B, int32_t reps, float* ms_chol, float* ms_inv) {
+  if (!ctx || n < 1 || B < 1 || B > CM_MAX_BATCH || reps < 1 || !ms_chol || !ms_inv) { cm_set_error("cm_k_solve_bench: bad argument"); return CM_ERR_INVALID; }
+  CM_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const int nblk = (n + TS - 1) / TS, ld = nblk * TS + CM_LD_PAD;
+  const size_t msz = (size_t)(nblk * TS) * ld;
+  std::vector<cm_pdev> h(B);
+  std::vector<void*> owned;
+  auto alloc = [&](size_t bytes) -> void* { void* q = nullptr; if (hipMalloc(&q, bytes) != hipSuccess) return nullptr; owned.push_back(q); return q; };
+  int rc = CM_OK;
+  for (int c = 0; c < B && rc == CM_OK; ++c) {
+    cm_pdev& d = h[c];
+    ::memset(&d, 0, sizeof(d));
+    d.N = n; d.small_cap = 0; d.ld_alloc = nblk * TS;
+    d.A = (double*)alloc(msz * 8); d.X = (double*)alloc(msz * 8); d.Lf = (double*)alloc(msz * 8);
+    d.Dinv = (double*)alloc((size_t)nblk * TS * TS * 8); d.n_act = (int*)alloc(16);
+    if (!d.A || !d.X || !d.Lf || !d.Dinv || !d.n_act) { cm_set_error("cm_k_solve_bench: out of memory"); rc = CM_ERR_HIP; break; }
+    const int na4[4] = {n, 0, 0, 0};
+    if (hipMemcpy(d.n_act, na4, 16, hipMemcpyHostToDevice) != hipSuccess) rc = CM_ERR_HIP;
+  }
+  cm_pdev* d_arr = nullptr;
+  if (rc == CM_OK && B > 1) {
+    d_arr = (cm_pdev*)alloc(sizeof(cm_pdev) * B);
+    if (!d_arr || hipMemcpy(d_arr, h.data(), sizeof(cm_pdev) * B, hipMemcpyHostToDevice) != hipSuccess) rc = CM_ERR_HIP;
+  }
+  double tc = 0.0, ti = 0.0;
+  for (int r = 0; r < reps + 1 && rc == CM_OK; ++r) {          // (first repetition: warm-up)
+    for (int c = 0; c < B; ++c) hipLaunchKernelGGL(k_bench_fill_spd, dim3((unsigned)((msz + 255) / 256)), dim3(256), 0, st, h[c].A, n, ld, 0.01 * c);
+    cm_solve_sub g;
+    g.B = B; g.single = B == 1; g.h0 = h[0]; g.d_arr = d_arr;
+    const int large_min = B > 1 ? 1 : CM_LARGE_TILES;
+    const int xflags = 0 | (ctx->xcd_mode << 8);
+    rc = cm_solve_group_launch(ctx, g, nblk, n, B == 1 ? n : 0, 0, xflags, large_min, 2, ctx->ev[0], ctx->ev[1]);
+    if (rc == CM_OK) rc = cm_solve_group_launch(ctx, g, nblk, n, B == 1 ? n : 0, 0, xflags, large_min, 4, nullptr, nullptr);
+    if (rc != CM_OK) break;
+    if (hipEventRecord(ctx->ev[2], st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { cm_set_error("cm_k_solve_bench: %s", hipGetErrorString(hipGetLastError())); rc = CM_ERR_HIP; break; }
+    float a = 0, b = 0;
+    hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]);
+    hipEventElapsedTime(&b, ctx->ev[1], ctx->ev[2]);
+    if (r > 0) { tc += a; ti += b; }
+  }
+  if (rc == CM_OK) {                                           // the factor must have been positive definite
+    int flag[4] = {0, 0, 0, 0};
+    if (hipMemcpy(flag, h[0].n_act, 16, hipMemcpyDeviceToHost) == hipSuccess && flag[1]) { cm_set_error("cm_k_solve_bench: test matrix not positive definite"); rc = CM_ERR_NOT_SPD; }
+  }
+  hipStreamSynchronize(st);
+  for (void* q : owned) hipFree(q);
+  *ms_chol = (float)(tc / reps); *ms_inv = (float)(ti / reps);
+  return rc;
+}
+
 // block_update_mu for active sets of known sizes (s.na): small sets in one workgroup each, larger ones by the tiled factorisation.
 // skip_le: circuits whose active set is no larger than this were already solved (by the fused mid-iteration kernel) and are left
 // alone; -1 = solve every circuit of the set.  In a batch each circuit reads its own size on the device; the host only sizes the
@@ -1141,10 +1284,11 @@ int cm_solve_launch(cm_ctx* ctx, cm_set& s, int skip_mode, hipEvent_t fact_begin
   // next, where the lock-step batch as a whole streams ~1 GB per pass through it.
   const int G = (s.B > 1 && ctx->solve_group > 0) ? std::min(ctx->solve_group, s.B) : s.B;
   const int xflags = skip_le | (ctx->xcd_mode << 8);
-  struct sub_t { int B; cm_pdev h0; const cm_pdev* d_arr; } g;
   bool first_group = true;
   for (int c0 = 0; c0 < s.B; c0 += G) {
+    cm_solve_sub g;
     g.B = std::min(G, s.B - c0);
+    g.single = s.B == 1;
     if (s.B == 1) g.h0 = s.h0;
     g.d_arr = s.d_arr ? s.d_arr + c0 : nullptr;
     int nblk = 0, na_g = 0;
@@ -1153,71 +1297,9 @@ int cm_solve_launch(cm_ctx* ctx, cm_set& s, int skip_mode, hipEvent_t fact_begin
       nblk = std::max(nblk, (s.na[c] + TS - 1) / TS); na_g = std::max(na_g, s.na[c]);
     }
     if (nblk == 0) continue;
-    const bool large_g = nblk > large_min;
-    const int ld = nblk * TS;                        // rows (the row stride is ld + CM_LD_PAD)
-    const unsigned gy = s.B == 1 ? 1u : (unsigned)g.B;
-#define CM_LAUNCH_G(KERN, gridx, block, lds, ...)                                                                                           \
-    do {                                                                                                                                  \
-      if (s.B == 1) hipLaunchKernelGGL((KERN<false>), dim3(gridx), dim3(block), lds, st, cm_parg<false>{g.h0}, ##__VA_ARGS__);              \
-      else hipLaunchKernelGGL((KERN<true>), dim3(gridx, gy), dim3(block), lds, st, cm_parg<true>{g.d_arr}, ##__VA_ARGS__);                  \
-    } while (0)
-#define CM_LAUNCH_GT(KERN, TARG, gridx, block, lds, ...)                                                                                    \
-    do {                                                                                                                                  \
-      if (s.B == 1) hipLaunchKernelGGL((KERN<false, TARG>), dim3(gridx), dim3(block), lds, st, cm_parg<false>{g.h0}, ##__VA_ARGS__);        \
-      else hipLaunchKernelGGL((KERN<true, TARG>), dim3(gridx, gy), dim3(block), lds, st, cm_parg<true>{g.d_arr}, ##__VA_ARGS__);            \
-    } while (0)
-    CM_LAUNCH_G(k_build_precision, ld, 64, build_prec_lds(ld + CM_LD_PAD), na1, skip_le);
-    // Cholesky
-    if (first_group && fact_begin) CM_HIP(hipEventRecord(fact_begin, st));
+    s.fact_launches += nblk > large_min ? (ctx->chol_family == 1 ? (nblk - 1) / CM_GRP : nblk / 2) : std::max(0, nblk - 1);
+    CM_TRY(cm_solve_group_launch(ctx, g, nblk, na_g, na1, skip_le, xflags, large_min, 15, first_group ? fact_begin : nullptr, fact_end));
     first_group = false;
-    s.fact_launches += large_g ? (ctx->chol_family == 1 ? (nblk - 1) / CM_GRP : nblk / 2) : std::max(0, nblk - 1);
-    if (large_g && ctx->chol_family == 1) {            // grouped family: four panels per pass over the trailing matrix, 64 x 64 super-tiles
-      if (s.B == 1) {
-        CM_TRY(cm_raise_lds(ctx, CM_LDS_CHOL_DIAG, reinterpret_cast<const void*>(k_chol_diag<false>), CM_GROUP_LDS, 48 * 1024));
-        CM_TRY(cm_raise_lds(ctx, CM_LDS_CHOL_GPANEL, reinterpret_cast<const void*>(k_chol_gpanel<false>), CM_GROUP_LDS, 48 * 1024));
-        CM_TRY(cm_raise_lds(ctx, CM_LDS_CHOL_WIDE, reinterpret_cast<const void*>(k_chol_wide<false>), CM_GROUP_LDS, 48 * 1024));
-      } else {
-        CM_TRY(cm_raise_lds(ctx, CM_LDS_CHOL_DIAG_B, reinterpret_cast<const void*>(k_chol_diag<true>), CM_GROUP_LDS, 48 * 1024));
-        CM_TRY(cm_raise_lds(ctx, CM_LDS_CHOL_GPANEL_B, reinterpret_cast<const void*>(k_chol_gpanel<true>), CM_GROUP_LDS, 48 * 1024));
-        CM_TRY(cm_raise_lds(ctx, CM_LDS_CHOL_WIDE_B, reinterpret_cast<const void*>(k_chol_wide<true>), CM_GROUP_LDS, 48 * 1024));
-      }
-      CM_LAUNCH_G(k_chol_diag, 1, 256, CM_GROUP_LDS, na1, skip_le, 0, large_min);
-      for (int j0 = 0; j0 + CM_GRP < nblk; j0 += CM_GRP) {
-        const int t = nblk - j0 - CM_GRP, ns = (t + 1) / 2, nst = ns * (ns + 1) / 2;
-        CM_LAUNCH_G(k_chol_gpanel, t, 256, CM_GROUP_LDS, na1, xflags, j0, large_min);
-        CM_LAUNCH_G(k_chol_wide, ns >= 2 ? nst - 2 : 1, 256, CM_GROUP_LDS, na1, xflags, j0, large_min);
-      }
-    } else if (large_g) {                              // panels in pairs: panel solve, thin column, panel solve, rank-64 trailing update
-      CM_LAUNCH_G(k_chol_first, 1, 256, 0, na1, skip_le);
-      for (int j = 0; j + 1 < nblk; j += 2) {
-        const int t = nblk - j - 1;
-        CM_LAUNCH_GT(k_chol_bulk, false, t, 256, 0, na1, xflags, j, large_min);        // (carries the panel solve of column j)
-        if (t < 2) break;
-        CM_LAUNCH_G(k_chol_trsm, t - 1, 256, 0, na1, skip_le, j + 1, large_min);
-        CM_LAUNCH_GT(k_chol_bulk, true, (t - 1) * t / 2, 256, 0, na1, xflags, j, large_min);
-      }
-    } else {                                           // small / medium (one circuit): one launch per panel
-      CM_LAUNCH_G(k_chol_first, 1, 256, 0, na1, skip_le);
-      for (int j = 0; j + 1 < nblk; ++j) {
-        const int tp = nblk - j - 1;
-        CM_LAUNCH_G(k_chol_panel, tp * (tp + 1) / 2, 1024, 0, na1, skip_le, j, large_min);
-      }
-    }
-    if (fact_end) CM_HIP(hipEventRecord(fact_end, st));   // after EVERY group that factorised (a group without tiled circuits skips the loop body above): the last record stands
-    // inverse of the factor (strictly-upper tiles of X are never read: no clearing needed)
-    CM_LAUNCH_G(k_inv_seed, nblk, 256, 0, na1, skip_le);
-    for (int b = 1; b < nblk; b *= 2) {
-      const int npairs = (nblk + 2 * b - 1) / (2 * b);
-      CM_LAUNCH_G(k_inv_T, npairs * b * b, 256, 0, na1, xflags, b);
-      CM_LAUNCH_G(k_inv_X21, npairs * b * b, 256, 0, na1, xflags, b);
-    }
-    // mu, beta
-    CM_LAUNCH_G(k_tri_matvec, (na_g + 3) / 4, 256, 0, na1, skip_le);
-    const int nchunks = (na_g + CM_COLCHUNK - 1) / CM_COLCHUNK, nbx = (ld + 63) / 64;
-    CM_LAUNCH_G(k_colsum_partial, nbx * nchunks, 64, 0, na1, skip_le, nbx);
-    CM_LAUNCH_G(k_colsum_final, (na_g + 255) / 256, 256, 0, na1, skip_le);
-#undef CM_LAUNCH_G
-#undef CM_LAUNCH_GT
   }
   CM_HIP(hipGetLastError());
   return CM_OK;

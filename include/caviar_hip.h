@@ -235,6 +235,11 @@ int cm_k_rng_streams(cm_ctx* ctx, uint64_t seed, int32_t it, int32_t N, int32_t 
  * with a profiler's kernel trace. */
 int cm_k_event_pair_overhead(cm_ctx* ctx, int32_t reps, int32_t blocks, int32_t threads, float* ms_per_pair);
 
+/* Measurement aid for the tiled solve: B synthetic SPD matrices of n rows go through the Cholesky factorisation and the inverse of the
+ * factor exactly as a lock-step batch of B circuits with n active rows each launches them (B = 1: the single-circuit launches); average
+ * milliseconds over `reps` repetitions after one warm-up (tools/solve_bench.py). */
+int cm_k_solve_bench(cm_ctx* ctx, int32_t n, int32_t B, int32_t reps, float* ms_chol, float* ms_inv);
+
 /* Test hook for the library's dynamic-LDS bookkeeping (no GPU needed): hipFuncAttributeMaxDynamicSharedMemorySize REPLACES the value in
  * force for a (kernel, device), so the library keeps one process-wide table and only ever raises it.  Returns the value the runtime
  * would be called with for this request (0 = the value in force already covers it).  `kernel_key` is an arbitrary test key. */
