@@ -627,7 +627,19 @@ __device__ __noinline__ double cm_logit_literal(double x) {
   const double f = cm_sigmoid(x);
   return log(f / (1.0 - f));
 }
+// Where the rounding residue is evaluated at all.  rho(x) = log(f / (1 - f)) - x is the reference's own rounding noise: exp(-x) enters it as
+// an absolute 1e-16 and the rounding of f = 1 / (1 + e) as 2^-53 / (1 - f) = 2^-53 (1 + e^x), so |rho(x)| <= 2^-52 for x <= 0 and
+// <= 2^-53 (1 + e^x) above: 3.3e-13 at x = 8.  Which way f rounds depends on the last bit of e, i.e. on the exp implementation (the
+// library's, this table's and XLA's differ in a fraction of the arguments), so below that size rho is not reproducible against the
+// reference in the first place -- for -700 < x < CM_LOGIT_RESIDUE_FROM the logit is x itself, and the ~40 instructions of the residue
+// are only spent where it can matter (large positive x; near the overflow of exp(-x), x < -709.78, the literal form decides).
+// -DCM_LOGIT_RESIDUE_FROM=-1e300 evaluates the residue everywhere (tests/test_gpu_parity.py::test_mc_logit_residue_threshold
+// compares the two builds' trajectories).
+#ifndef CM_LOGIT_RESIDUE_FROM
+#define CM_LOGIT_RESIDUE_FROM 8.0
+#endif
 __device__ __forceinline__ double cm_logit_of_sigmoid(double x, const double* etab) {
+  if (x < CM_LOGIT_RESIDUE_FROM && x > -700.0) return x;
   if (fabs(x) < 20.0) {
     const double e = cm_exp_tab(-x, etab);
     const double f = cm_rcp(1.0 + e);                  // 1 + e in [1, 5e8]: normal range
@@ -650,18 +662,20 @@ __device__ __noinline__ double cm_quantile_slow(double arg) { return normcdfinv(
 // phi_0 draws, then all phi_1 draws): c is then uniform over the wavefront and the miss path is only entered for a component
 // that needs it (phi_1 of rows whose posterior is wide, e.g. all-zero rows: c ~ 1e-7 there).
 // HAVE_C: c0 / c1 = ndtr(-mean / sdev) are supplied (per-run constants of an all-zero row, k_phi_dead) instead of evaluated here.
-template <bool FULL, bool HAVE_C = false>
+// PRE: the first two rounds of the table row (samples lane, lane + 64; both components) were fetched by the caller (`pre`).
+template <bool FULL, bool HAVE_C = false, bool PRE = false>
 __device__ __forceinline__ void mc_logit_body(int n, int lane, double mean0, double mean1, double sd0, double sd1,
                                               const double2* __restrict__ wu, const double* __restrict__ vals, int V, int S,
-                                              double* mc, double* __restrict__ mcE, const double* etab, double c0_in = 0.0, double c1_in = 0.0) {
+                                              double* mc, double* __restrict__ mcE, const double* etab, double c0_in = 0.0, double c1_in = 0.0,
+                                              const double2* pre = nullptr) {
   const double c0 = HAVE_C ? c0_in : normcdf(-mean0 / sd0), c1 = HAVE_C ? c1_in : normcdf(-mean1 / sd1);
 #pragma unroll
   for (int comp = 0; comp < 2; ++comp) {
     const double c = comp ? c1 : c0, sd = comp ? sd1 : sd0, mean = comp ? mean1 : mean0;
     const bool tiny = !FULL && c < 0x1p-106;           // (wave-uniform)
-    for (int s_ = lane; s_ < S; s_ += CM_WAVE) {
+    for (int s_ = lane, rnd = 0; s_ < S; s_ += CM_WAVE, ++rnd) {
       const int j = 2 * s_ + comp;                     // u has shape [S, 2] (caviar.py:210)
-      const double2 t = wu[j];
+      const double2 t = (PRE && rnd < 2) ? (rnd == 0 ? pre[comp] : pre[2 + comp]) : wu[j];
       double q;
       if (FULL) {
         q = normcdfinv(c + t.y * (1.0 - c));           // caviar.py:212

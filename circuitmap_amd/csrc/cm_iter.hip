@@ -54,15 +54,38 @@ __global__ __launch_bounds__(256) void k_mc_dead(cm_parg<BATCH> pa, IterDyn a) {
   const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE;
   const int n = (int)blockIdx.x * (int)(blockDim.x / CM_WAVE) + wave;
   const int N = p.N;
-  if (n >= N || !(p.rs[(size_t)n * 4 + 3] < 0.0)) return;
+  if (n >= N) return;
+  // The launch is latency-bound (one short dependent chain per wavefront, 128 000 wavefronts): everything the row needs is requested
+  // BEFORE the test of the row's state -- its flag, its per-run constants and the first two rounds of its table row (the table is stored by
+  // neuron: no look-up of the sweep position in front of it) -- one memory round trip instead of three.  Rows with lam != 0 (5 % in the
+  // steady state) fetched in vain.
+  const double flag = p.rs[(size_t)n * 4 + 3];
+  const size_t off = ((size_t)a.nx * N + n) * 2 * a.S;
+  const double2* __restrict__ wu = (const double2*)p.wtab + off;
+  double2 pre[4];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int comp = 0; comp < 2; ++comp) {
+      const int s_ = lane + r * CM_WAVE;
+      pre[2 * r + comp] = (a.do_mc && s_ < a.S) ? wu[2 * s_ + comp] : make_double2(0.0, 0.0);
+    }
   double pc[4], c0, c1;
-  dead_phi_copy(p, n, lane, pc, &c0, &c1);
-  if (a.do_mc) {
-    const int m = p.inv_all[(size_t)a.nx * N + n];
-    const size_t off = ((size_t)a.nx * N + m) * 2 * a.S;
-    mc_logit_body<false, true>(n, lane, pc[0], pc[1], pc[2], pc[3], (const double2*)p.wtab + off, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S,
-                               p.mcE, etab, c0, c1);
+  const double* __restrict__ pd = p.phi_dead + 2 * (size_t)n;
+  const double* __restrict__ cd = p.phi_cov_dead + 4 * (size_t)n;
+  const double* __restrict__ cc = p.phi_c_dead + 2 * (size_t)n;
+  pc[0] = pd[0]; pc[1] = pd[1];
+  const double c01 = cd[1], c10 = cd[2];
+  pc[2] = cd[0]; pc[3] = cd[3];
+  c0 = cc[0]; c1 = cc[1];
+  if (!(flag < 0.0)) return;
+  if (lane == 0) {
+    p.phi[2 * n] = pc[0]; p.phi[2 * n + 1] = pc[1];
+    p.phi_cov[4 * n] = pc[2]; p.phi_cov[4 * n + 1] = c01; p.phi_cov[4 * n + 2] = c10; p.phi_cov[4 * n + 3] = pc[3];
   }
+  if (a.do_mc)
+    mc_logit_body<false, true, true>(n, lane, pc[0], pc[1], pc[2], pc[3], wu, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S,
+                                     p.mcE, etab, c0, c1, pre);
 }
 
 // LISTED (batches, steady state): the per-neuron role walks the list of rows with lam != 0 in a stride loop -- its own instantiation,
@@ -111,8 +134,7 @@ __global__ __launch_bounds__(CM_ITER_THREADS) void k_iter_mid(cm_parg<BATCH> pa,
       double pc[4];
       phi_body<SEG>(n, lane, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, pc);
       if (a.do_mc) {
-        const int m = p.inv_all[(size_t)a.nx * N + n];
-        const size_t off = ((size_t)a.nx * N + m) * 2 * a.S;
+        const size_t off = ((size_t)a.nx * N + n) * 2 * a.S;      // (the table is stored by neuron)
         mc_logit_body<FULLMC>(n, lane, pc[0], pc[1], pc[2], pc[3], (const double2*)p.wtab + off, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE, etab);
       }
     }
@@ -134,9 +156,8 @@ __global__ __launch_bounds__(CM_ITER_THREADS) void k_iter_mid(cm_parg<BATCH> pa,
   }
   if (a.do_mc) {
     // random tables of iteration nx (the next one)
-    const int m = p.inv_all[(size_t)a.nx * N + n];
-    const size_t off = ((size_t)a.nx * N + m) * 2 * a.S;
-    const double2* wu = (const double2*)p.wtab + off;   // (ndtri(u), u) of that sweep step
+    const size_t off = ((size_t)a.nx * N + n) * 2 * a.S;
+    const double2* wu = (const double2*)p.wtab + off;   // (ndtri(u), u) of the neuron's sweep step (the table is stored by neuron)
     if (!FULLMC && dead_row)
       mc_logit_body<false, true>(n, lane, pc[0], pc[1], pc[2], pc[3], wu, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE, etab, dc0, dc1);
     else
@@ -163,8 +184,7 @@ __global__ __launch_bounds__(CM_ITER_THREADS) void k_iter_overflow(cm_parg<true>
     double pc[4];
     phi_body<SEG>(n, lane, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, pc);
     if (a.do_mc) {
-      const int m = p.inv_all[(size_t)a.nx * N + n];
-      const size_t off = ((size_t)a.nx * N + m) * 2 * a.S;
+      const size_t off = ((size_t)a.nx * N + n) * 2 * a.S;
       mc_logit_body<false>(n, lane, pc[0], pc[1], pc[2], pc[3], (const double2*)p.wtab + off, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE, etab);
     }
   }

@@ -88,15 +88,19 @@ __global__ __launch_bounds__(256) void k_invert_orders(const int* __restrict__ o
 // w * sdev + mean bit for bit and the quantile function leaves the per-iteration critical path.
 // ------------------------------------------------------------------------------------------------
 // grid (N, n_it): block (m, it) tabulates ndtri(u) of sweep step m of iteration it0 + it
-__global__ __launch_bounds__(64) void k_ndtri_table(const uint32_t* __restrict__ keys_all, const double* __restrict__ uexp_all, int it0,
-                                                     int N, int S, double* __restrict__ wtab, double* __restrict__ u_out) {
+// The table rows are stored BY NEURON (row of iteration `it`, neuron orders_all[it][m] <- the draws of sweep step m): a consumer that works on
+// neuron n reads its row without first looking up the neuron's sweep position (one dependent memory round trip less in kernels that are
+// latency-bound).  orders_all == nullptr (cm_k_rng_streams): rows by sweep step.
+__global__ __launch_bounds__(64) void k_ndtri_table(const uint32_t* __restrict__ keys_all, const double* __restrict__ uexp_all, const int* __restrict__ orders_all,
+                                                     int it0, int N, int S, double* __restrict__ wtab, double* __restrict__ u_out) {
   const int m = blockIdx.x, it = it0 + blockIdx.y;
   const size_t base = ((size_t)it * N + m) * 2 * S;
+  const size_t wbase = ((size_t)it * N + (orders_all ? orders_all[(size_t)it * N + m] : m)) * 2 * S;
   uint32_t k0 = 0, k1 = 0;
   if (!uexp_all) { const uint32_t* keys = keys_all + (size_t)it * (N + 3) * 2; k0 = keys[2 * (3 + m)]; k1 = keys[2 * (3 + m) + 1]; }
   for (int j = threadIdx.x; j < 2 * S; j += CM_WAVE) {
     const double u = uexp_all ? uexp_all[base + j] : cm_uniform64(k0, k1, j, S);
-    if (wtab) { wtab[2 * (base + j)] = normcdfinv(u); wtab[2 * (base + j) + 1] = u; }   // (ndtri(u), u) pairs
+    if (wtab) { wtab[2 * (wbase + j)] = normcdfinv(u); wtab[2 * (wbase + j) + 1] = u; }   // (ndtri(u), u) pairs
     if (u_out) u_out[(size_t)m * 2 * S + j] = u;
   }
 }
@@ -749,7 +753,7 @@ int cm_launch_ndtri_table(cm_ctx* ctx, cm_problem* p, int it0, int n_it, int S, 
   (void)ctx;
   if (n_it <= 0) return CM_OK;
   const double* uexp = (rng_mode == CM_RNG_EXPLICIT) ? p->uexp : nullptr;
-  hipLaunchKernelGGL(k_ndtri_table, dim3(p->N, n_it), dim3(64), 0, st, p->keys, uexp, it0, p->N, S, p->wtab, (double*)nullptr);
+  hipLaunchKernelGGL(k_ndtri_table, dim3(p->N, n_it), dim3(64), 0, st, p->keys, uexp, (const int*)p->orders_all, it0, p->N, S, p->wtab, (double*)nullptr);
   if (rng_mode == CM_RNG_EXPLICIT) {
     const long long total = (long long)n_it * p->N;
     hipLaunchKernelGGL(k_invert_orders, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p->orders_all + (size_t)it0 * p->N,
@@ -760,7 +764,7 @@ int cm_launch_ndtri_table(cm_ctx* ctx, cm_problem* p, int it0, int n_it, int S, 
 }
 
 int cm_k_rng_streams_impl(cm_ctx* ctx, cm_problem* p, int it, int S, double* d_u) {
-  hipLaunchKernelGGL(k_ndtri_table, dim3(p->N, 1), dim3(64), 0, ctx->stream, p->keys, (const double*)nullptr, it, p->N, S, (double*)nullptr, d_u);
+  hipLaunchKernelGGL(k_ndtri_table, dim3(p->N, 1), dim3(64), 0, ctx->stream, p->keys, (const double*)nullptr, (const int*)nullptr, it, p->N, S, (double*)nullptr, d_u);
   CM_HIP(hipGetLastError());
   return CM_OK;
 }
