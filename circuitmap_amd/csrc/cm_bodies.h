@@ -690,6 +690,27 @@ __device__ __forceinline__ void mc_logit_body(int n, int lane, double mean0, dou
       mc[j] = q * sd + mean;
     }
   }
+#ifdef CM_MC_AFFINE
+  // MEASUREMENT VARIANT (tools/build_variant.sh affine -DCM_MC_AFFINE; never the default build): the mean logit of a power from the means of
+  // the draws, mean_s(mc0_s v - mc1_s) = v mean(mc0) - mean(mc1), wherever no sample of the row can saturate the sigmoid
+  // (max |mc0| v_max + max |mc1| < 36); rows that can take the literal path below.
+  {
+    double a0 = 0.0, a1 = 0.0, m0 = 0.0, m1 = 0.0;
+    for (int s_ = lane; s_ < S; s_ += CM_WAVE) {
+      const double x0 = mc[2 * s_], x1 = mc[2 * s_ + 1];       // (this lane's own draws: written above by this lane)
+      a0 += x0; a1 += x1; m0 = fmax(m0, fabs(x0)); m1 = fmax(m1, fabs(x1));
+    }
+    double vmax = 0.0;
+    for (int g = 0; g < V; ++g) vmax = fmax(vmax, vals[g]);
+    m0 = cm_wave_max(m0); m1 = cm_wave_max(m1);
+    if (m0 * vmax + m1 < 36.0) {
+      a0 = cm_wave_sum(a0); a1 = cm_wave_sum(a1);
+      const double e0 = a0 / (double)S, e1 = a1 / (double)S;
+      if (lane < V && vals[lane] > 0.0) mcE[(size_t)n * CM_MAX_VALS + lane] = e0 * vals[lane] - e1;
+      return;
+    }
+  }
+#endif
   // same-wave LDS write -> read: the LDS pipe is in order for one wave; the (free) wave barrier keeps the compiler from moving the
   // reads above the writes of other lanes
   __builtin_amdgcn_wave_barrier();

@@ -42,8 +42,14 @@ __device__ __forceinline__ void dead_phi_copy(const cm_pdev& p, int n, int lane,
 }
 
 // Batches: the all-zero rows of every circuit (95 % of the rows in the steady state) in a kernel of their own -- copy of the
-// constants + the next Monte-Carlo logit, nothing else: few registers, so twice the wavefronts per SIMD hide the table loads, and
-// no workgroup waits for a Newton iteration.  One wavefront per row; rows with lam != 0 leave at once (k_iter_mid takes them).
+// constants + the next Monte-Carlo logit, nothing else, so that no workgroup waits for a Newton iteration.  TWO rows per wavefront, one
+// per 32-lane half: the per-row overhead (constants, address arithmetic, the reductions' instruction streams, the division) is issued
+// once for two rows -- the launch was bound by instruction issue at ~340 vector instructions per row, of which the evaluations
+// themselves were a fifth.  Every row's sums are bitwise those of mc_logit_body (one row per wavefront): there lane l accumulates the
+// samples l, l + 64 and cm_wave_sum reduces the 64 lanes as four 16-lane rows, (r0 + r1) + (r2 + r3); here physical lane j of a half
+// carries the two virtual lanes j (samples j, j + 64) and j + 32 (samples j + 32, j + 96) in separate accumulators, the 16-lane
+// reductions run on both sets, and the four row sums are combined in the same order.  A lane's samples never leave its registers: no LDS.
+// Rows with lam != 0 leave at once (k_iter_mid takes them); more than four powers or more than 128 samples: the general body, row by row.
 template <bool BATCH>
 __global__ __launch_bounds__(256) void k_mc_dead(cm_parg<BATCH> pa, IterDyn a) {
   extern __shared__ double sm[];
@@ -51,41 +57,85 @@ __global__ __launch_bounds__(256) void k_mc_dead(cm_parg<BATCH> pa, IterDyn a) {
   cm_exptab_init(etab);
   __syncthreads();                                   // (before any wavefront leaves)
   const cm_pdev& p = pa.get();
-  const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE;
-  const int n = (int)blockIdx.x * (int)(blockDim.x / CM_WAVE) + wave;
-  const int N = p.N;
-  if (n >= N) return;
-  // The launch is latency-bound (one short dependent chain per wavefront, 128 000 wavefronts): everything the row needs is requested
-  // BEFORE the test of the row's state -- its flag, its per-run constants and the first two rounds of its table row (the table is stored by
-  // neuron: no look-up of the sweep position in front of it) -- one memory round trip instead of three.  Rows with lam != 0 (5 % in the
-  // steady state) fetched in vain.
-  const double flag = p.rs[(size_t)n * 4 + 3];
-  const size_t off = ((size_t)a.nx * N + n) * 2 * a.S;
-  const double2* __restrict__ wu = (const double2*)p.wtab + off;
-  double2 pre[4];
+  const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE, h = lane >> 5, j = lane & 31;
+  const int N = p.N, S = a.S;
+  const int n = 2 * ((int)blockIdx.x * (int)(blockDim.x / CM_WAVE) + wave) + h;
+  const bool in = n < N;
+  const int nn = in ? n : N - 1;
+  // The launch is also latency-bound (one short dependent chain per wavefront): everything a row needs is requested BEFORE the test of
+  // its state -- the flag, the per-run constants, its table row (stored by neuron: no look-up of the sweep position in front of it).
+  const double flag = p.rs[(size_t)nn * 4 + 3];
+  const double2* __restrict__ wu = (const double2*)p.wtab + ((size_t)a.nx * N + nn) * 2 * S;
+  double2 t[4][2];
 #pragma unroll
-  for (int r = 0; r < 2; ++r)
+  for (int q = 0; q < 4; ++q) {
+    const int s_ = j + 32 * (q >> 1) + 64 * (q & 1);               // slots: j, j + 64 (virtual lane j), j + 32, j + 96 (virtual lane j + 32)
 #pragma unroll
-    for (int comp = 0; comp < 2; ++comp) {
-      const int s_ = lane + r * CM_WAVE;
-      pre[2 * r + comp] = (a.do_mc && s_ < a.S) ? wu[2 * s_ + comp] : make_double2(0.0, 0.0);
-    }
-  double pc[4], c0, c1;
-  const double* __restrict__ pd = p.phi_dead + 2 * (size_t)n;
-  const double* __restrict__ cd = p.phi_cov_dead + 4 * (size_t)n;
-  const double* __restrict__ cc = p.phi_c_dead + 2 * (size_t)n;
-  pc[0] = pd[0]; pc[1] = pd[1];
-  const double c01 = cd[1], c10 = cd[2];
-  pc[2] = cd[0]; pc[3] = cd[3];
-  c0 = cc[0]; c1 = cc[1];
-  if (!(flag < 0.0)) return;
-  if (lane == 0) {
-    p.phi[2 * n] = pc[0]; p.phi[2 * n + 1] = pc[1];
-    p.phi_cov[4 * n] = pc[2]; p.phi_cov[4 * n + 1] = c01; p.phi_cov[4 * n + 2] = c10; p.phi_cov[4 * n + 3] = pc[3];
+    for (int comp = 0; comp < 2; ++comp) t[q][comp] = (a.do_mc && s_ < S) ? wu[2 * s_ + comp] : make_double2(0.0, 0.0);
   }
-  if (a.do_mc)
-    mc_logit_body<false, true, true>(n, lane, pc[0], pc[1], pc[2], pc[3], wu, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S,
-                                     p.mcE, etab, c0, c1, pre);
+  const double* __restrict__ pd = p.phi_dead + 2 * (size_t)nn;
+  const double* __restrict__ cd = p.phi_cov_dead + 4 * (size_t)nn;
+  const double* __restrict__ cc = p.phi_c_dead + 2 * (size_t)nn;
+  const double mean0 = pd[0], mean1 = pd[1], sd0 = cd[0], c01 = cd[1], c10 = cd[2], sd1 = cd[3], c0 = cc[0], c1 = cc[1];
+  const bool dead = in && flag < 0.0;
+  if (!__any(dead)) return;
+  if (dead && j == 0) {
+    p.phi[2 * n] = mean0; p.phi[2 * n + 1] = mean1;
+    p.phi_cov[4 * n] = sd0; p.phi_cov[4 * n + 1] = c01; p.phi_cov[4 * n + 2] = c10; p.phi_cov[4 * n + 3] = sd1;
+  }
+  if (!a.do_mc) return;
+  int gi[4] = {0, 0, 0, 0}, P = 0;
+  for (int g = 0; g < p.V; ++g)
+    if (p.vals[g] > 0.0) { if (P < 4) gi[P] = g; ++P; }
+  if (P > 4 || S > 2 * CM_WAVE) {                    // rare shapes: the general body, one row after the other on the whole wavefront
+    for (int hh = 0; hh < 2; ++hh) {
+      const int src = 32 * hh;
+      if (!__builtin_amdgcn_readlane((int)dead, src)) continue;
+      const int row = __builtin_amdgcn_readlane(n, src);
+      mc_logit_body<false, true>(row, lane, cm_readlane_f64(mean0, src), cm_readlane_f64(mean1, src), cm_readlane_f64(sd0, src), cm_readlane_f64(sd1, src),
+                                 (const double2*)p.wtab + ((size_t)a.nx * N + row) * 2 * S, p.vals, p.V, S, sm + (size_t)wave * 2 * S, p.mcE, etab,
+                                 cm_readlane_f64(c0, src), cm_readlane_f64(c1, src));
+    }
+    return;
+  }
+  double vk[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) vk[k] = p.vals[gi[k]];
+  const bool tiny0 = c0 < 0x1p-106, tiny1 = c1 < 0x1p-106;
+  double acc[4][2] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int s_ = j + 32 * (q >> 1) + 64 * (q & 1);
+    if (dead && s_ < S) {
+      // the draw of mc_logit_body<false> (caviar.py:212): the tabulated quantile whenever arg = c + u (1 - c) is u bit for bit
+      double qq[2];
+#pragma unroll
+      for (int comp = 0; comp < 2; ++comp) {
+        const double c = comp ? c1 : c0;
+        const bool tiny = comp ? tiny1 : tiny0;
+        const double2 tt = t[q][comp];
+        if (tiny) qq[comp] = (tt.x == -INFINITY && c != 0.0) ? cm_quantile_slow(c) : tt.x;
+        else { const double arg = c + tt.y * (1.0 - c); qq[comp] = (arg == tt.y) ? tt.x : cm_quantile_slow(arg); }
+      }
+      const double m0 = qq[0] * sd0 + mean0, m1 = qq[1] * sd1 + mean1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (k < P) acc[k][q >> 1] += cm_logit_of_sigmoid(m0 * vk[k] - m1, etab);
+    }
+  }
+  double tot = 0.0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (k < P) {
+      double r01 = cm_seg_sum<16>(acc[k][0]), r23 = cm_seg_sum<16>(acc[k][1]);   // r0 | r1 and r2 | r3 in the two 16-lane rows of the half
+      r01 += __shfl_xor(r01, 16, CM_WAVE);                                          // r0 + r1 (the other row: r1 + r0, the same bits)
+      r23 += __shfl_xor(r23, 16, CM_WAVE);
+      const double sum = r01 + r23;
+      if (j == k) tot = sum;
+    }
+  }
+  const double mean = tot / (double)S;                 // lane k of the half: the mean of power k -- one division serves all of them
+  if (dead && j < P) p.mcE[(size_t)n * CM_MAX_VALS + (j == 0 ? gi[0] : (j == 1 ? gi[1] : (j == 2 ? gi[2] : gi[3])))] = mean;
 }
 
 // LISTED (batches, steady state): the per-neuron role walks the list of rows with lam != 0 in a stride loop -- its own instantiation,
@@ -229,7 +279,7 @@ static int launch_iter2(cm_ctx* ctx, cm_set& s, const IterDyn& a0, size_t lds, i
     }
     if (between) CM_HIP(hipEventRecord(between, ctx->stream));
     CM_TRY(cm_raise_lds(ctx, CM_LDS_MC_DEAD_B, reinterpret_cast<const void*>(k_mc_dead<true>), 4 * lds_waves, 48 * 1024));   // (num_mc_samples > 768)
-    CM_LAUNCH_SET(k_mc_dead, s, (s.lead->N + 3) / 4, 256, 4 * lds_waves, ctx->stream, a0);
+    CM_LAUNCH_SET(k_mc_dead, s, (s.lead->N + 7) / 8, 256, 4 * lds_waves, ctx->stream, a0);   // two rows per wavefront
   } else {
     CM_LAUNCH_SET_T(k_iter_mid, (SEG, FULLMC), s, blocks, threads, lds, ctx->stream, a0);
     if (between) CM_HIP(hipEventRecord(between, ctx->stream));
