@@ -156,7 +156,6 @@ extern "C" int cm_ctx_destroy(cm_ctx* c) {
   for (auto& e : c->pool) hipEventDestroy(e);
   if (c->h_pinned) hipHostFree(c->h_pinned);
   if (c->h_stage) hipHostFree(c->h_stage);
-  delete c->pool_host;
   if (c->h_pdev) hipHostFree(c->h_pdev);
   if (c->d_pdev) hipFree(c->d_pdev);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -709,11 +708,16 @@ static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_option
   CM_HIP(hipEventRecord(ctx->ev[2], st));
   lap("iterations");
 
-  if (o->fn_scan) {                                                  // caviar.py:94-98
+  if (o->fn_scan && o->verbose == 0 && cm_fn_scan_fits(s)) {         // caviar.py:94-98
+    // reconnect_spont_cells on the device, one workgroup per circuit, straight on mu | beta | z | lam in HBM (cm_fnscan.hip): no host
+    // round trip, no synchronisation; the final update_phi follows on the stream
+    CM_TRY(cm_launch_fn_scan(ctx, s, o->msrmp, o->minimum_spike_count));
+    CM_TRY(cm_launch_update_phi(ctx, s, st, iters > 0 ? 1 : 0));     // (iters == 0: the per-run constants were not produced)
+  } else if (o->fn_scan) {
+    // Host path (verbose runs: the reference's progress messages; circuits too large for the scan kernel's LDS).
     // mu | beta | z | lam are one device slab per circuit.  The scan reads mu and z and only ever WRITES lam (entries set to 1), so
     // only mu | beta | z travel and lam stays in HBM; the few entries a reconnection sets go back as an index list.  Both directions
-    // are ONE kernel for the whole set, reading / writing host-mapped pinned memory directly (a batch of 64 would otherwise issue
-    // 128 copies: 2.5 ms of a 35 ms step).  The scans of a batch are independent: they run on a few persistent host threads.
+    // are ONE kernel for the whole set, reading / writing host-mapped pinned memory directly.
     const size_t per = 2 * (size_t)N + p->K;                           // doubles per circuit (N, K are those of the group)
     size_t nnz_tot = 0;
     for (int c = 0; c < B; ++c) nnz_tot += (size_t)s.ps[c]->nnz;
@@ -726,16 +730,10 @@ static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_option
     CM_LAUNCH_SET(k_fn_gather, s, (unsigned)((per + 255) / 256), 256, 0, st, dbase, per);
     CM_HIP(hipStreamSynchronize(st));
     std::vector<std::vector<int32_t>> ones(B);
-    auto scan = [&](int c) {
+    for (int c = 0; c < B; ++c) {
       const cm_problem* q = s.ps[c];
       double* h = hbase + (size_t)c * per;
       cm_host_reconnect(host_rows(q), h, h + N, nullptr, h + 2 * (size_t)N, o->msrmp, o->minimum_spike_count, o->verbose, &ones[c]);
-    };
-    if (B > 1 && o->verbose == 0) {
-      if (!ctx->pool_host) ctx->pool_host = new cm_host_pool((int)std::max(1u, std::min(15u, std::thread::hardware_concurrency() > 1 ? std::thread::hardware_concurrency() - 1 : 1u)));
-      ctx->pool_host->run(B, scan);
-    } else {
-      for (int c = 0; c < B; ++c) scan(c);
     }
     size_t start = 0;
     for (int c = 0; c < B; ++c) {                                      // lam[e] = 1 for the reconnected cells' events (:136)
@@ -1126,18 +1124,27 @@ extern "C" int cm_k_lam_sweep(cm_ctx* ctx, int32_t N, int32_t K, const double* s
 extern "C" int cm_k_reconnect(cm_ctx* ctx, int32_t N, int32_t K, const double* stim, double* lam, double* mu, double* beta, double* z,
                               double minimax_spk_prob, double minimum_spike_count) {
   if (!ctx || !stim || !lam || !mu || !beta || !z) { cm_set_error("cm_k_reconnect: NULL argument"); return CM_ERR_INVALID; }
+  CM_HIP(hipSetDevice(ctx->device));
   cm_problem* p = nullptr;
-  CM_TRY(problem_from_dense(ctx, N, K, stim, lam, nullptr, &p));     // builds the compressed rows (device) + host mirror
-  const size_t nnz = p->nnz;
-  std::vector<double> vm(mu, mu + N), vb(beta, beta + N), vz(z, z + K), vl(nnz ? nnz : 1);
-  for (int n = 0; n < N; ++n)
-    for (int e = p->h_row_ptr[n]; e < p->h_row_ptr[n + 1]; ++e) vl[e] = lam[(size_t)n * K + p->h_col[e]];
-  cm_host_reconnect(host_rows(p), vm.data(), vb.data(), vl.data(), vz.data(), minimax_spk_prob, minimum_spike_count, 0);
-  for (int n = 0; n < N; ++n)
-    for (int e = p->h_row_ptr[n]; e < p->h_row_ptr[n + 1]; ++e) lam[(size_t)n * K + p->h_col[e]] = vl[e];
-  std::copy(vm.begin(), vm.end(), mu); std::copy(vb.begin(), vb.end(), beta); std::copy(vz.begin(), vz.end(), z);
+  CM_TRY(problem_from_dense(ctx, N, K, stim, lam, nullptr, &p));     // compressed rows + the dense lam scattered onto them
+  hipStream_t st = ctx->stream;
+  int rc = CM_OK;
+  if (hipMemcpy(p->mu, mu, (size_t)N * 8, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(p->beta, beta, (size_t)N * 8, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(p->z, z, (size_t)K * 8, hipMemcpyHostToDevice) != hipSuccess) { cm_set_error("upload failed"); rc = CM_ERR_HIP; }
+  cm_set set;
+  if (!rc) rc = cm_set_single(ctx, p, &set);
+  if (!rc) rc = cm_launch_fn_scan(ctx, set, minimax_spk_prob, minimum_spike_count);      // the device scan (cm_fnscan.hip), as a run launches it
+  double* d_dense = nullptr;
+  if (!rc) rc = dmalloc(&d_dense, (size_t)N * K);
+  if (!rc) rc = cm_launch_expand_lam(ctx, p, p->lam, d_dense);
+  if (!rc && (hipMemcpyAsync(lam, d_dense, (size_t)N * K * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+              hipMemcpyAsync(mu, p->mu, (size_t)N * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+              hipMemcpyAsync(beta, p->beta, (size_t)N * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+              hipMemcpyAsync(z, p->z, (size_t)K * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+              hipStreamSynchronize(st) != hipSuccess)) { cm_set_error("download failed: %s", hipGetErrorString(hipGetLastError())); rc = CM_ERR_HIP; }
+  if (d_dense) hipFree(d_dense);
   cm_problem_destroy(p);
-  return CM_OK;
+  return rc;
 }
 
 __global__ void k_nop(int* sink) { if (sink && threadIdx.x == 0xFFFFFF) *sink = 0; }

@@ -112,6 +112,7 @@ void cm_host_reconnect(const cm_host_rows& p, double* mu, double* beta, double* 
   }
   std::vector<double> srates(P > 0 ? P : 0);
   std::vector<int> locs;
+  std::vector<double> amp;
   while (!heap.empty()) {
     if (!((double)nz > minimum_spike_count)) break;                           // :111,141
     const Ent top = heap.top();
@@ -137,11 +138,11 @@ void cm_host_reconnect(const cm_host_rows& p, double* mu, double* beta, double* 
       locs.clear();
       for (int e = p.row_ptr[focus]; e < p.row_ptr[focus + 1]; ++e) if (z[p.col[e]] != 0.0) locs.push_back(e);
       const size_t m = locs.size();
-      double s = 0.0;
-      for (int e : locs) s += z[p.col[e]];
-      const double mean = s / (double)m;
-      double ssd = 0.0;
-      for (int e : locs) { const double d = z[p.col[e]] - mean; ssd += d * d; }
+      amp.resize(m);
+      for (size_t i = 0; i < m; ++i) amp[i] = z[p.col[locs[i]]];
+      const double mean = cm_np_sum(amp.data(), (int)m) / (double)m;           // np.mean: NumPy's pairwise sum
+      for (size_t i = 0; i < m; ++i) { const double d = amp[i] - mean; amp[i] = d * d; }
+      const double ssd = cm_np_sum(amp.data(), (int)m);                        // np.std(ddof = 1) inside scipy.stats.sem
       mu[focus] = mean;                                                        // :134
       beta[focus] = m > 1 ? sqrt(ssd / (double)(m - 1)) / sqrt((double)m) : NAN;   // :135 scipy.stats.sem, ddof = 1
       for (int e : locs) {                                                     // :136-137

@@ -27,6 +27,50 @@ inline void cm_threefry2x32_host(uint32_t k0, uint32_t k1, uint32_t& x0, uint32_
   }
 }
 
+// np.add.reduce over a contiguous float64 array as NumPy evaluates it (pairwise summation, numpy/core/src/umath/loops_utils.h.src:
+// below 8 elements a plain loop; up to 128 eight strided partial sums combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) plus the
+// remainder in order; above, halves split at a multiple of 8).  reconnect_spont_cells takes np.mean and scipy.stats.sem of the
+// event amplitudes with it (caviar.py:134-135), so a cell reconnected on 8 or more events gets bitwise NumPy's mean only in this order
+// (checked against numpy.sum for 1000 random arrays of 1..1000 elements when this was written).
+#ifdef __HIPCC__
+#define CM_HD __host__ __device__
+#else
+#define CM_HD
+#endif
+CM_HD static inline double cm_np_sum_block(const double* a, int n) {        // n <= 128
+  if (n < 8) {
+    double r = 0.0;
+    for (int i = 0; i < n; ++i) r += a[i];
+    return r;
+  }
+  double r[8];
+  for (int j = 0; j < 8; ++j) r[j] = a[j];
+  int i = 8;
+  for (; i < n - (n % 8); i += 8)
+    for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+  double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  for (; i < n; ++i) res += a[i];
+  return res;
+}
+CM_HD static inline double cm_np_sum(const double* a, int n) {
+  if (n <= 128) return cm_np_sum_block(a, n);
+  // post-order walk of the split tree with an explicit stack (depth <= log2(n / 64))
+  int off[40], len[40], phase[40];
+  double left[40];
+  int sp = 0;
+  off[0] = 0; len[0] = n; phase[0] = 0;
+  double ret = 0.0;
+  while (sp >= 0) {
+    if (len[sp] <= 128) { ret = cm_np_sum_block(a + off[sp], len[sp]); --sp; continue; }
+    int n2 = len[sp] / 2;
+    n2 -= n2 % 8;
+    if (phase[sp] == 0) { phase[sp] = 1; off[sp + 1] = off[sp]; len[sp + 1] = n2; phase[sp + 1] = 0; ++sp; }
+    else if (phase[sp] == 1) { left[sp] = ret; phase[sp] = 2; off[sp + 1] = off[sp] + n2; len[sp + 1] = len[sp] - n2; phase[sp + 1] = 0; ++sp; }
+    else { ret = left[sp] + ret; --sp; }
+  }
+  return ret;
+}
+
 int cm_perm_rounds(int N);
 void cm_host_key_schedule_range(uint32_t key[2], int it0, int n_it, int N, uint32_t* keys);
 void cm_host_key_schedule(uint64_t seed, int iters, int N, std::vector<uint32_t>& keys);

@@ -2,8 +2,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <condition_variable>
-#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -41,59 +39,6 @@ void cm_set_error(const char* fmt, ...);
     if (_s != CM_OK) return _s;   \
   } while (0)
 
-// A few persistent host threads for the per-circuit host work of a batch (the false-negative scans): spawning threads per call
-// costs more than the scans themselves, and their start-up jitter showed in the batch timings.
-class cm_host_pool {
- public:
-  explicit cm_host_pool(int n) { for (int i = 0; i < n; ++i) th_.emplace_back([this]() { work(); }); }
-  ~cm_host_pool() {
-    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
-    cv_.notify_all();
-    for (auto& t : th_) t.join();
-  }
-  int size() const { return (int)th_.size(); }
-  // runs fn(0) .. fn(n - 1) on the pool (the caller takes part) and returns when all are done
-  void run(int n, const std::function<void(int)>& fn) {
-    { std::lock_guard<std::mutex> lk(mu_); fn_ = &fn; n_ = n; next_ = 0; done_ = 0; ++gen_; }
-    cv_.notify_all();
-    for (;;) {
-      int i;
-      { std::lock_guard<std::mutex> lk(mu_); if (next_ >= n_) break; i = next_++; }
-      fn(i);
-      { std::lock_guard<std::mutex> lk(mu_); ++done_; }
-    }
-    std::unique_lock<std::mutex> lk(mu_);
-    cv_done_.wait(lk, [this]() { return done_ >= n_; });
-    fn_ = nullptr;
-  }
-
- private:
-  void work() {
-    unsigned long long seen = 0;
-    for (;;) {
-      std::unique_lock<std::mutex> lk(mu_);
-      cv_.wait(lk, [&]() { return stop_ || (gen_ != seen && fn_ != nullptr && next_ < n_); });
-      if (stop_) return;
-      seen = gen_;
-      while (fn_ != nullptr && next_ < n_) {
-        const int i = next_++;
-        const std::function<void(int)>* f = fn_;
-        lk.unlock();
-        (*f)(i);
-        lk.lock();
-        if (++done_ >= n_) cv_done_.notify_all();
-      }
-    }
-  }
-  std::vector<std::thread> th_;
-  std::mutex mu_;
-  std::condition_variable cv_, cv_done_;
-  const std::function<void(int)>* fn_ = nullptr;
-  int n_ = 0, next_ = 0, done_ = 0;
-  unsigned long long gen_ = 0;
-  bool stop_ = false;
-};
-
 struct cm_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -113,7 +58,6 @@ struct cm_ctx {
   size_t h_stage_bytes = 0;
   size_t lds_attr[64] = {};       // dynamic-LDS caps already raised for this context's device, by kernel slot (cm_raise_lds)
   long long* dbg_block0 = nullptr; // diagnostic buffer (CAVIAR_HIP_TRACE_BLOCK0): 64 launches x 8 device-clock stamps
-  cm_host_pool* pool_host = nullptr; // host threads for the per-circuit host work of batches (created with the first batch)
   void* d_pdev = nullptr;         // descriptors of the current batch (device) and their pinned source
   void* h_pdev = nullptr;
   size_t pdev_cap = 0;
@@ -424,7 +368,7 @@ inline void cm_threefry2x32(uint32_t k0, uint32_t k1, uint32_t& x0, uint32_t& x1
 enum cm_lds_slot { CM_LDS_ITER = 0 /* 7 x 2 x 2 template variants */, CM_LDS_SOLVE_SMALL = 28, CM_LDS_SWEEP_PAR, CM_LDS_SWEEP_PAR2, CM_LDS_SWEEP_SEQ,
                    CM_LDS_NWD, CM_LDS_SIM_SORT, CM_LDS_BUILD_PREC, CM_LDS_SWEEP_PAR_B, CM_LDS_SWEEP_PAR2_B, CM_LDS_SWEEP_SEQ_B,
                    CM_LDS_SOLVE_SMALL_B, CM_LDS_BUILD_PREC_B, CM_LDS_ITER_LISTED /* 7 SEG variants */, CM_LDS_MC_DEAD = 47, CM_LDS_MC_DEAD_B, CM_LDS_ITER_OVERFLOW /* 7 SEG variants */, CM_LDS_CHOL_DIAG = 56, CM_LDS_CHOL_GPANEL, CM_LDS_CHOL_WIDE,
-                   CM_LDS_CHOL_DIAG_B, CM_LDS_CHOL_GPANEL_B, CM_LDS_CHOL_WIDE_B, CM_LDS_SLOTS = 62 };
+                   CM_LDS_CHOL_DIAG_B, CM_LDS_CHOL_GPANEL_B, CM_LDS_CHOL_WIDE_B, CM_LDS_FN_SCAN, CM_LDS_FN_SCAN_B, CM_LDS_SLOTS = 64 };
 static_assert(CM_LDS_SLOTS <= 64, "cm_ctx::lds_attr");
 // Table update AND runtime call under ONE lock: `set(fn, bytes, user)` is invoked while the table's mutex is held, and the table takes
 // the new value only after the setter succeeded -- two host threads (contexts on one GPU) can therefore never apply their values in
@@ -466,4 +410,6 @@ int cm_launch_post_single(cm_ctx* ctx, cm_set& s, int it, const cm_options* o, i
 int cm_wait_active(cm_ctx* ctx, cm_set& s);
 int cm_launch_update_phi(cm_ctx* ctx, cm_set& s, hipStream_t st, int use_dead = 0);
 int cm_launch_phi_dead(cm_ctx* ctx, cm_set& s, hipStream_t st);
+bool cm_fn_scan_fits(const cm_set& s);
+int cm_launch_fn_scan(cm_ctx* ctx, cm_set& s, double minimax_spk_prob, double minimum_spike_count);   // reconnect_spont_cells on the device (cm_fnscan.hip)
 

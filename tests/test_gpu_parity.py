@@ -722,3 +722,33 @@ def test_cholesky_families_bitwise_equal(ctx, monkeypatch, N, K, B, iters):
     for c in range(B):
         _assert_same_fit(res[0][c], res[1][c], "family 1 vs 0, circuit %d" % c)
     assert np.count_nonzero(res[0][0][0]) > 0
+
+
+def test_device_fn_scan_vs_oracle_random(ctx):
+    """reconnect_spont_cells on the device (cm_fnscan.hip, one workgroup per circuit; cm_k_reconnect runs the kernel a fit runs): random
+    scenarios against the oracle's literal restatement of caviar.py:102-144 -- several reconnections per case, ties in the event counts
+    (first maximum in cell order), single-event reconnections (sem = NaN, quirk 7), minimum_spike_count 1..3, one to three powers,
+    long rows -- mu, lam, z bit for bit, beta to 1e-14."""
+    import warnings
+    from circuitmap_amd import _lib
+    from oracle import caviar_oracle as co
+    rng = np.random.default_rng(11)
+    for trial in range(14):
+        N, K = int(rng.integers(3, 40)), int(rng.integers(12, 300))
+        H = int(rng.integers(1, min(N, 6) + 1))
+        powers = np.array([30.0, 50.0, 70.0])[: int(rng.integers(1, 4))]
+        stim = np.zeros((N, K))
+        for k in range(K):
+            stim[rng.choice(N, H, replace=False), k] = powers[rng.integers(0, len(powers))]
+        lam = rng.random((N, K)) * (stim > 0)
+        mu = rng.normal(5, 2, N) * (rng.random(N) > 0.6)
+        z = rng.uniform(2, 6, K) * (rng.random(K) > (0.4 if trial % 2 else 0.85))
+        mc = float(rng.integers(1, 4))
+        minimax = 0.2
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want = co.reconnect_spont_cells(np.zeros(K), stim, lam, mu, rng.random(N) * 0 + 0.5, z, minimax, mc)
+        gl, gm, gb, gz = _lib.f64(lam).copy(), _lib.f64(mu).copy(), 0.5 * np.ones(N), _lib.f64(z).copy()
+        _lib.check(ctx.lib.cm_k_reconnect(ctx.handle, N, K, _lib.dptr(_lib.f64(stim)), _lib.dptr(gl), _lib.dptr(gm), _lib.dptr(gb), _lib.dptr(gz), minimax, mc))
+        assert np.array_equal(gm, want[0]) and np.array_equal(gl, want[2]) and np.array_equal(gz, want[3]), trial
+        assert np.allclose(gb, want[1], rtol=1e-14, atol=0, equal_nan=True), trial

@@ -69,8 +69,10 @@ def test_reconnect_golden_and_random(exe):
     g = np.load(GOLDEN + "/units.npz")
     cases = [(g["stim"], g["lam"], g["rec_mu_in"], g["bum_beta"], g["rec_z_in"], 0.3, 3.0, (g["rec_mu"], g["rec_beta"], g["rec_lam"], g["rec_z"]))]
     rng = np.random.default_rng(4)
-    for trial in range(6):                                # random scenarios against the oracle, incl. single-event reconnections (NaN sem)
+    for trial in range(10):                               # random scenarios against the oracle, incl. single-event reconnections (NaN sem)
         N, K = int(rng.integers(3, 9)), int(rng.integers(12, 40))
+        if trial >= 6:                                    # long rows: cells reconnect on 8+ (up to > 128) events -> NumPy's pairwise mean / sem (cm_np_sum)
+            N, K = int(rng.integers(3, 6)), int(rng.integers(150, 900))
         powers = np.array([30.0, 50.0, 70.0])[: int(rng.integers(1, 4))]
         stim = np.zeros((N, K))
         for k in range(K):
