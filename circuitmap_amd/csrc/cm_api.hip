@@ -212,7 +212,7 @@ extern "C" int cm_problem_destroy(cm_problem* p) {
   if (!p) return CM_OK;
   hipSetDevice(p->ctx->device);
   hipStreamSynchronize(p->ctx->stream);
-  void* ptrs[] = {p->y, p->ss, p->sum_y, p->vals, p->row_ptr, p->col, p->grp, p->rowcnt, p->col_ptr, p->csc_row, p->csc_pos,
+  void* ptrs[] = {p->y, p->ss, p->sum_y, p->vals, p->row_ptr, p->col, p->grp, p->rowcnt, p->col_ptr, p->csc_row, p->csc_pos, p->csc_grp,
                   p->mask, p->ye, p->me, p->slab, p->pslab, p->phi, p->phi_cov, p->phi_dead,
                   p->R, p->colany, p->mcE, p->rs, p->act_idx, p->act_inv, p->n_act, p->alive, p->orders_all, p->orders_tmp, p->inv_all, p->wtab,
                   p->keys, p->uexp, p->A, p->X, p->Lf, p->Dinv, p->rhs, p->seq_n, p->seq_off, p->seq_pos, p->chunk_first,
@@ -306,7 +306,7 @@ void cm_fill_pdev(const cm_problem* p, const cm_problem* r, int* mailbox, cm_pde
   memset(d, 0, sizeof(*d));
   d->N = p->N; d->K = p->K; d->V = p->V; d->small_cap = p->small_cap; d->max_row_len = p->max_row_len; d->ld_alloc = p->ld; d->nnz = p->nnz;
   d->y = p->y; d->ss = p->ss; d->sum_y = p->sum_y; d->vals = p->vals; d->row_ptr = p->row_ptr; d->col = p->col; d->grp = p->grp;
-  d->rowcnt = p->rowcnt; d->col_ptr = p->col_ptr; d->csc_row = p->csc_row; d->csc_pos = p->csc_pos; d->mask = p->mask; d->colany = p->colany; d->ye = p->ye; d->me = p->me;
+  d->rowcnt = p->rowcnt; d->col_ptr = p->col_ptr; d->csc_row = p->csc_row; d->csc_pos = p->csc_pos; d->csc_grp = p->csc_grp; d->mask = p->mask; d->colany = p->colany; d->ye = p->ye; d->me = p->me;
   d->lam = p->lam; d->mu = p->mu; d->beta = p->beta; d->phi = p->phi; d->phi_cov = p->phi_cov; d->scal = p->scal; d->R = p->R; d->z = p->z;
   d->mcE = p->mcE; d->rs = p->rs; d->phi_dead = p->phi_dead; d->phi_cov_dead = p->phi_dead ? p->phi_dead + 2 * (size_t)p->N : nullptr; d->phi_c_dead = p->phi_dead ? p->phi_dead + 6 * (size_t)p->N : nullptr; d->pslab = p->pslab; d->mu_prior = p->mu_prior; d->beta_prior = p->beta_prior; d->phi_prior = p->phi_prior;
   d->phi_cov_prior = p->phi_cov_prior; d->act_idx = p->act_idx; d->act_inv = p->act_inv; d->n_act = p->n_act; d->alive = p->alive; d->seq_n = p->seq_n;

@@ -56,7 +56,7 @@ struct cm_ctx {
   int num_cus = 256;
   void* h_stage = nullptr;        // pinned staging buffer (priors upload, fn_scan round trip), grown on demand
   size_t h_stage_bytes = 0;
-  size_t lds_attr[64] = {};       // dynamic-LDS caps already raised for this context's device, by kernel slot (cm_raise_lds)
+  size_t lds_attr[72] = {};       // dynamic-LDS caps already raised for this context's device, by kernel slot (cm_raise_lds)
   long long* dbg_block0 = nullptr; // diagnostic buffer (CAVIAR_HIP_TRACE_BLOCK0): 64 launches x 8 device-clock stamps
   void* d_pdev = nullptr;         // descriptors of the current batch (device) and their pinned source
   void* h_pdev = nullptr;
@@ -86,6 +86,7 @@ struct cm_problem {
   int32_t* col_ptr = nullptr; // [K+1] CSC
   int32_t* csc_row = nullptr; // [nnz] neuron index
   int32_t* csc_pos = nullptr; // [nnz] position of the entry in CSR order
+  uint8_t* csc_grp = nullptr; // [nnz] power code of the entry (grp[csc_pos[ce]])
   // host mirror of the CSR (for reconnect_spont_cells and dense expansion)
   std::vector<int32_t> h_row_ptr, h_col, h_col_ptr, h_csc_row;
   std::vector<uint8_t> h_grp;
@@ -163,6 +164,7 @@ struct cm_pdev {
   const int *row_ptr, *col;
   const uint8_t* grp;
   const int *rowcnt, *col_ptr, *csc_row, *csc_pos;
+  const uint8_t* csc_grp;
   uint8_t *mask, *colany;
   const double* ye; const uint8_t* me;      // per-entry copies of y and mask (refreshed by k_init_state / cm_launch_entry_copies)
   double *lam, *mu, *beta, *phi, *phi_cov, *scal, *R, *z, *mcE, *rs;
@@ -368,8 +370,8 @@ inline void cm_threefry2x32(uint32_t k0, uint32_t k1, uint32_t& x0, uint32_t& x1
 enum cm_lds_slot { CM_LDS_ITER = 0 /* 7 x 2 x 2 template variants */, CM_LDS_SOLVE_SMALL = 28, CM_LDS_SWEEP_PAR, CM_LDS_SWEEP_PAR2, CM_LDS_SWEEP_SEQ,
                    CM_LDS_NWD, CM_LDS_SIM_SORT, CM_LDS_BUILD_PREC, CM_LDS_SWEEP_PAR_B, CM_LDS_SWEEP_PAR2_B, CM_LDS_SWEEP_SEQ_B,
                    CM_LDS_SOLVE_SMALL_B, CM_LDS_BUILD_PREC_B, CM_LDS_ITER_LISTED /* 7 SEG variants */, CM_LDS_MC_DEAD = 47, CM_LDS_MC_DEAD_B, CM_LDS_ITER_OVERFLOW /* 7 SEG variants */, CM_LDS_CHOL_DIAG = 56, CM_LDS_CHOL_GPANEL, CM_LDS_CHOL_WIDE,
-                   CM_LDS_CHOL_DIAG_B, CM_LDS_CHOL_GPANEL_B, CM_LDS_CHOL_WIDE_B, CM_LDS_FN_SCAN, CM_LDS_FN_SCAN_B, CM_LDS_SLOTS = 64 };
-static_assert(CM_LDS_SLOTS <= 64, "cm_ctx::lds_attr");
+                   CM_LDS_CHOL_DIAG_B, CM_LDS_CHOL_GPANEL_B, CM_LDS_CHOL_WIDE_B, CM_LDS_FN_SCAN, CM_LDS_FN_SCAN_B, CM_LDS_FN_SCAN_G, CM_LDS_FN_SCAN_GB, CM_LDS_SLOTS = 66 };
+static_assert(CM_LDS_SLOTS <= 72, "cm_ctx::lds_attr");
 // Table update AND runtime call under ONE lock: `set(fn, bytes, user)` is invoked while the table's mutex is held, and the table takes
 // the new value only after the setter succeeded -- two host threads (contexts on one GPU) can therefore never apply their values in
 // the opposite order of their table updates (the smaller request landing last would leave the attribute below what the table and both

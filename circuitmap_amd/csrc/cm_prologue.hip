@@ -206,6 +206,11 @@ __global__ __launch_bounds__(256) void k_csc_scatter(const int* __restrict__ row
     csc_pos[w] = e;
   }
 }
+// power code of every CSC entry (csc_grp[ce] = grp[csc_pos[ce]]): lets a walk over a trial's column read the codes without the dependent gather
+__global__ __launch_bounds__(256) void k_csc_grp(const int* __restrict__ csc_pos, const uint8_t* __restrict__ grp, long long nnz, uint8_t* __restrict__ csc_grp) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nnz) csc_grp[i] = grp[csc_pos[i]];
+}
 __global__ __launch_bounds__(256) void k_csc_sort(const int* __restrict__ col_ptr, int K, int* __restrict__ csc_row, int* __restrict__ csc_pos) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= K) return;
@@ -272,6 +277,8 @@ int cm_encode_stim(cm_ctx* ctx, cm_problem* p, const double* d_stim) {
   CM_HIP(hipMemsetAsync(d_col_cnt, 0, (size_t)K * sizeof(int), st));            // reused as the per-column cursors
   hipLaunchKernelGGL(k_csc_scatter, dim3(row_blocks), dim3(256), 0, st, p->row_ptr, p->col, N, p->col_ptr, d_col_cnt, p->csc_row, p->csc_pos);
   hipLaunchKernelGGL(k_csc_sort, dim3((K + 255) / 256), dim3(256), 0, st, p->col_ptr, K, p->csc_row, p->csc_pos);
+  CM_HIP(hipMalloc(&p->csc_grp, nnz_alloc));
+  hipLaunchKernelGGL(k_csc_grp, dim3((unsigned)((nnz_alloc + 255) / 256)), dim3(256), 0, st, p->csc_pos, p->grp, (long long)p->nnz, p->csc_grp);
   CM_HIP(hipGetLastError());
   p->h_col.resize(nnz_alloc);
   p->h_grp.resize(nnz_alloc);
