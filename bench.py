@@ -287,6 +287,75 @@ def measure_batch(ctx, local_rank, wl, pri, iters, B, seed0, steps, warmup, sync
     return dt, tms
 
 
+def end_to_end(_lib, ctx, local_rank, wl, pri, a, B):
+    """The whole call, not only the fit (the reference's `model.time` wraps everything, circuitmap/model.py:105-148): the same B circuits
+    (a) from inputs already in HBM -- cm_problem_create(CM_MEM_DEVICE) x B, one lock-step cm_caviar_run_batch, cm_caviar_fetch of
+    mu / beta / phi / phi_cov / z, cm_problem_destroy -- and (b) from host arrays through the C entry point cm_caviar_fit_batch (upload over
+    PCIe included; the dense N x K lam is not requested).  Never `value`: the headline keeps inputs resident."""
+    import numpy as np
+    from circuitmap_amd.optimise.caviar import Problem, run_batch, make_options, _priors_struct
+    from circuitmap_amd.simulation import simulate_device
+    N, K, T, H = wl["N"], wl["K"], wl["T"], wl["H"]
+    opts = dict(iters=a.iters, seed=0)
+    devs = [simulate_device(N=N, T=T, H=H, trials=K, seed=a.circuit_seed + j, device_id=local_rank, keep_on_device=True, ctx=ctx) for j in range(B)]
+    res = {}
+
+    def dev_pass():
+        t = [time.perf_counter()]
+        probs = [Problem(ctx, None, None, device_ptrs=(N, K, T, d["psc_ptr"], d["stim_ptr"])) for d in devs]
+        ctx.synchronize(); t.append(time.perf_counter())
+        run_batch(probs, pri, **opts)
+        ctx.synchronize(); t.append(time.perf_counter())
+        outs = [q.fetch(want_lam=False) for q in probs]
+        t.append(time.perf_counter())
+        for q in probs:
+            q.close()
+        t.append(time.perf_counter())
+        return [(t[i + 1] - t[i]) * 1e3 for i in range(4)], outs[0][0]
+    dev_pass()
+    best = None
+    for _ in range(3):
+        ms, mu0 = dev_pass()
+        if best is None or sum(ms) < sum(best):
+            best = ms
+    tot = sum(best)
+    res["device_resident"] = {"ms": tot, "value": B * a.iters / tot * 1e3, "unit": "iterations/s", "create_ms": best[0], "create_ms_per_circuit": best[0] / B,
+                              "fit_ms": best[1], "fetch_ms": best[2], "destroy_ms": best[3],
+                              "note": "inputs in HBM: cm_problem_create(CM_MEM_DEVICE) x B (two allocations + one host wait each), one lock-step batch, "
+                                      "fetch of mu / beta / phi / phi_cov / z per circuit, destroy; best of 3"}
+    # (b) host arrays through the C entry point
+    hosts = [(ctx.download(d["psc_ptr"], np.empty((K, T))), ctx.download(d["stim_ptr"], np.empty((N, K)))) for d in devs]
+    for d in devs:
+        ctx.free(d["psc_ptr"]); ctx.free(d["stim_ptr"])
+    lib = ctx.lib
+    o = make_options(lib, **opts)
+    keep = []
+    prs = (_lib.CmPriors * B)(*[_priors_struct(N, pri["mu"], pri["beta"], pri["shape"], pri["rate"], pri["phi"], pri["phi_cov"], keep) for _ in range(B)])
+    resv = (_lib.CmResult * B)()
+    bufs = []
+    for c in range(B):
+        ob = dict(mu=np.empty(N), beta=np.empty(N), phi=np.empty((N, 2)), phi_cov=np.empty((N, 2, 2)), z=np.empty(K))
+        for k_, v in ob.items():
+            setattr(resv[c], k_, _lib.dptr(v))
+        bufs.append(ob)
+    i32 = lambda v: (C.c_int32 * B)(*v)
+    dpp = lambda arrs: (C.POINTER(C.c_double) * B)(*[_lib.dptr(x) for x in arrs])
+    args = (B, i32([N] * B), i32([K] * B), i32([T] * B), dpp([h[0] for h in hosts]), dpp([h[1] for h in hosts]), prs, C.byref(o),
+            (C.c_int32 * 1)(local_rank), 1, resv, None)
+    _lib.check(lib.cm_caviar_fit_batch(*args))
+    hbest = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        _lib.check(lib.cm_caviar_fit_batch(*args))
+        dt = (time.perf_counter() - t0) * 1e3
+        hbest = dt if hbest is None else min(hbest, dt)
+    res["host_arrays"] = {"ms": hbest, "value": B * a.iters / hbest * 1e3, "unit": "iterations/s", "upload_bytes": int(B * (K * T + N * K) * 8),
+                          "same_mu_as_device_resident": bool(np.array_equal(bufs[0]["mu"], mu0)),
+                          "note": "cm_caviar_fit_batch: context, upload of psc + stim (pageable host memory over PCIe), create, one lock-step batch, fetch "
+                                  "(no dense lam), destroy; best of 2"}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -307,6 +376,8 @@ def main():
     ap.add_argument("--no-single-leg", action="store_true", help="with B > 1 on one GPU: skip the one-circuit-at-a-time measurement that is "
                     "otherwise reported beside the batch under `single_circuit`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the `end_to_end` leg (problem creation + fit + fetch of the same B circuits, from "
+                    "device-resident inputs and from host arrays through cm_caviar_fit_batch)")
     ap.add_argument("--phases", action="store_true", help="stamp every phase of every iteration (more host API calls)")
     ap.add_argument("--circuit-seed", type=int, default=2000, help="seed of rank 0's synthetic circuit (rank r uses seed + r)")
     ap.add_argument("--host-sim", action="store_true", help="generate the synthetic experiments with the NumPy restatement on the host "
@@ -586,6 +657,8 @@ def main():
             out["batch_equals_single_note"] = ("circuit 0 of the timed lock-step batch vs its own single fit on the same problem object, "
                                                "bitwise over mu, beta, lam, shape, rate, phi, phi_cov, z")
             del batch_res0, single_res0
+        if world == 1 and B > 1 and not a.no_end_to_end and a.workload != "cfg5":
+            out["end_to_end"] = end_to_end(_lib, ctx, local_rank, wl, pri, a, B)
         if world == 1 and B > 1 and a.streams_leg and a.streams_leg > 1 and G == 1:
             # the same B circuits as several lock-step batches in flight on separate contexts (HIP streams), one host thread each
             for probs_ in sets:                              # (the main measurement's circuits are released first)

@@ -212,15 +212,35 @@ extern "C" int cm_problem_destroy(cm_problem* p) {
   if (!p) return CM_OK;
   hipSetDevice(p->ctx->device);
   hipStreamSynchronize(p->ctx->stream);
-  void* ptrs[] = {p->y, p->ss, p->sum_y, p->vals, p->row_ptr, p->col, p->grp, p->rowcnt, p->col_ptr, p->csc_row, p->csc_pos, p->csc_grp,
-                  p->mask, p->ye, p->me, p->slab, p->pslab, p->phi, p->phi_cov, p->phi_dead,
-                  p->R, p->colany, p->mcE, p->rs, p->act_idx, p->act_inv, p->n_act, p->alive, p->orders_all, p->orders_tmp, p->inv_all, p->wtab,
-                  p->keys, p->uexp, p->A, p->X, p->Lf, p->Dinv, p->rhs, p->seq_n, p->seq_off, p->seq_pos, p->chunk_first,
-                  p->seq_meta, p->packed};
+  // the two slabs hold every static / state buffer; the random tables of a run (sized by iters, S) are allocated by the run
+  void* ptrs[] = {p->slabA, p->slabB, p->orders_all, p->orders_tmp, p->inv_all, p->wtab, p->keys, p->uexp};
   for (void* q : ptrs) if (q) hipFree(q);
   free_hist(p);
   delete p;
   return CM_OK;
+}
+
+// carves aligned pieces out of one allocation: first pass (base == nullptr) only sizes it
+struct cm_carver {
+  char* base = nullptr; size_t off = 0;
+  template <typename T> void take(T** out, size_t n) { if (base) *out = reinterpret_cast<T*>(base + off); off = (off + (n ? n : 1) * sizeof(T) + 255) & ~(size_t)255; }
+};
+static void carve_a(cm_problem* p, cm_carver& c) {           // sizes known from N, K
+  const size_t N = p->N, K = p->K, ld = p->ld;
+  c.take(&p->y, K); c.take(&p->ss, K); c.take(&p->sum_y, 2); c.take(&p->vals, CM_MAX_VALS); c.take(&p->rowcnt, N * CM_MAX_VALS);
+  c.take(&p->row_ptr, N + 1); c.take(&p->col_ptr, K + 1); c.take(&p->mask, K); c.take(&p->pslab, 8 * N + CM_S_COUNT); c.take(&p->phi, 2 * N);
+  c.take(&p->phi_cov, 4 * N); c.take(&p->phi_dead, 8 * N); c.take(&p->R, K); c.take(&p->colany, K); c.take(&p->mcE, N * CM_MAX_VALS);
+  c.take(&p->rs, 4 * N); c.take(&p->act_idx, N); c.take(&p->act_inv, N); c.take(&p->n_act, 4); c.take(&p->alive, N + 1);
+  c.take(&p->A, ld * (ld + CM_LD_PAD)); c.take(&p->X, ld * (ld + CM_LD_PAD)); c.take(&p->Lf, ld * (ld + CM_LD_PAD)); c.take(&p->Dinv, ld * CM_TILE);
+  c.take(&p->rhs, 2 * ld); c.take(&p->seq_n, N); c.take(&p->seq_off, N + 1); c.take(&p->seq_pos, N); c.take(&p->seq_meta, 8);
+  c.take(&p->enc_table, CM_MAX_VALS); c.take(&p->enc_flags, 8); c.take(&p->enc_row_nnz, N); c.take(&p->enc_col_cnt, K);
+}
+static void carve_b(cm_problem* p, cm_carver& c) {           // sizes that need nnz
+  const size_t N = p->N, K = p->K, nnz = p->nnz > 0 ? (size_t)p->nnz : 1;
+  c.take(&p->col, nnz); c.take(&p->grp, nnz); c.take(&p->csc_row, nnz); c.take(&p->csc_pos, nnz); c.take(&p->csc_grp, nnz);
+  c.take(&p->ye, nnz + 1); c.take(&p->me, nnz + 1); c.take(&p->slab, 2 * N + K + nnz);
+  c.take(&p->chunk_first, (N + nnz) / 256 + 8);
+  char* pk = nullptr; c.take(&pk, (N + nnz) * 32); if (c.base) p->packed = pk;
 }
 
 extern "C" int cm_problem_create(cm_ctx* ctx, int32_t N, int32_t K, int32_t T, const double* psc, const double* stim, int mem_kind,
@@ -231,9 +251,19 @@ extern "C" int cm_problem_create(cm_ctx* ctx, int32_t N, int32_t K, int32_t T, c
   hipStream_t st = ctx->stream;
   cm_problem* p = new cm_problem();
   p->ctx = ctx; p->N = N; p->K = K; p->T = T;
+  p->ld = ((N + CM_TILE - 1) / CM_TILE) * CM_TILE;
   int rc = CM_OK;
   double *d_psc = nullptr, *d_stim = nullptr;
   auto fail = [&](int code) { if (mem_kind == CM_MEM_HOST) { if (d_psc) hipFree(d_psc); if (d_stim) hipFree(d_stim); } cm_problem_destroy(p); return code; };
+  // Two allocations per circuit instead of ~50 (each hipMalloc is tens of microseconds of driver time; creating the 128 circuits of a
+  // batch was 0.2 s in front of a 35 ms fit): slab A holds everything N and K size, slab B what needs nnz.
+  {
+    cm_carver sz;
+    carve_a(p, sz);
+    if (hipMalloc(&p->slabA, sz.off) != hipSuccess) { cm_set_error("cm_problem_create: out of device memory (%zu bytes)", sz.off); return fail(CM_ERR_HIP); }
+    cm_carver c; c.base = (char*)p->slabA;
+    carve_a(p, c);
+  }
   if (mem_kind == CM_MEM_HOST) {
     if ((rc = dmalloc(&d_psc, (size_t)K * T)) || (rc = dmalloc(&d_stim, (size_t)N * K))) return fail(rc);
     if (hipMemcpyAsync(d_psc, psc, (size_t)K * T * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
@@ -245,31 +275,25 @@ extern "C" int cm_problem_create(cm_ctx* ctx, int32_t N, int32_t K, int32_t T, c
     d_psc = const_cast<double*>(psc);
     d_stim = const_cast<double*>(stim);
   }
-  if ((rc = dmalloc(&p->y, K)) || (rc = dmalloc(&p->ss, K)) || (rc = dmalloc(&p->sum_y, 2))) return fail(rc);
   if ((rc = cm_launch_psc_prologue(ctx, K, T, d_psc, p->y, p->ss))) return fail(rc);
-  if ((rc = cm_encode_stim(ctx, p, d_stim))) return fail(rc);
-  if (mem_kind == CM_MEM_HOST) { hipFree(d_psc); hipFree(d_stim); d_psc = d_stim = nullptr; }
-
-  p->ld = ((N + CM_TILE - 1) / CM_TILE) * CM_TILE;
-  const size_t ld = p->ld;
-  if ((rc = dmalloc(&p->mask, K)) || (rc = dmalloc(&p->ye, (size_t)p->nnz + 1)) || (rc = dmalloc(&p->me, (size_t)p->nnz + 1)) ||
-      (rc = dmalloc(&p->slab, 2 * (size_t)N + K + (size_t)p->nnz)) ||
-      (rc = dmalloc(&p->pslab, 8 * (size_t)N + CM_S_COUNT)) || (rc = dmalloc(&p->phi, 2 * (size_t)N)) ||
-      (rc = dmalloc(&p->phi_cov, 4 * (size_t)N)) || (rc = dmalloc(&p->phi_dead, 8 * (size_t)N)) || (rc = dmalloc(&p->R, K)) ||
-      (rc = dmalloc(&p->colany, K)) || (rc = dmalloc(&p->mcE, (size_t)N * CM_MAX_VALS)) ||
-      (rc = dmalloc(&p->rs, 4 * (size_t)N)) || (rc = dmalloc(&p->act_idx, N)) || (rc = dmalloc(&p->act_inv, N)) ||
-      (rc = dmalloc(&p->n_act, 4)) || (rc = dmalloc(&p->alive, (size_t)N + 1)) || (rc = dmalloc(&p->A, ld * (ld + CM_LD_PAD))) || (rc = dmalloc(&p->X, ld * (ld + CM_LD_PAD))) ||
-      (rc = dmalloc(&p->Lf, ld * (ld + CM_LD_PAD))) ||
-      (rc = dmalloc(&p->Dinv, ld * CM_TILE)) || (rc = dmalloc(&p->rhs, 2 * ld)) || (rc = dmalloc(&p->seq_n, N)) ||
-      (rc = dmalloc(&p->seq_off, (size_t)N + 1)) || (rc = dmalloc(&p->seq_pos, N)) || (rc = dmalloc(&p->chunk_first, ((size_t)N + p->nnz) / 256 + 8)) ||
-      (rc = dmalloc(&p->seq_meta, 8)) || (rc = dmalloc((char**)&p->packed, ((size_t)N + p->nnz) * 32)))
-    return fail(rc);
-  p->mu = p->slab; p->beta = p->slab + N; p->z = p->slab + 2 * (size_t)N; p->lam = p->slab + 2 * (size_t)N + K;
-  p->mu_prior = p->pslab; p->beta_prior = p->pslab + N; p->phi_prior = p->pslab + 2 * (size_t)N;
-  p->phi_cov_prior = p->pslab + 4 * (size_t)N; p->scal = p->pslab + 8 * (size_t)N;
-  if (hipMemsetAsync(p->mcE, 0, (size_t)N * CM_MAX_VALS * sizeof(double), st) != hipSuccess ||
-      hipMemsetAsync(p->alive, 0, ((size_t)N + 1) * sizeof(int), st) != hipSuccess) return fail(CM_ERR_HIP);
+  if ((rc = cm_encode_stim_stage1(ctx, p, d_stim))) return fail(rc);          // (the one host wait in the middle: nnz)
+  {
+    cm_carver sz;
+    carve_b(p, sz);
+    if (hipMalloc(&p->slabB, sz.off) != hipSuccess) { cm_set_error("cm_problem_create: out of device memory (%zu bytes)", sz.off); return fail(CM_ERR_HIP); }
+    cm_carver c; c.base = (char*)p->slabB;
+    carve_b(p, c);
+  }
+  if ((rc = cm_encode_stim_stage2(ctx, p, d_stim))) return fail(rc);
+  const size_t Nz = N;
+  p->mu = p->slab; p->beta = p->slab + Nz; p->z = p->slab + 2 * Nz; p->lam = p->slab + 2 * Nz + K;
+  p->mu_prior = p->pslab; p->beta_prior = p->pslab + Nz; p->phi_prior = p->pslab + 2 * Nz;
+  p->phi_cov_prior = p->pslab + 4 * Nz; p->scal = p->pslab + 8 * Nz;
+  if (hipMemsetAsync(p->mcE, 0, Nz * CM_MAX_VALS * sizeof(double), st) != hipSuccess ||
+      hipMemsetAsync(p->alive, 0, (Nz + 1) * sizeof(int), st) != hipSuccess) return fail(CM_ERR_HIP);
   if (hipStreamSynchronize(st) != hipSuccess) { cm_set_error("prologue failed: %s", hipGetErrorString(hipGetLastError())); return fail(CM_ERR_HIP); }
+  p->max_col_len = ctx->h_pinned[8 + 3];
+  if (mem_kind == CM_MEM_HOST) { hipFree(d_psc); hipFree(d_stim); d_psc = d_stim = nullptr; }
   *out = p;
   return CM_OK;
 }
@@ -730,6 +754,7 @@ static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_option
     CM_LAUNCH_SET(k_fn_gather, s, (unsigned)((per + 255) / 256), 256, 0, st, dbase, per);
     CM_HIP(hipStreamSynchronize(st));
     std::vector<std::vector<int32_t>> ones(B);
+    for (int c = 0; c < B; ++c) CM_TRY(cm_host_mirror(ctx, s.ps[c]));
     for (int c = 0; c < B; ++c) {
       const cm_problem* q = s.ps[c];
       double* h = hbase + (size_t)c * per;
@@ -826,6 +851,7 @@ extern "C" int cm_caviar_fetch(cm_ctx* ctx, cm_problem* p, cm_result* r) {
   double sc[CM_S_COUNT];
   CM_HIP(hipMemcpyAsync(sc, p->scal, sizeof(sc), k, st));
   std::vector<double> sp;
+  if (r->lam || (p->hist_iters > 0 && r->lam_hist)) CM_TRY(cm_host_mirror(ctx, p));
   if (r->lam) {   // compressed rows over PCIe, dense expansion on the host (lam is zero off the targeted trials)
     sp.resize(nnz ? nnz : 1);
     if (nnz) CM_HIP(hipMemcpyAsync(sp.data(), p->lam, nnz * 8, k, st));

@@ -88,6 +88,9 @@ struct cm_problem {
   int32_t* csc_pos = nullptr; // [nnz] position of the entry in CSR order
   uint8_t* csc_grp = nullptr; // [nnz] power code of the entry (grp[csc_pos[ce]])
   // host mirror of the CSR (for reconnect_spont_cells and dense expansion)
+  bool have_mirror = false;       // the vectors below are filled (cm_host_mirror)
+  void *slabA = nullptr, *slabB = nullptr;   // the two allocations behind every static / state pointer below (sizes from N, K; from nnz)
+  unsigned long long* enc_table = nullptr; int32_t *enc_flags = nullptr, *enc_row_nnz = nullptr, *enc_col_cnt = nullptr;   // scratch of the encoding (slab A)
   std::vector<int32_t> h_row_ptr, h_col, h_col_ptr, h_csc_row;
   std::vector<uint8_t> h_grp;
   std::vector<double> h_vals;
@@ -391,7 +394,9 @@ inline int cm_raise_lds(cm_ctx* ctx, int slot, const void* fn, size_t bytes, siz
 // phase launchers (each enqueues kernels on ctx->stream; no host sync unless stated)
 // ------------------------------------------------------------------------------------------------
 int cm_launch_psc_prologue(cm_ctx* ctx, int K, int T, const double* d_psc, double* d_y, double* d_ss);
-int cm_encode_stim(cm_ctx* ctx, cm_problem* p, const double* d_stim);               // syncs (sizes nnz)
+int cm_encode_stim_stage1(cm_ctx* ctx, cm_problem* p, const double* d_stim);        // syncs once: V, nnz, longest row
+int cm_encode_stim_stage2(cm_ctx* ctx, cm_problem* p, const double* d_stim);        // enqueues the nnz-sized part (no wait)
+int cm_host_mirror(cm_ctx* ctx, cm_problem* p);                                      // host copy of the compressed rows, on first use
 int cm_launch_entry_copies(cm_ctx* ctx, cm_set& s);                                  // ye / me from the current y / mask (after a test hook uploaded either)
 int cm_launch_init_state(cm_ctx* ctx, cm_set& s, double y_xcorr_thresh);             // state from the uploaded priors, lam0, mask, z, counters
 int cm_launch_scatter_dense_lam(cm_ctx* ctx, cm_problem* p, const double* d_lam_dense);

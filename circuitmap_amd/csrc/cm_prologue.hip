@@ -223,77 +223,84 @@ __global__ __launch_bounds__(256) void k_csc_sort(const int* __restrict__ col_pt
   }
 }
 
-int cm_encode_stim(cm_ctx* ctx, cm_problem* p, const double* d_stim) {
+// longest row / column of a CSR / CSC pointer array -> *out (atomicMax; out zeroed by the caller)
+__global__ __launch_bounds__(256) void k_max_len(const int* __restrict__ ptr, int n, int* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int v = i < n ? ptr[i + 1] - ptr[i] : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, CM_WAVE));
+  if (threadIdx.x % CM_WAVE == 0 && v > 0) atomicMax(out, v);
+}
+
+// The encoding in two stages around ONE host wait.  Stage 1 (everything whose size N and K give): distinct values, per-row value counts,
+// row pointers, longest row -> the host reads (too many values?, V, nnz, longest row) from host-mapped memory.  Stage 2 (sized by nnz, in the
+// second slab): CSR entries, CSC, power codes of the CSC entries, longest column -- enqueued, not waited for (cm_problem_create's final
+// synchronisation covers it).  All buffers live in the problem's two slabs: no allocation here.
+int cm_encode_stim_stage1(cm_ctx* ctx, cm_problem* p, const double* d_stim) {
   const int N = p->N, K = p->K;
   hipStream_t st = ctx->stream;
-  unsigned long long* d_table = nullptr;
-  int *d_flags = nullptr, *d_row_nnz = nullptr, *d_col_cnt = nullptr;
-  CM_HIP(hipMalloc(&d_table, CM_MAX_VALS * sizeof(unsigned long long)));
-  CM_HIP(hipMalloc(&d_flags, 4 * sizeof(int)));
-  CM_HIP(hipMalloc(&d_row_nnz, (size_t)N * sizeof(int)));
-  CM_HIP(hipMalloc(&d_col_cnt, (size_t)K * sizeof(int)));
-  CM_HIP(hipMemsetAsync(d_table, 0xFF, CM_MAX_VALS * sizeof(unsigned long long), st));
-  CM_HIP(hipMemsetAsync(d_flags, 0, 4 * sizeof(int), st));
-  CM_HIP(hipMalloc(&p->vals, CM_MAX_VALS * sizeof(double)));
-  CM_HIP(hipMalloc(&p->rowcnt, (size_t)N * CM_MAX_VALS * sizeof(int)));
+  CM_HIP(hipMemsetAsync(p->enc_table, 0xFF, CM_MAX_VALS * sizeof(unsigned long long), st));
+  CM_HIP(hipMemsetAsync(p->enc_flags, 0, 8 * sizeof(int), st));
   CM_HIP(hipMemsetAsync(p->rowcnt, 0, (size_t)N * CM_MAX_VALS * sizeof(int), st));
-  CM_HIP(hipMalloc(&p->row_ptr, (size_t)(N + 1) * sizeof(int)));
-  CM_HIP(hipMalloc(&p->col_ptr, (size_t)(K + 1) * sizeof(int)));
-
   const size_t total = (size_t)N * K;
   int blocks = (int)((total + 255) / 256);
   if (blocks > ctx->num_cus * 8) blocks = ctx->num_cus * 8;
-  hipLaunchKernelGGL(k_stim_distinct, dim3(blocks), dim3(256), 0, st, d_stim, total, d_table, d_flags);
-  hipLaunchKernelGGL(k_vals_finalize, dim3(1), dim3(64), 0, st, d_table, p->vals, d_flags + 1);
+  hipLaunchKernelGGL(k_stim_distinct, dim3(blocks), dim3(256), 0, st, d_stim, total, p->enc_table, p->enc_flags);
+  hipLaunchKernelGGL(k_vals_finalize, dim3(1), dim3(64), 0, st, p->enc_table, p->vals, p->enc_flags + 1);
   const int row_blocks = (N + 3) / 4;
-  hipLaunchKernelGGL(k_stim_rowcount, dim3(row_blocks), dim3(256), 0, st, d_stim, N, K, p->vals, d_flags + 1, p->rowcnt, d_row_nnz);
-  hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, st, d_row_nnz, N, p->row_ptr);
+  hipLaunchKernelGGL(k_stim_rowcount, dim3(row_blocks), dim3(256), 0, st, d_stim, N, K, p->vals, p->enc_flags + 1, p->rowcnt, p->enc_row_nnz);
+  hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, st, p->enc_row_nnz, N, p->row_ptr);
+  hipLaunchKernelGGL(k_max_len, dim3((N + 255) / 256), dim3(256), 0, st, p->row_ptr, N, p->enc_flags + 2);
   CM_HIP(hipGetLastError());
-
-  int h_flags[4];
-  p->h_row_ptr.resize(N + 1);
-  CM_HIP(hipMemcpyAsync(h_flags, d_flags, sizeof(h_flags), hipMemcpyDeviceToHost, st));
-  CM_HIP(hipMemcpyAsync(p->h_row_ptr.data(), p->row_ptr, (size_t)(N + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
+  // (too many values, V, longest row, -) and nnz = row_ptr[N] into the context's pinned scratch words [8..15], then the one wait
+  int* h = ctx->h_pinned + 8;
+  CM_HIP(hipMemcpyAsync(h, p->enc_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+  CM_HIP(hipMemcpyAsync(h + 4, p->row_ptr + N, sizeof(int), hipMemcpyDeviceToHost, st));
   CM_HIP(hipStreamSynchronize(st));
-  if (h_flags[0]) {
-    hipFree(d_table); hipFree(d_flags); hipFree(d_row_nnz); hipFree(d_col_cnt);
-    cm_set_error("stimulus matrix has more than %d distinct values", CM_MAX_VALS);
-    return CM_ERR_TOO_MANY_POWERS;
-  }
-  p->V = h_flags[1];
-  p->nnz = p->h_row_ptr[N];
-  p->max_row_len = 0;
-  for (int n = 0; n < N; ++n) p->max_row_len = std::max(p->max_row_len, p->h_row_ptr[n + 1] - p->h_row_ptr[n]);
+  if (h[0]) { cm_set_error("stimulus matrix has more than %d distinct values", CM_MAX_VALS); return CM_ERR_TOO_MANY_POWERS; }
+  p->V = h[1];
+  p->max_row_len = h[2];
+  p->nnz = h[4];
   p->small_cap = cm_small_cap(p);
+  return CM_OK;
+}
+
+int cm_encode_stim_stage2(cm_ctx* ctx, cm_problem* p, const double* d_stim) {
+  const int N = p->N, K = p->K;
+  hipStream_t st = ctx->stream;
+  const int row_blocks = (N + 3) / 4;
   const size_t nnz_alloc = p->nnz > 0 ? (size_t)p->nnz : 1;
-  CM_HIP(hipMalloc(&p->col, nnz_alloc * sizeof(int)));
-  CM_HIP(hipMalloc(&p->grp, nnz_alloc));
-  CM_HIP(hipMalloc(&p->csc_row, nnz_alloc * sizeof(int)));
-  CM_HIP(hipMalloc(&p->csc_pos, nnz_alloc * sizeof(int)));
-  hipLaunchKernelGGL(k_stim_fill_csr, dim3(row_blocks), dim3(256), 0, st, d_stim, N, K, p->vals, d_flags + 1, p->row_ptr, p->col, p->grp);
-  CM_HIP(hipMemsetAsync(d_col_cnt, 0, (size_t)K * sizeof(int), st));
-  hipLaunchKernelGGL(k_csc_count, dim3(row_blocks), dim3(256), 0, st, p->row_ptr, p->col, N, d_col_cnt);
-  hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, st, d_col_cnt, K, p->col_ptr);
-  CM_HIP(hipMemsetAsync(d_col_cnt, 0, (size_t)K * sizeof(int), st));            // reused as the per-column cursors
-  hipLaunchKernelGGL(k_csc_scatter, dim3(row_blocks), dim3(256), 0, st, p->row_ptr, p->col, N, p->col_ptr, d_col_cnt, p->csc_row, p->csc_pos);
+  hipLaunchKernelGGL(k_stim_fill_csr, dim3(row_blocks), dim3(256), 0, st, d_stim, N, K, p->vals, p->enc_flags + 1, p->row_ptr, p->col, p->grp);
+  CM_HIP(hipMemsetAsync(p->enc_col_cnt, 0, (size_t)K * sizeof(int), st));
+  hipLaunchKernelGGL(k_csc_count, dim3(row_blocks), dim3(256), 0, st, p->row_ptr, p->col, N, p->enc_col_cnt);
+  hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, st, p->enc_col_cnt, K, p->col_ptr);
+  CM_HIP(hipMemsetAsync(p->enc_col_cnt, 0, (size_t)K * sizeof(int), st));            // reused as the per-column cursors
+  hipLaunchKernelGGL(k_csc_scatter, dim3(row_blocks), dim3(256), 0, st, p->row_ptr, p->col, N, p->col_ptr, p->enc_col_cnt, p->csc_row, p->csc_pos);
   hipLaunchKernelGGL(k_csc_sort, dim3((K + 255) / 256), dim3(256), 0, st, p->col_ptr, K, p->csc_row, p->csc_pos);
-  CM_HIP(hipMalloc(&p->csc_grp, nnz_alloc));
   hipLaunchKernelGGL(k_csc_grp, dim3((unsigned)((nnz_alloc + 255) / 256)), dim3(256), 0, st, p->csc_pos, p->grp, (long long)p->nnz, p->csc_grp);
+  hipLaunchKernelGGL(k_max_len, dim3((K + 255) / 256), dim3(256), 0, st, p->col_ptr, K, p->enc_flags + 3);
   CM_HIP(hipGetLastError());
-  p->h_col.resize(nnz_alloc);
-  p->h_grp.resize(nnz_alloc);
-  p->h_vals.resize(CM_MAX_VALS);
+  CM_HIP(hipMemcpyAsync(ctx->h_pinned + 8 + 3, p->enc_flags + 3, sizeof(int), hipMemcpyDeviceToHost, st));   // longest column: read after the caller's synchronisation
+  return CM_OK;
+}
+
+// host mirror of the compressed rows: only the host-side false-negative scan (verbose runs, shapes the scan kernel does not take) and the
+// dense expansion of a fetched lam need it -- copied on first use
+int cm_host_mirror(cm_ctx* ctx, cm_problem* p) {
+  if (p->have_mirror) return CM_OK;
+  const int N = p->N, K = p->K;
+  const size_t nnz_alloc = p->nnz > 0 ? (size_t)p->nnz : 1;
+  hipStream_t st = ctx->stream;
+  p->h_row_ptr.resize(N + 1); p->h_col.resize(nnz_alloc); p->h_grp.resize(nnz_alloc); p->h_vals.resize(CM_MAX_VALS);
+  p->h_col_ptr.resize(K + 1); p->h_csc_row.resize(nnz_alloc);
+  CM_HIP(hipMemcpyAsync(p->h_row_ptr.data(), p->row_ptr, (size_t)(N + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
   CM_HIP(hipMemcpyAsync(p->h_col.data(), p->col, (size_t)p->nnz * sizeof(int), hipMemcpyDeviceToHost, st));
   CM_HIP(hipMemcpyAsync(p->h_grp.data(), p->grp, (size_t)p->nnz, hipMemcpyDeviceToHost, st));
   CM_HIP(hipMemcpyAsync(p->h_vals.data(), p->vals, CM_MAX_VALS * sizeof(double), hipMemcpyDeviceToHost, st));
-  p->h_col_ptr.resize(K + 1);
-  p->h_csc_row.resize(nnz_alloc);
   CM_HIP(hipMemcpyAsync(p->h_col_ptr.data(), p->col_ptr, (size_t)(K + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
   CM_HIP(hipMemcpyAsync(p->h_csc_row.data(), p->csc_row, (size_t)p->nnz * sizeof(int), hipMemcpyDeviceToHost, st));
   CM_HIP(hipStreamSynchronize(st));
-  p->max_col_len = 0;
-  for (int k = 0; k < K; ++k) p->max_col_len = std::max(p->max_col_len, p->h_col_ptr[k + 1] - p->h_col_ptr[k]);
-  hipFree(d_table); hipFree(d_flags); hipFree(d_row_nnz); hipFree(d_col_cnt);
+  p->have_mirror = true;
   return CM_OK;
 }
 
