@@ -4,7 +4,8 @@ CAVIaR does not shard within a circuit (the sweep is a sequential chain with one
 circuits are independent, so the multi-GPU path is embarrassingly parallel: one process per GPU
 (`torch.distributed`, backend "nccl" = RCCL over xGMI on MI355X, "gloo" in CPU tests), rank r fits circuits
 r, r + W, r + 2W, ...  The only collectives are a broadcast of the shared priors / fit options from rank 0 before the
-sweep and a gather of the per-circuit results to rank 0 after it; nothing is exchanged inside the iteration loop.
+sweep, optionally a scatter of the circuits themselves when only rank 0 holds them (`scatter=True`), and a gather of the
+per-circuit results to rank 0 after it; nothing is exchanged inside the iteration loop.
 (The reference has no multi-device path at all: it scales out with SLURM job arrays of single-GPU processes,
 reference scripts/generate_loho_cv_slurm_scripts.py:8-36.)
 """
@@ -62,8 +63,14 @@ def _fit_lockstep(circuits, mine, priors, fit_options, device_id, max_group, str
     groups = [mine[g0:g0 + max_group] for g0 in range(0, len(mine), max_group)]
     out = {}
 
+    def make_problem(ctx, c):
+        if len(c) == 2:
+            return Problem(ctx, *c)                                   # host arrays (psc, stim)
+        _, t, N, K, T = c                                             # ("device", float64 CUDA tensor [K*T + N*K], N, K, T): a scattered circuit, never on this host
+        return Problem(ctx, None, None, device_ptrs=(N, K, T, t.data_ptr(), t.data_ptr() + K * T * 8))
+
     def fit_group(ctx, idx):
-        probs = [Problem(ctx, *circuits[ci]) for ci in idx]
+        probs = [make_problem(ctx, circuits[ci]) for ci in idx]
         try:
             run_batch(probs, priors, **fit_options)
             for ci, q in zip(idx, probs):
@@ -97,13 +104,54 @@ def _fit_lockstep(circuits, mine, priors, fit_options, device_id, max_group, str
     return [out[ci] for ci in mine]
 
 
-def fit_batch(circuits, priors=None, fit_options=None, fit_fn=None, device=None, group=None, circuits_per_launch=32, streams=4):
+def _scatter_circuits(circuits, n_total, shape, rank, world, device, group):
+    """Rank 0 holds every circuit's host arrays; rank r receives the circuits shard_indices(n_total, r, world) -- one `dist.scatter` per slot
+    (RCCL over xGMI with the "nccl" backend: rank 0 stages a slot's `world` circuits in HBM, the receivers get device tensors that go
+    straight into cm_problem_create(CM_MEM_DEVICE); gloo: CPU tensors).  Returns {circuit index: circuit} for this rank, rank 0 included."""
+    import torch
+    import torch.distributed as dist
+    N, K, T = shape
+    L = K * T + N * K
+    mine = shard_indices(n_total, rank, world)
+    n_slots = (n_total + world - 1) // world
+    local = {}
+    for slot in range(n_slots):
+        recv = torch.empty(L, dtype=torch.float64, device=device)
+        parts = None
+        if rank == 0:
+            parts = []
+            for r in range(world):
+                idx = shard_indices(n_total, r, world)
+                if slot < len(idx):
+                    psc, stim = circuits[idx[slot]]
+                    flat = np.concatenate([np.ascontiguousarray(psc, dtype=np.float64).ravel(), np.ascontiguousarray(stim, dtype=np.float64).ravel()])
+                    parts.append(torch.from_numpy(flat).to(device))
+                else:
+                    parts.append(torch.zeros(L, dtype=torch.float64, device=device))     # (equal-size payloads: a rank without a circuit in this slot)
+        dist.scatter(recv, parts, src=0, group=group)
+        if slot < len(mine):
+            if device.type == "cuda":
+                local[mine[slot]] = ("device", recv, N, K, T)
+            else:
+                a = recv.numpy()
+                local[mine[slot]] = (a[:K * T].reshape(K, T), a[K * T:].reshape(N, K))
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)                                # the library reads the tensors on its own stream
+    return local
+
+
+def fit_batch(circuits, priors=None, fit_options=None, fit_fn=None, device=None, group=None, circuits_per_launch=32, streams=4, scatter=False):
     """Fit a list of circuits [(psc K x T, stim N x K), ...] across the ranks of the default process group.
 
     Rank 0's `priors` / `fit_options` are broadcast to every rank.  Returns, on rank 0, a list of result dicts
     (mu, beta, shape, rate, phi, phi_cov, z) in circuit order; on other ranks None.  Without an initialised process
     group it degenerates to one GPU.  `fit_fn(psc, stim, priors, fit_options, device_id)` is injectable so that the sharding /
     collective logic can be exercised on CPU with the gloo backend (then the circuits are fitted one by one).
+
+    `scatter=False`: every rank already holds every circuit's arrays (e.g. read from shared storage) and fits its share.
+    `scatter=True`: only rank 0 holds data (`circuits` may be None elsewhere); it sends each rank its share first (`dist.scatter`, one
+    slot of `world` circuits at a time; on GPUs the receivers keep the circuits in HBM and never copy them to their hosts).  All
+    circuits must then have one shape (N, K, T).
 
     On a GPU each rank fits its share as LOCK-STEP BATCHES of up to `circuits_per_launch` circuits (C ABI cm_caviar_run_batch): one
     set of kernel launches per phase for the whole batch, one Gauss-Seidel workgroup per circuit; `streams` such batches run at a
@@ -122,14 +170,24 @@ def fit_batch(circuits, priors=None, fit_options=None, fit_fn=None, device=None,
     device_id = device.index if device.type == "cuda" else 0
 
     # ---- broadcast of the shared configuration (rank 0 -> all)
+    shape = None
     if distributed:
-        box = [(priors, fit_options, len(circuits))] if rank == 0 else [None]
+        if rank == 0:
+            shape = (np.asarray(circuits[0][1]).shape + (np.asarray(circuits[0][0]).shape[1],)) if len(circuits) else (0, 0, 0)
+            if scatter and any(np.asarray(c[1]).shape + (np.asarray(c[0]).shape[1],) != shape for c in circuits):
+                raise ValueError("fit_batch(scatter=True) needs circuits of one shape")
+        box = [(priors, fit_options, len(circuits), shape)] if rank == 0 else [None]
         dist.broadcast_object_list(box, src=0, group=group, device=device if backend == "nccl" else None)
-        priors, fit_options, n_total = box[0]
+        priors, fit_options, n_total, shape = box[0]
+        if scatter and n_total > 0:
+            circuits = _scatter_circuits(circuits, n_total, shape, rank, world, device, group)
     else:
         n_total = len(circuits)
     fit_options = dict(fit_options or {})
-    N, K = np.asarray(circuits[0][1]).shape if len(circuits) else (0, 0)
+    if shape is not None:
+        N, K = int(shape[0]), int(shape[1])
+    else:
+        N, K = np.asarray(circuits[0][1]).shape if len(circuits) else (0, 0)
     if priors is None:
         from .model import Model
         priors = Model(N).priors
@@ -144,7 +202,12 @@ def fit_batch(circuits, priors=None, fit_options=None, fit_fn=None, device=None,
             local[slot] = torch.from_numpy(_pack(res, N, K))
     else:
         for slot, ci in enumerate(mine):
-            psc, stim = circuits[ci]
+            c = circuits[ci]
+            if len(c) != 2:                                           # a scattered circuit on a GPU: the injected fit wants host arrays
+                _, t, n_, k_, t_ = c
+                a = t.cpu().numpy()
+                c = (a[:k_ * t_].reshape(k_, t_), a[k_ * t_:].reshape(n_, k_))
+            psc, stim = c
             local[slot] = torch.from_numpy(_pack(fit_fn(psc, stim, priors, fit_options, device_id), N, K))
 
     # ---- gather of the results (all -> rank 0)

@@ -35,29 +35,32 @@ def _make_circuits(n):
     return out
 
 
-def _worker(rank, world, port, n_circuits, q):
+def _worker(rank, world, port, n_circuits, q, scatter=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
     from circuitmap_amd import batch
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     try:
-        circuits = _make_circuits(n_circuits)
+        # scatter=True: the data exists on rank 0 only and travels to the other rank through the scatter
+        circuits = _make_circuits(n_circuits) if (rank == 0 or not scatter) else None
         # only rank 0 supplies the options: the others must receive them through the broadcast
         opts = dict(iters=4, num_mc_samples=5, seed=2) if rank == 0 else None
-        res = batch.fit_batch(circuits, priors=None, fit_options=opts, fit_fn=_oracle_fit)
+        res = batch.fit_batch(circuits, priors=None, fit_options=opts, fit_fn=_oracle_fit, scatter=scatter)
         q.put((rank, res))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_circuits", [5, 2])
-def test_fit_batch_two_ranks_equals_serial(n_circuits):
+@pytest.mark.parametrize("n_circuits,scatter", [(5, False), (2, False), (5, True), (1, True)])
+def test_fit_batch_two_ranks_equals_serial(n_circuits, scatter):
+    """scatter=False: both ranks hold every circuit; scatter=True: only rank 0 does, rank 1 passes circuits=None and receives its share
+    (5 circuits: ranks own 3 and 2 -- the last slot carries a padding payload; 1 circuit: rank 1 owns nothing)."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_circuits, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_circuits, q, scatter)) for r in range(2)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=300) for _ in range(2))

@@ -752,3 +752,26 @@ def test_device_fn_scan_vs_oracle_random(ctx):
         _lib.check(ctx.lib.cm_k_reconnect(ctx.handle, N, K, _lib.dptr(_lib.f64(stim)), _lib.dptr(gl), _lib.dptr(gm), _lib.dptr(gb), _lib.dptr(gz), minimax, mc))
         assert np.array_equal(gm, want[0]) and np.array_equal(gl, want[2]) and np.array_equal(gz, want[3]), trial
         assert np.allclose(gb, want[1], rtol=1e-14, atol=0, equal_nan=True), trial
+
+
+def test_fit_lockstep_accepts_scattered_device_circuits():
+    """What a rank holds after fit_batch(scatter=True) over RCCL: float64 CUDA tensors [psc | stim] that never existed on its host.  They go into
+    cm_problem_create(CM_MEM_DEVICE) by address; the fit equals the one from host arrays bit for bit."""
+    import torch
+    from circuitmap_amd import batch
+    from circuitmap_amd.optimise import caviar
+    N, K, T = 40, 120, 900
+    pri = default_priors(N)
+    opts = dict(iters=6, seed=1)
+    sims = [_sim_case(N, K, 60 + c)[0] for c in range(3)]
+    circuits = {}
+    for c, sim in enumerate(sims):
+        flat = np.concatenate([sim["psc"].ravel(), sim["stim_matrix"].ravel()])
+        circuits[c] = ("device", torch.from_numpy(flat).cuda(), N, K, T)
+    torch.cuda.synchronize()
+    got = batch._fit_lockstep(circuits, [0, 1, 2], pri, opts, 0, 8, streams=1)
+    for sim, g in zip(sims, got):
+        res = caviar(sim["psc"], sim["stim_matrix"], *prior_args(pri), **opts)
+        for i, nm in enumerate(OUT_NAMES):
+            if nm != "lam":
+                np.testing.assert_array_equal(np.asarray(res[i], dtype=float), np.asarray(g[nm], dtype=float), err_msg=nm)
