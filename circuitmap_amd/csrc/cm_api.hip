@@ -227,7 +227,7 @@ struct cm_carver {
 };
 static void carve_a(cm_problem* p, cm_carver& c) {           // sizes known from N, K
   const size_t N = p->N, K = p->K, ld = p->ld;
-  c.take(&p->y, K); c.take(&p->ss, K); c.take(&p->sum_y, 2); c.take(&p->vals, CM_MAX_VALS); c.take(&p->rowcnt, N * CM_MAX_VALS);
+  c.take(&p->y, K); c.take(&p->ss, K); c.take(&p->sum_y, 2); c.take(&p->vals, CM_MAX_VALS); c.take(&p->rowcnt, N * CM_MAX_VALS); c.take(&p->mcnt, N * CM_MAX_VALS); c.take(&p->qcnt, N * 8); c.take(&p->touch, N);
   c.take(&p->row_ptr, N + 1); c.take(&p->col_ptr, K + 1); c.take(&p->mask, K); c.take(&p->pslab, 8 * N + CM_S_COUNT); c.take(&p->phi, 2 * N);
   c.take(&p->phi_cov, 4 * N); c.take(&p->phi_dead, 8 * N); c.take(&p->R, K); c.take(&p->colany, K); c.take(&p->mcE, N * CM_MAX_VALS);
   c.take(&p->rs, 4 * N); c.take(&p->act_idx, N); c.take(&p->act_inv, N); c.take(&p->n_act, 4); c.take(&p->alive, N + 1);
@@ -330,7 +330,8 @@ void cm_fill_pdev(const cm_problem* p, const cm_problem* r, int* mailbox, cm_pde
   memset(d, 0, sizeof(*d));
   d->N = p->N; d->K = p->K; d->V = p->V; d->small_cap = p->small_cap; d->max_row_len = p->max_row_len; d->ld_alloc = p->ld; d->nnz = p->nnz;
   d->y = p->y; d->ss = p->ss; d->sum_y = p->sum_y; d->vals = p->vals; d->row_ptr = p->row_ptr; d->col = p->col; d->grp = p->grp;
-  d->rowcnt = p->rowcnt; d->col_ptr = p->col_ptr; d->csc_row = p->csc_row; d->csc_pos = p->csc_pos; d->csc_grp = p->csc_grp; d->mask = p->mask; d->colany = p->colany; d->ye = p->ye; d->me = p->me;
+  d->rowcnt = p->rowcnt; d->col_ptr = p->col_ptr; d->csc_row = p->csc_row; d->csc_pos = p->csc_pos; d->csc_grp = p->csc_grp; d->mask = p->mask; d->colany = p->colany; d->ye = p->ye; d->me = p->me; d->mcnt = p->mcnt; d->touch = p->touch; d->qcnt = p->qcnt;
+  { int l = 1; while (l < p->V) l <<= 1; d->mce_ld = l; }
   d->lam = p->lam; d->mu = p->mu; d->beta = p->beta; d->phi = p->phi; d->phi_cov = p->phi_cov; d->scal = p->scal; d->R = p->R; d->z = p->z;
   d->mcE = p->mcE; d->rs = p->rs; d->phi_dead = p->phi_dead; d->phi_cov_dead = p->phi_dead ? p->phi_dead + 2 * (size_t)p->N : nullptr; d->phi_c_dead = p->phi_dead ? p->phi_dead + 6 * (size_t)p->N : nullptr; d->pslab = p->pslab; d->mu_prior = p->mu_prior; d->beta_prior = p->beta_prior; d->phi_prior = p->phi_prior;
   d->phi_cov_prior = p->phi_cov_prior; d->act_idx = p->act_idx; d->act_inv = p->act_inv; d->n_act = p->n_act; d->alive = p->alive; d->seq_n = p->seq_n;
@@ -688,7 +689,7 @@ static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_option
     if (phases) CM_HIP(hipEventRecord(EV(it, 1), st));
     CM_TRY(cm_launch_sweep(ctx, s, it, o, timed ? EV(it, 3) : nullptr));  // :81  update_lam
     if (timed) CM_HIP(hipEventRecord(EV(it, 4), st));
-    CM_TRY(cm_launch_stats(ctx, s, o->spont_orthogonality));         // row + column statistics of the new lam
+    CM_TRY(cm_launch_stats(ctx, s, o->spont_orthogonality, cm_sweep_quiescent(ctx, s, it, o)));   // row + column statistics of the new lam
     if (rng_deferred) {
       // The work of this iteration is enqueued and the GPU is busy with it: extend the (sequential, host-side) threefry key
       // chain (~17 us per iteration at N = 1000) and turn it into sweep orders / ndtri tables on the side stream.  Three chunks,

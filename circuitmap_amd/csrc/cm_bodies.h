@@ -23,9 +23,14 @@ __device__ __forceinline__ void cm_col_dot16(int t, int K, const double* __restr
     const int ce = beg + c0 + j;
     double v = 0.0;
     if (ce < end) {
-      const double l = lam[csc_pos[ce]];
-      v = mu[csc_row[ce]] * l;
-      any |= (l >= orth);
+      // without the "any" output only rows with mu != 0 contribute (mu * lam = +0 exactly otherwise: lam is finite and >= 0), and those are
+      // a few percent of the entries in the steady state: lam is gathered for them alone
+      const double m = mu[csc_row[ce]];
+      if (colany || m != 0.0) {
+        const double l = lam[csc_pos[ce]];
+        v = m * l;
+        any |= (l >= orth);
+      }
     }
     s += cm_seg_sum<16>(v);
   }
@@ -58,8 +63,10 @@ __device__ __forceinline__ void cm_col_dot16x2(int t, int K, const double* __res
   const bool in0 = ce0 < end0, in1 = ce1 < end1;
   const int p0 = in0 ? csc_pos[ce0] : 0, r0 = in0 ? csc_row[ce0] : 0;
   const int p1 = in1 ? csc_pos[ce1] : 0, r1 = in1 ? csc_row[ce1] : 0;
-  const double l0 = in0 ? lam[p0] : 0.0, m0 = in0 ? mu[r0] : 0.0;
-  const double l1 = in1 ? lam[p1] : 0.0, m1 = in1 ? mu[r1] : 0.0;
+  const double m0 = in0 ? mu[r0] : 0.0, m1 = in1 ? mu[r1] : 0.0;
+  // (without the "any" output lam is gathered only where mu != 0: mu * lam = +0 exactly otherwise -- see cm_col_dot16)
+  const double l0 = (in0 && (colany || m0 != 0.0)) ? lam[p0] : 0.0;
+  const double l1 = (in1 && (colany || m1 != 0.0)) ? lam[p1] : 0.0;
   double s0 = 0.0, s1 = 0.0;
   if (end0 > beg0) s0 += cm_seg_sum<16>(in0 ? m0 * l0 : 0.0);          // (a column without entries adds nothing: s stays +0.0)
   if (end1 > beg1) s1 += cm_seg_sum<16>(in1 ? m1 * l1 : 0.0);
@@ -667,7 +674,7 @@ template <bool FULL, bool HAVE_C = false, bool PRE = false>
 __device__ __forceinline__ void mc_logit_body(int n, int lane, double mean0, double mean1, double sd0, double sd1,
                                               const double2* __restrict__ wu, const double* __restrict__ vals, int V, int S,
                                               double* mc, double* __restrict__ mcE, const double* etab, double c0_in = 0.0, double c1_in = 0.0,
-                                              const double2* pre = nullptr) {
+                                              const double2* pre = nullptr, int mld = CM_MAX_VALS) {
   const double c0 = HAVE_C ? c0_in : normcdf(-mean0 / sd0), c1 = HAVE_C ? c1_in : normcdf(-mean1 / sd1);
 #pragma unroll
   for (int comp = 0; comp < 2; ++comp) {
@@ -706,7 +713,7 @@ __device__ __forceinline__ void mc_logit_body(int n, int lane, double mean0, dou
     if (m0 * vmax + m1 < 36.0) {
       a0 = cm_wave_sum(a0); a1 = cm_wave_sum(a1);
       const double e0 = a0 / (double)S, e1 = a1 / (double)S;
-      if (lane < V && vals[lane] > 0.0) mcE[(size_t)n * CM_MAX_VALS + lane] = e0 * vals[lane] - e1;
+      if (lane < V && vals[lane] > 0.0) mcE[(size_t)n * mld + lane] = e0 * vals[lane] - e1;
       return;
     }
   }
@@ -757,7 +764,7 @@ __device__ __forceinline__ void mc_logit_body(int n, int lane, double mean0, dou
       }
     }
     const double mean = tot / (double)S;
-    if (lane < P) mcE[(size_t)n * CM_MAX_VALS + (lane == 0 ? gi[0] : (lane == 1 ? gi[1] : (lane == 2 ? gi[2] : gi[3])))] = mean;
+    if (lane < P) mcE[(size_t)n * mld + (lane == 0 ? gi[0] : (lane == 1 ? gi[1] : (lane == 2 ? gi[2] : gi[3])))] = mean;
     __builtin_amdgcn_wave_barrier();                 // (a caller's next row rewrites the scratch)
     return;
   }
@@ -767,7 +774,7 @@ __device__ __forceinline__ void mc_logit_body(int n, int lane, double mean0, dou
     double acc = 0.0;
     for (int s = lane; s < S; s += CM_WAVE) acc += cm_logit_of_sigmoid(mc[2 * s] * v - mc[2 * s + 1], etab);
     acc = cm_wave_sum(acc);
-    if (lane == 0) mcE[(size_t)n * CM_MAX_VALS + g] = acc / (double)S;
+    if (lane == 0) mcE[(size_t)n * mld + g] = acc / (double)S;
   }
 }
 

@@ -99,6 +99,9 @@ struct cm_problem {
   uint8_t* mask = nullptr;    // [K] lam_mask
   double* ye = nullptr;       // [nnz] y[col[e]]: per-entry copy of the trial's response (y is constant during a run) -- the row kernels
   uint8_t* me = nullptr;      // [nnz] mask[col[e]]                 read it contiguously instead of gathering 8 (1) bytes per 64-byte line
+  int32_t* qcnt = nullptr;    // [N*8] per power: unmasked trials << 16 | trials (compact copy for the closed-form gate of all-zero rows)
+  int32_t* mcnt = nullptr;    // [N*CM_MAX_VALS] unmasked trials of row n at each stimulus value (per run: the mask depends on y_xcorr_thresh)
+  uint8_t* touch = nullptr;   // [N] the pre-sweep wrote this (previously all-zero) row in the current iteration: k_stats must look at it
   double* slab = nullptr;     // one allocation: mu | beta | z | lam (so the false-negative scan moves them in one copy each way)
   double* pslab = nullptr;    // one allocation: mu_prior | beta_prior | phi_prior | phi_cov_prior | scal
   double* lam = nullptr;      // [nnz] CSR order
@@ -162,6 +165,7 @@ enum {
 // ------------------------------------------------------------------------------------------------
 struct cm_pdev {
   int N, K, V, small_cap, max_row_len, ld_alloc;
+  int mce_ld;                    // row stride of mcE: the smallest power of two >= V (the logits of a row sit in one cache line for V <= 8)
   long long nnz;
   const double *y, *ss, *sum_y, *vals;
   const int *row_ptr, *col;
@@ -170,6 +174,8 @@ struct cm_pdev {
   const uint8_t* csc_grp;
   uint8_t *mask, *colany;
   const double* ye; const uint8_t* me;      // per-entry copies of y and mask (refreshed by k_init_state / cm_launch_entry_copies)
+  const int* mcnt; uint8_t* touch;          // unmasked trials per (row, value); rows the pre-sweep revived this iteration
+  const int* qcnt;                          // [N*8] power q of row n: unmasked trials << 16 | trials (quiescent_gate; valid for <= 8 powers, rows < 65536 trials)
   double *lam, *mu, *beta, *phi, *phi_cov, *scal, *R, *z, *mcE, *rs;
   double *phi_dead, *phi_cov_dead, *phi_c_dead;   // update_phi of an all-zero row, per neuron, and ndtr(-mean / sdev) of it: constants of a run (k_phi_dead)
   const double *pslab, *mu_prior, *beta_prior, *phi_prior, *phi_cov_prior;
@@ -412,7 +418,8 @@ int cm_launch_rng(cm_ctx* ctx, cm_problem* p, int it0, int n_it, hipStream_t st)
 int cm_launch_sweep(cm_ctx* ctx, cm_set& s, int it, const cm_options* o, hipEvent_t mid, int table_it = -1);   // table_it: iteration whose sweep order is used (default: it)
 int cm_launch_sum_y(cm_ctx* ctx, cm_set& s);
 int cm_sweep_variant(const cm_set& s, int rows_hint);
-int cm_launch_stats(cm_ctx* ctx, cm_set& s, double spont_orthogonality);
+int cm_launch_stats(cm_ctx* ctx, cm_set& s, double spont_orthogonality, int quiescent = 0);   // quiescent: cm_sweep_quiescent() of the sweep just launched
+int cm_sweep_quiescent(const cm_ctx* ctx, const cm_set& s, int it, const cm_options* o);
 int cm_launch_post_single(cm_ctx* ctx, cm_set& s, int it, const cm_options* o, int do_sigma);
 int cm_wait_active(cm_ctx* ctx, cm_set& s);
 int cm_launch_update_phi(cm_ctx* ctx, cm_set& s, hipStream_t st, int use_dead = 0);

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void k_mc_dead(cm_parg<BATCH> pa, IterDyn a) {
       const int row = __builtin_amdgcn_readlane(n, src);
       mc_logit_body<false, true>(row, lane, cm_readlane_f64(mean0, src), cm_readlane_f64(mean1, src), cm_readlane_f64(sd0, src), cm_readlane_f64(sd1, src),
                                  (const double2*)p.wtab + ((size_t)a.nx * N + row) * 2 * S, p.vals, p.V, S, sm + (size_t)wave * 2 * S, p.mcE, etab,
-                                 cm_readlane_f64(c0, src), cm_readlane_f64(c1, src));
+                                 cm_readlane_f64(c0, src), cm_readlane_f64(c1, src), nullptr, p.mce_ld);
     }
     return;
   }
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void k_mc_dead(cm_parg<BATCH> pa, IterDyn a) {
     }
   }
   const double mean = tot / (double)S;                 // lane k of the half: the mean of power k -- one division serves all of them
-  if (dead && j < P) p.mcE[(size_t)n * CM_MAX_VALS + (j == 0 ? gi[0] : (j == 1 ? gi[1] : (j == 2 ? gi[2] : gi[3])))] = mean;
+  if (dead && j < P) p.mcE[(size_t)n * p.mce_ld + (j == 0 ? gi[0] : (j == 1 ? gi[1] : (j == 2 ? gi[2] : gi[3])))] = mean;
 }
 
 // LISTED (batches, steady state): the per-neuron role walks the list of rows with lam != 0 in a stride loop -- its own instantiation,
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(CM_ITER_THREADS) void k_iter_mid(cm_parg<BATCH> pa,
       phi_body<SEG>(n, lane, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, pc);
       if (a.do_mc) {
         const size_t off = ((size_t)a.nx * N + n) * 2 * a.S;      // (the table is stored by neuron)
-        mc_logit_body<FULLMC>(n, lane, pc[0], pc[1], pc[2], pc[3], (const double2*)p.wtab + off, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE, etab);
+        mc_logit_body<FULLMC>(n, lane, pc[0], pc[1], pc[2], pc[3], (const double2*)p.wtab + off, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE, etab, 0.0, 0.0, nullptr, p.mce_ld);
       }
     }
     return;
@@ -209,9 +209,9 @@ __global__ __launch_bounds__(CM_ITER_THREADS) void k_iter_mid(cm_parg<BATCH> pa,
     const size_t off = ((size_t)a.nx * N + n) * 2 * a.S;
     const double2* wu = (const double2*)p.wtab + off;   // (ndtri(u), u) of the neuron's sweep step (the table is stored by neuron)
     if (!FULLMC && dead_row)
-      mc_logit_body<false, true>(n, lane, pc[0], pc[1], pc[2], pc[3], wu, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE, etab, dc0, dc1);
+      mc_logit_body<false, true>(n, lane, pc[0], pc[1], pc[2], pc[3], wu, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE, etab, dc0, dc1, nullptr, p.mce_ld);
     else
-      mc_logit_body<FULLMC>(n, lane, pc[0], pc[1], pc[2], pc[3], wu, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE, etab);
+      mc_logit_body<FULLMC>(n, lane, pc[0], pc[1], pc[2], pc[3], wu, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE, etab, 0.0, 0.0, nullptr, p.mce_ld);
   }
 }
 
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(CM_ITER_THREADS) void k_iter_overflow(cm_parg<true>
     phi_body<SEG>(n, lane, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, pc);
     if (a.do_mc) {
       const size_t off = ((size_t)a.nx * N + n) * 2 * a.S;
-      mc_logit_body<false>(n, lane, pc[0], pc[1], pc[2], pc[3], (const double2*)p.wtab + off, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE, etab);
+      mc_logit_body<false>(n, lane, pc[0], pc[1], pc[2], pc[3], (const double2*)p.wtab + off, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE, etab, 0.0, 0.0, nullptr, p.mce_ld);
     }
   }
 }

@@ -41,10 +41,29 @@ __device__ __forceinline__ void stats_row(const cm_pdev& p, const double* __rest
   }
 }
 
+// `quiescent` (set with the pre-sweep's, cm_launch_sweep): rows are screened one per THREAD -- a row that was all zero before the sweep, was
+// not on the chain (mu == 0) and was not revived by the pre-sweep is still all zero and keeps its statistics {0, 0, 0, -1}; only the
+// others (a few dozen per circuit in the steady state) are re-read, one wavefront each.
 template <bool BATCH>
-__global__ __launch_bounds__(256) void k_stats(cm_parg<BATCH> pa, int nbR, double orth) {
+__global__ __launch_bounds__(256) void k_stats(cm_parg<BATCH> pa, int nbR, double orth, int quiescent) {
   const cm_pdev& p = pa.get();
   const double* __restrict__ lam = p.lam;
+  if (quiescent && (int)blockIdx.x < nbR) {
+    __shared__ int qlist[256];
+    __shared__ int qn;
+    if (threadIdx.x == 0) qn = 0;
+    __syncthreads();
+    const int n = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (n < p.N) {
+      const bool revived = p.touch[n] != 0;
+      if (revived) p.touch[n] = 0;
+      if (revived || p.rs[(size_t)n * 4 + 3] >= 0.0 || p.seq_pos[n] >= 0) qlist[atomicAdd(&qn, 1)] = n;
+    }
+    __syncthreads();
+    const int cnt = qn;
+    for (int i = threadIdx.x / CM_WAVE; i < cnt; i += 4) stats_row<BATCH>(p, lam, qlist[i], threadIdx.x % CM_WAVE);
+    return;
+  }
   if (BATCH && (int)blockIdx.x < nbR) {
     // batches: FOUR rows per wavefront -- two pairs (one row per 32-lane half), the load levels of both pairs in flight together: the
     // launch is latency-bound at full occupancy, so its duration is its number of wavefronts times the length of their dependent
@@ -116,11 +135,11 @@ __global__ __launch_bounds__(CM_POST_THREADS) void k_post_single(cm_parg<false> 
 }
 
 // Row + column statistics of the current lam.
-int cm_launch_stats(cm_ctx* ctx, cm_set& s, double spont_orthogonality) {
+int cm_launch_stats(cm_ctx* ctx, cm_set& s, double spont_orthogonality, int quiescent) {
   const cm_problem* p = s.lead;
-  const int nbR = s.B > 1 ? (p->N + 15) / 16 : (p->N + 3) / 4;      // one wave per row (batches: per four rows)
+  const int nbR = quiescent ? (p->N + 255) / 256 : (s.B > 1 ? (p->N + 15) / 16 : (p->N + 3) / 4);      // one wave per row (batches: per four rows); screened: 256 rows per block
   const int nbC = ((s.B > 1 ? (p->K + 1) / 2 : p->K) * 16 + 255) / 256;   // 16 lanes per trial column (batches: per two columns)
-  CM_LAUNCH_SET(k_stats, s, nbR + nbC, 256, 0, ctx->stream, nbR, spont_orthogonality);
+  CM_LAUNCH_SET(k_stats, s, nbR + nbC, 256, 0, ctx->stream, nbR, spont_orthogonality, quiescent);
   CM_HIP(hipGetLastError());
   return CM_OK;
 }

@@ -348,8 +348,39 @@ __global__ __launch_bounds__(256) void k_entry_copies(cm_parg<BATCH> pa) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < p.nnz) { const int c = p.col[i]; const_cast<uint8_t*>(p.me)[i] = p.mask[c]; const_cast<double*>(p.ye)[i] = p.y[c]; }
 }
+static int launch_mask_counts(cm_ctx* ctx, cm_set& s);
 int cm_launch_entry_copies(cm_ctx* ctx, cm_set& s) {
   CM_LAUNCH_SET(k_entry_copies, s, (unsigned)((std::max<long long>(s.nnz_max, 1) + 255) / 256), 256, 0, ctx->stream);
+  CM_HIP(hipGetLastError());
+  CM_TRY(launch_mask_counts(ctx, s));
+  return CM_OK;
+}
+
+// unmasked trials of every row at each stimulus value (one wavefront per row), and the "revived" flags cleared: the closed-form gate of an
+// all-zero row (cm_sweep.hip: quiescent_gate) needs the counts; they change only with the mask, i.e. once per run
+template <bool BATCH>
+__global__ __launch_bounds__(256) void k_mask_counts(cm_parg<BATCH> pa) {
+  const cm_pdev& p = pa.get();
+  const int n = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE, lane = threadIdx.x % CM_WAVE;
+  if (n >= p.N) return;
+  int* __restrict__ out = const_cast<int*>(p.mcnt) + (size_t)n * CM_MAX_VALS;
+  int mine = 0;                                             // lane g: unmasked entries of value g
+  for (int e0 = p.row_ptr[n]; e0 < p.row_ptr[n + 1]; e0 += CM_WAVE) {
+    const int e = e0 + lane;
+    const bool in = e < p.row_ptr[n + 1];
+    const int g = in ? p.grp[e] : -1;
+    const bool on = in && p.me[e] != 0;
+    for (int v = 0; v < p.V; ++v) {
+      const int c = __popcll(__ballot(on && g == v));
+      if (lane == v) mine += c;
+    }
+  }
+  if (lane < CM_MAX_VALS) out[lane] = lane < p.V ? mine : 0;
+  if (lane >= 1 && lane <= 8) const_cast<int*>(p.qcnt)[(size_t)n * 8 + lane - 1] = lane < p.V ? ((mine << 16) | (p.rowcnt[(size_t)n * CM_MAX_VALS + lane] & 0xFFFF)) : 0;
+  if (lane == 0) p.touch[n] = 0;
+}
+static int launch_mask_counts(cm_ctx* ctx, cm_set& s) {
+  CM_LAUNCH_SET(k_mask_counts, s, (unsigned)((s.lead->N + 3) / 4), 256, 0, ctx->stream);
   CM_HIP(hipGetLastError());
   return CM_OK;
 }
@@ -361,7 +392,7 @@ int cm_launch_init_state(cm_ctx* ctx, cm_set& s, double y_xcorr_thresh) {
   CM_LAUNCH_SET(k_init_state, s, (unsigned)((n + 255) / 256), 256, 0, st, y_xcorr_thresh);
   CM_LAUNCH_SET(k_sum_y_set, s, 1, 1024, 0, st);
   CM_HIP(hipGetLastError());
-  return CM_OK;
+  return launch_mask_counts(ctx, s);
 }
 
 // dense <-> compressed lam (targeted entries only; everything else is identically zero, caviar.py:216)

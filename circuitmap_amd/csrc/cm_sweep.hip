@@ -109,6 +109,8 @@ __global__ __launch_bounds__(64) void k_ndtri_table(const uint32_t* __restrict__
 // one sweep step for neuron n (caviar.py:203-225)
 // ------------------------------------------------------------------------------------------------
 struct SweepArgs {
+  const int* qcnt; const double* rs; uint8_t* touch; int quiescent_ok;   // closed-form gate of all-zero rows (quiescent_gate)
+  int mld;                                                                // row stride of mcE
   const int* row_ptr; const int* col; const uint8_t* grp; const int* rowcnt;
   const double* y; const uint8_t* mask; const double* ye; const uint8_t* me; const double* mu; const double* beta; const double* mcE; const double* scal;
   double* lam;
@@ -121,7 +123,42 @@ __device__ __forceinline__ SweepArgs sweep_args(const cm_pdev& p, int gated, dou
   a.row_ptr = p.row_ptr; a.col = p.col; a.grp = p.grp; a.rowcnt = p.rowcnt;
   a.y = p.y; a.mask = p.mask; a.ye = p.ye; a.me = p.me; a.mu = p.mu; a.beta = p.beta; a.mcE = p.mcE; a.scal = p.scal;
   a.lam = p.lam; a.V = p.V; a.gated = gated; a.msrmp = msrmp; a.min_count = min_count;
+  a.qcnt = p.qcnt; a.rs = p.rs; a.touch = p.touch; a.mld = p.mce_ld;
+  a.quiescent_ok = gated && p.V - 1 <= 8 && p.V >= 1 && p.max_row_len < 65536 && p.vals[0] == 0.0;   // (a stimulus matrix without zeros keeps value-0 entries in the rows: the plain path)
   return a;
+}
+
+// The gate of a row that is identically zero and has mu == 0 (95 % of the rows in the steady state), WITHOUT touching its entries.  Such
+// a row's estimate takes one value per power, est_p = sigmoid(mcE[n][p] - sigma beta^2 / 2) on its unmasked trials (caviar.py:205-216 with
+// mu = 0), so the per-power sums of caviar.py:179-184 are counts times values: rate_p = m_p est_p / trials_p (m_p unmasked trials of
+// power p: a per-run constant, k_mask_counts), total = sum_p m_p est_p; then the isotonic last value max_j mean(rate[j:]) and the two
+// tests of :220.  A row that fails stays zero -- nothing to write, nothing for the statistics to re-read; a row that passes is
+// written by the plain path with the gate already decided.  (Sums of equal terms taken as count x term: the decision can differ from
+// the entry-by-entry sum only in an exact tie of a threshold; single fits and batches take the same path.)  One thread evaluates it.
+__device__ __forceinline__ bool quiescent_gate(const SweepArgs& a, int n, double sig, double thresh) {
+  const int P = a.V - 1;
+  const double be = a.beta[n];
+  const double arg = sig * (be * be);
+  double sr[8], total = 0.0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    sr[q] = 0.0;
+    if (q < P) {
+      const double est = cm_sigmoid(a.mcE[(size_t)n * a.mld + q + 1] - 0.5 * arg);
+      const int packed = a.qcnt[(size_t)n * 8 + q], cnt = packed & 0xFFFF;
+      const double num = (double)(packed >> 16) * est;
+      total += num;
+      sr[q] = num / ((double)cnt + 1e-4 * (double)(cnt == 0));                  // caviar.py:183
+    }
+  }
+  double S = 0.0, best = -1.0;
+  int c = 0;
+#pragma unroll
+  for (int j = 7; j >= 0; --j) {
+    if (j < P) { S += sr[j]; ++c; const double m = S / (double)c; best = m > best ? m : best; }
+  }
+  const double iso = P > 0 ? best : 0.0;
+  return iso >= thresh && total >= a.min_count;                                 // caviar.py:220
 }
 
 // pava.py:9-88 with gamma = 1, last element only; literal pool walk (strict '>' merge test, pava.py:42)
@@ -231,7 +268,7 @@ __device__ __forceinline__ void sweep_step_long(const SweepArgs& a, int n, RPtr 
             const double lo = a.lam[e];
             const double loo = USE_R ? sig * (R[k] - mu * lo) : 0.0;
             const double arg = -2.0 * sig * a.y[k] * mu + 2.0 * mu * loo + t3;          // caviar.py:205-206
-            est = cm_sigmoid(a.mcE[(size_t)n * CM_MAX_VALS + g] - 0.5 * arg);            // caviar.py:216
+            est = cm_sigmoid(a.mcE[(size_t)n * a.mld + g] - 0.5 * arg);            // caviar.py:216
           }
         }
         if (p0 == 0) total += est;
@@ -258,7 +295,7 @@ __device__ __forceinline__ void sweep_step_long(const SweepArgs& a, int n, RPtr 
     if (a.mask[k]) {
       const double loo = USE_R ? sig * (R[k] - mu * lo) : 0.0;
       const double arg = -2.0 * sig * a.y[k] * mu + 2.0 * mu * loo + t3;
-      est = cm_sigmoid(a.mcE[(size_t)n * CM_MAX_VALS + a.grp[e]] - 0.5 * arg);
+      est = cm_sigmoid(a.mcE[(size_t)n * a.mld + a.grp[e]] - 0.5 * arg);
     }
     const double nl = est * pava;                                                         // caviar.py:224
     a.lam[e] = nl;
@@ -313,8 +350,20 @@ __device__ __forceinline__ void sweep_indep_row(const SweepArgs& a, int n, int l
   if (a.mu[n] != 0.0) return;
   const double sig = a.scal[CM_S_SHAPE] / a.scal[CM_S_RATE];
   const double thresh = a.msrmp + a.scal[CM_S_SPONT_RATE];
+  bool decided = false;                              // the row is all zero and its gate was taken in closed form (and passed)
+  if (a.quiescent_ok && a.rs[(size_t)n * 4 + 3] < 0.0) {
+    if (!quiescent_gate(a, n, sig, thresh)) return;  // stays zero: nothing to write
+    decided = true;
+    if (lane == 0) a.touch[n] = 1;
+  }
   const int beg = a.row_ptr[n], len = a.row_ptr[n + 1] - beg;
-  if (!LEAN && len > CM_WAVE) { sweep_step_long<false>(a, n, (double*)nullptr, sig, thresh, lane, scr); return; }
+  if (!LEAN && len > CM_WAVE) {
+    if (decided) {                                   // revived long row: the estimates, ungated
+      SweepArgs b = a; b.gated = 0;
+      sweep_step_long<false>(b, n, (double*)nullptr, sig, thresh, lane, scr);
+    } else sweep_step_long<false>(a, n, (double*)nullptr, sig, thresh, lane, scr);
+    return;
+  }
   const bool valid = lane < len;
   const double be = a.beta[n];
   const double arg = sig * (be * be);                // mu == 0: caviar.py:205-206 reduces to sigma * beta^2
@@ -323,10 +372,10 @@ __device__ __forceinline__ void sweep_indep_row(const SweepArgs& a, int n, int l
   if (valid) {
     const int e = beg + lane;
     g = a.grp[e];
-    if (a.me[e]) est = cm_sigmoid(a.mcE[(size_t)n * CM_MAX_VALS + g] - 0.5 * arg);     // me[e] = mask[col[e]]
+    if (a.me[e]) est = cm_sigmoid(a.mcE[(size_t)n * a.mld + g] - 0.5 * arg);     // me[e] = mask[col[e]]
   }
   double pava = 1.0;
-  if (a.gated) pava = row_gate<LEAN>(valid, g, est, a.V - 1, thresh, a.min_count, scr);
+  if (a.gated && !decided) pava = row_gate<LEAN>(valid, g, est, a.V - 1, thresh, a.min_count, scr);
   if (valid) a.lam[beg + lane] = est * pava;
 }
 
@@ -335,16 +384,23 @@ __device__ __forceinline__ void sweep_indep_row(const SweepArgs& a, int n, int l
 template <bool LEAN>
 __device__ __forceinline__ void sweep_indep_pair(const SweepArgs& a, int n0, int N, int lane, double* scr) {
   const int sub = lane & 31, n = n0 + (lane >> 5);
-  const bool row_on = n < N && a.mu[n < N ? n : 0] == 0.0;
+  bool row_on = n < N && a.mu[n < N ? n : 0] == 0.0;
+  const double sig = a.scal[CM_S_SHAPE] / a.scal[CM_S_RATE];
+  const double thresh = a.msrmp + a.scal[CM_S_SPONT_RATE];
+  // all-zero rows: the gate in closed form, per half (every lane of a half evaluates its row's); a row that fails is done
+  bool decided = false;
+  if (row_on && a.quiescent_ok && a.rs[(size_t)n * 4 + 3] < 0.0) {
+    if (!quiescent_gate(a, n, sig, thresh)) row_on = false;
+    else { decided = true; if (sub == 0) a.touch[n] = 1; }
+  }
+  if (!__any(row_on)) return;
   const int beg = row_on ? a.row_ptr[n] : 0, len = row_on ? a.row_ptr[n + 1] - beg : 0;
   const int P = a.V - 1;
-  if (__any(len > 32) || (!LEAN && P > 8)) {
+  if (__any(len > 32) || (!LEAN && P > 8)) {         // (sweep_indep_row takes the same decisions again, row by row)
     sweep_indep_row<LEAN>(a, n0, lane, scr);
     if (n0 + 1 < N) sweep_indep_row<LEAN>(a, n0 + 1, lane, scr);
     return;
   }
-  const double sig = a.scal[CM_S_SHAPE] / a.scal[CM_S_RATE];
-  const double thresh = a.msrmp + a.scal[CM_S_SPONT_RATE];
   const bool valid = sub < len;
   int g = -1;
   double est = 0.0;
@@ -353,7 +409,7 @@ __device__ __forceinline__ void sweep_indep_pair(const SweepArgs& a, int n0, int
     const double arg = sig * (be * be);              // mu == 0: caviar.py:205-206 reduces to sigma * beta^2
     const int e = beg + sub;
     g = a.grp[e];
-    if (a.me[e]) est = cm_sigmoid(a.mcE[(size_t)n * CM_MAX_VALS + g] - 0.5 * arg);     // me[e] = mask[col[e]]
+    if (a.me[e]) est = cm_sigmoid(a.mcE[(size_t)n * a.mld + g] - 0.5 * arg);     // me[e] = mask[col[e]]
   }
   double pava = 1.0;
   if (a.gated) {
@@ -365,6 +421,7 @@ __device__ __forceinline__ void sweep_indep_pair(const SweepArgs& a, int n0, int
       default: pava = row_gate_half<0>(valid, g, est, P, thresh, a.min_count); break;
     }
   }
+  if (decided) pava = 1.0;                           // (a revived row: its gate was the closed form)
   if (valid) a.lam[beg + sub] = est * pava;
 }
 
@@ -450,9 +507,13 @@ __device__ __forceinline__ void seq_scan_body(const int* __restrict__ order, con
 // LEAN (batches whose rows hold at most 64 trials and whose stimuli take at most 8 powers -- the host checks): the instantiation has
 // neither the long-row walk nor the literal pool walk, so that its register count allows two workgroups per CU; the launch is
 // latency-bound and as long as its wavefronts take turns.
+// `quiescent` (the host sets it once fewer than half of the rows are active and the gate is on): the first role screens ONE ROW PER THREAD
+// -- rows with mu == 0 that are all zero take their gate in closed form (quiescent_gate) and, failing it, are done without a
+// wavefront, a row pointer or an entry of theirs being touched -- and only the rows left over (rows with lam != 0 but mu == 0, revived
+// rows: a handful) are walked by the workgroup's wavefronts.  1 workgroup per 1024 rows instead of 32 or 64.
 template <bool BATCH, bool LEAN>
 __global__ __launch_bounds__(1024) void k_presweep(cm_parg<BATCH> pa, int it, int gated, double msrmp, double min_count, int nbI, int nbC,
-                                                    int roles, int gran) {
+                                                    int roles, int gran, int quiescent) {
   __shared__ double scr_all[16][3 * CM_MAX_VALS];
   __shared__ int wsum[2][16];
   __shared__ int carry[2];
@@ -462,6 +523,23 @@ __global__ __launch_bounds__(1024) void k_presweep(cm_parg<BATCH> pa, int it, in
   const int b = blockIdx.x;
   if (b < nbI) {
     if (!(roles & 1)) return;
+    if (quiescent) {
+      __shared__ int qlist[1024];
+      __shared__ int qn;
+      if (threadIdx.x == 0) qn = 0;
+      __syncthreads();
+      const int n = b * 1024 + (int)threadIdx.x;
+      if (n < N && a.mu[n] == 0.0) {
+        bool need = true;
+        if (a.quiescent_ok && a.rs[(size_t)n * 4 + 3] < 0.0)
+          need = quiescent_gate(a, n, a.scal[CM_S_SHAPE] / a.scal[CM_S_RATE], a.msrmp + a.scal[CM_S_SPONT_RATE]);
+        if (need) qlist[atomicAdd(&qn, 1)] = n;
+      }
+      __syncthreads();
+      const int cnt = qn;
+      for (int i = threadIdx.x / CM_WAVE; i < cnt; i += 16) sweep_indep_row<LEAN>(a, qlist[i], threadIdx.x % CM_WAVE, scr_all[threadIdx.x / CM_WAVE]);
+      return;
+    }
     if (BATCH) {                                     // two rows per wavefront (four were measured slower here, unlike in k_stats)
       const int n0 = 2 * (b * 16 + threadIdx.x / CM_WAVE);
       if (n0 < N) sweep_indep_pair<LEAN>(a, n0, N, threadIdx.x % CM_WAVE, scr_all[threadIdx.x / CM_WAVE]);
@@ -515,7 +593,7 @@ __global__ __launch_bounds__(256) void k_seq_pack(cm_parg<BATCH> pa, int gated, 
     if (turns == 2 && j == 1 && lane == 0) turn = (turn + 1) & 0xFF;   // fault injection (CAVIAR_HIP_TEST_BAD_TICKET): a turn that never comes
     r.b = e | (turn << 24);
     r.x = a.lam[e];
-    r.y = a.mcE[(size_t)n * CM_MAX_VALS + g];
+    r.y = a.mcE[(size_t)n * a.mld + g];
     r.z = -2.0 * sig * a.ye[e] * mu;                                                      // caviar.py:205, first term (ye[e] = y[k])
     packed[off + 1 + lane] = r;
   }
@@ -769,6 +847,13 @@ int cm_k_rng_streams_impl(cm_ctx* ctx, cm_problem* p, int it, int S, double* d_u
   return CM_OK;
 }
 
+// the sweep of iteration `it` screens its mu == 0 rows one per thread (and the statistics after it skip the rows left untouched): once the
+// gate is on and fewer than half of the rows are active.  Any choice is correct; both launches of an iteration must take the same one.
+int cm_sweep_quiescent(const cm_ctx* ctx, const cm_set& s, int it, const cm_options* o) {
+  (void)ctx;
+  return (it > o->delay_spont_est && 2 * s.na_max < s.lead->N) ? 1 : 0;
+}
+
 int cm_launch_sweep(cm_ctx* ctx, cm_set& s, int it, const cm_options* o, hipEvent_t mid, int table_it) {
   const cm_problem* p = s.lead;
   const int gated = it > o->delay_spont_est;
@@ -788,9 +873,12 @@ int cm_launch_sweep(cm_ctx* ctx, cm_set& s, int it, const cm_options* o, hipEven
   int v_max = 0;
   for (const cm_problem* q : s.ps) v_max = std::max(v_max, q->V);
   const bool lean = s.max_row_len_max <= CM_WAVE && v_max - 1 <= 8;     // every circuit of the set: rows of at most 64 trials, at most 8 powers
+  // one row per THREAD in the first role once the gate is on and fewer than half of the rows are active (any choice is correct)
+  const int quiescent = table_it < 0 ? cm_sweep_quiescent(ctx, s, it, o) : 0;
+  const int nbIq = quiescent ? (N + 1023) / 1024 : nbI;
   for (int pass = 0; pass < (split ? 3 : 1); ++pass) {
-    if (lean) CM_LAUNCH_SET_T(k_presweep, (true), s, nbI + nbC + 1, 1024, 0, st, (table_it < 0 ? it : table_it), gated, msrmp, min_count, nbI, nbC, split ? (1 << pass) : 7, gran);
-    else CM_LAUNCH_SET_T(k_presweep, (false), s, nbI + nbC + 1, 1024, 0, st, (table_it < 0 ? it : table_it), gated, msrmp, min_count, nbI, nbC, split ? (1 << pass) : 7, gran);
+    if (lean) CM_LAUNCH_SET_T(k_presweep, (true), s, nbIq + nbC + 1, 1024, 0, st, (table_it < 0 ? it : table_it), gated, msrmp, min_count, nbIq, nbC, split ? (1 << pass) : 7, gran, quiescent);
+    else CM_LAUNCH_SET_T(k_presweep, (false), s, nbIq + nbC + 1, 1024, 0, st, (table_it < 0 ? it : table_it), gated, msrmp, min_count, nbIq, nbC, split ? (1 << pass) : 7, gran, quiescent);
   }
   static const bool bad_ticket = getenv("CAVIAR_HIP_TEST_BAD_TICKET") != nullptr;   // test hook: exercises the bounded wait + error report of the ticketed chain
   CM_LAUNCH_SET(k_seq_pack, s, (N + 3) / 4, 256, 0, st, gated, msrmp, min_count, par ? (bad_ticket ? 2 : 1) : 0);
