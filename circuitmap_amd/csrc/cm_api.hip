@@ -804,6 +804,7 @@ static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_option
     memset(&t0, 0, sizeof(t0));
     t0.total_ms = a; t0.iters_ms = b; t0.fn_scan_ms = c; t0.iters = iters; t0.batch = B;
     t0.fact_launches = s.fact_launches; t0.fact_tile_updates = s.fact_tile_updates; t0.fact_panel_tiles = s.fact_panel_tiles;
+    t0.fact_tri_tiles = s.fact_tri_tiles; t0.fact_products = s.fact_products;
     for (int it = 0; timed && it < iters; ++it) {
       float d = 0;
       hipEventElapsedTime(&d, EV(it, 3), EV(it, 4));

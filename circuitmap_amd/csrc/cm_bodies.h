@@ -274,6 +274,112 @@ __device__ __forceinline__ int post_single_body(const double* __restrict__ y, co
 }
 
 // ------------------------------------------------------------------------------------------------
+// exp(x) for the Monte-Carlo logit stream (|x| < 20: no overflow / underflow / NaN handling), table-driven:
+//   x = (64 m + j) ln2 / 64 + r,  |r| <= ln2 / 128:   exp(x) = 2^m * 2^(j/64) * (1 + r + r^2/2 + ... + r^5/120)
+// 16 instructions against ~30 of the library routine (whose degree-11 polynomial serves |r| <= ln2 / 2); 1.3 ulp worst case measured
+// over 2e6 arguments (library: 0.7) -- far inside what the consumer can see (see cm_logit_of_sigmoid: the error of e enters the logit as an
+// ABSOLUTE 1e-16).  `tab` = the 64 correctly rounded values 2^(j/64) in LDS (cm_exptab_init).
+static __device__ const double cm_exp2_64[64] = {
+    0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
+    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
+    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
+    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
+    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
+    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
+    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
+    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
+    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
+    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
+    0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
+    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
+    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
+    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0};
+__device__ __forceinline__ void cm_exptab_init(double* tab) {       // first 64 threads of the workgroup; the caller synchronises
+  if (threadIdx.x < 64) tab[threadIdx.x] = cm_exp2_64[threadIdx.x];
+}
+__device__ __forceinline__ double cm_exp_tab(double x, const double* tab) {
+  // k = rint(64 x / ln2) by the 1.5 * 2^52 shift: the sum's low word is k in two's complement, the difference is k as a double.
+  // (v_rndne_f64, v_cvt_i32_f64 and v_ldexp_f64 issue at a quarter of the fma rate: three of them cost more than the polynomial.)
+  const double y = fma(x, 0x1.71547652b82fep+6, 0x1.8p52);     // 64 / ln2
+  const double kf = y - 0x1.8p52;
+  const int k = __double2loint(y);
+  double r = fma(kf, -0x1.62e42fefa3000p-7, x);                // ln2 / 64, 41 significant bits: the product is exact
+  r = fma(kf, -0x1.3de6af278ece6p-48, r);
+  double q = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+  q = fma(r, q, 1.0 / 6.0);
+  q = fma(r, q, 0.5);
+  q = fma(r, q, 1.0);
+  const double t = tab[k & 63];
+  const double v = fma(t, r * q, t);                           // in [1, 2): scaling by 2^(k >> 6) is an add to the exponent field
+  return __hiloint2double(__double2hiint(v) + ((k >> 6) << 20), __double2loint(v));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Table-driven exp / log for the Newton objective of update_phi (the instruction stream of that 10-step chain is what bounds the
+// per-neuron role; the library routines are ~30 / ~70 fp64 instructions, these 16 / 25).  Accuracy: exp 1.3 ulp (cm_exp_tab, below);
+// log <= 6 ulp in general and <= 1.2e-16 ABSOLUTE for arguments in [0.5, 1] (where the result is small and the library's relative
+// accuracy buys nothing: the values are summed into an objective of order 1 - 100).  Arguments outside the fast range -- zero,
+// negative, NaN, infinite, subnormal, |x| >= 700 for exp -- take the library routine, so the nan_to_num classes of the reference's objective
+// (quirk 11) see exactly the special values they saw before.
+// log(x), x positive normal: x = 2^e m, m in [1, 2), table index i = top six mantissa bits, c_i the interval's centre:
+//   r = m / c_i - 1 (one fma with the tabulated 1 / c_i), |r| <= 2^-7;  log x = e' ln2 + log c_i' + log1p(r), e' = e + (i >= 27), c_i' = c_i / 2 there
+// (so that arguments just below 1 meet a small table value: no cancellation against ln 2).
+static __device__ const double cm_log_tab128[128] = {   // [0..63] 1 / c_i, [64..127] log(c_i) (- ln 2 from i = 27 on)
+    0x1.fc07f01fc07f0p-1, 0x1.f44659e4a4271p-1, 0x1.ecc07b301ecc0p-1, 0x1.e573ac901e574p-1,
+    0x1.de5d6e3f8868ap-1, 0x1.d77b654b82c34p-1, 0x1.d0cb58f6ec074p-1, 0x1.ca4b3055ee191p-1,
+    0x1.c3f8f01c3f8f0p-1, 0x1.bdd2b899406f7p-1, 0x1.b7d6c3dda338bp-1, 0x1.b2036406c80d9p-1,
+    0x1.ac5701ac5701bp-1, 0x1.a6d01a6d01a6dp-1, 0x1.a16d3f97a4b02p-1, 0x1.9c2d14ee4a102p-1,
+    0x1.970e4f80cb872p-1, 0x1.920fb49d0e229p-1, 0x1.8d3018d3018d3p-1, 0x1.886e5f0abb04ap-1,
+    0x1.83c977ab2beddp-1, 0x1.7f405fd017f40p-1, 0x1.7ad2208e0ecc3p-1, 0x1.767dce434a9b1p-1,
+    0x1.724287f46debcp-1, 0x1.6e1f76b4337c7p-1, 0x1.6a13cd1537290p-1, 0x1.661ec6a5122f9p-1,
+    0x1.623fa77016240p-1, 0x1.5e75bb8d015e7p-1, 0x1.5ac056b015ac0p-1, 0x1.571ed3c506b3ap-1,
+    0x1.5390948f40febp-1, 0x1.5015015015015p-1, 0x1.4cab88725af6ep-1, 0x1.49539e3b2d067p-1,
+    0x1.460cbc7f5cf9ap-1, 0x1.42d6625d51f87p-1, 0x1.3fb013fb013fbp-1, 0x1.3c995a47babe7p-1,
+    0x1.3991c2c187f63p-1, 0x1.3698df3de0748p-1, 0x1.33ae45b57bcb2p-1, 0x1.30d190130d190p-1,
+    0x1.2e025c04b8097p-1, 0x1.2b404ad012b40p-1, 0x1.288b01288b013p-1, 0x1.25e22708092f1p-1,
+    0x1.23456789abcdfp-1, 0x1.20b470c67c0d9p-1, 0x1.1e2ef3b3fb874p-1, 0x1.1bb4a4046ed29p-1,
+    0x1.19453808ca29cp-1, 0x1.16e0689427379p-1, 0x1.1485f0e0acd3bp-1, 0x1.12358e75d3033p-1,
+    0x1.0fef010fef011p-1, 0x1.0db20a88f4696p-1, 0x1.0b7e6ec259dc8p-1, 0x1.0953f39010954p-1,
+    0x1.073260a47f7c6p-1, 0x1.05197f7d73404p-1, 0x1.03091b51f5e1ap-1, 0x1.0101010101010p-1,
+    0x1.fe02a6b106799p-8, 0x1.7b91b07d5b126p-6, 0x1.39e87b9febd68p-5, 0x1.b42dd711971b9p-5,
+    0x1.16536eea37ae3p-4, 0x1.51b073f06183cp-4, 0x1.8c345d6319b23p-4, 0x1.c5e548f5bc743p-4,
+    0x1.fec9131dbeabcp-4, 0x1.1b72ad52f67a2p-3, 0x1.371fc201e8f75p-3, 0x1.526e5e3a1b438p-3,
+    0x1.6d60fe719d21bp-3, 0x1.87fa06520c911p-3, 0x1.a23bc1fe2b561p-3, 0x1.bc286742d8cd4p-3,
+    0x1.d5c216b4fbb94p-3, 0x1.ef0adcbdc5935p-3, 0x1.0402594b4d041p-2, 0x1.1058bf9ae4ad4p-2,
+    0x1.1c898c16999fbp-2, 0x1.2895a13de86a4p-2, 0x1.347dd9a987d56p-2, 0x1.404308686a7e4p-2,
+    0x1.4be5f957778a1p-2, 0x1.5767717455a6cp-2, 0x1.62c82f2b9c796p-2, -0x1.57bf753c8d1fbp-2,
+    -0x1.4c9e09e172c3dp-2, -0x1.419b423d5e8c6p-2, -0x1.36b6776be1116p-2, -0x1.2bef07cdc9355p-2,
+    -0x1.214456d0eb8d5p-2, -0x1.16b5ccbacfb73p-2, -0x1.0c42d676162e2p-2, -0x1.01eae5626c691p-2,
+    -0x1.ef5ade4dcffe5p-3, -0x1.db13db0d48941p-3, -0x1.c6ffbc6f00f71p-3, -0x1.b31d8575bce3bp-3,
+    -0x1.9f6c407089663p-3, -0x1.8beafeb38fe8fp-3, -0x1.7898d85444c74p-3, -0x1.6574ebe8c1339p-3,
+    -0x1.527e5e4a1b58dp-3, -0x1.3fb45a59928cap-3, -0x1.2d1610c86813dp-3, -0x1.1aa2b7e23f729p-3,
+    -0x1.08598b59e3a07p-3, -0x1.ec739830a1126p-4, -0x1.c885801bc4b20p-4, -0x1.a4e7640b1bc38p-4,
+    -0x1.8197e2f40e3f0p-4, -0x1.5e95a4d9791cdp-4, -0x1.3bdf5a7d1ee5ep-4, -0x1.1973bd1465561p-4,
+    -0x1.eea31c006b87cp-5, -0x1.aaef2d0fb1108p-5, -0x1.67c94f2d4bb65p-5, -0x1.252f32f8d1840p-5,
+    -0x1.c63d2ec14aad7p-6, -0x1.432a925980cbcp-6, -0x1.82448a388a283p-7, -0x1.0080559588b25p-8,
+};
+__device__ __forceinline__ void cm_logtab_init(double* tab) {       // first 128 threads of the workgroup; the caller synchronises
+  if (threadIdx.x < 128) tab[threadIdx.x] = cm_log_tab128[threadIdx.x];
+}
+__device__ __forceinline__ double cm_log_tab(double x, const double* tab) {
+  if (!(x >= 0x1p-1022 && x < INFINITY)) return log(x);
+  const int hi = __double2hiint(x);
+  const int i = (hi >> 14) & 63;
+  const double m = __hiloint2double((hi & 0x000FFFFF) | 0x3FF00000, __double2loint(x));
+  const double r = fma(m, tab[i], -1.0);
+  const double ef = (double)(((hi >> 20) & 0x7FF) - 1023 + (i >= 27));
+  double q = fma(r, 1.0 / 7.0, -1.0 / 6.0);
+  q = fma(r, q, 0.2);
+  q = fma(r, q, -0.25);
+  q = fma(r, q, 1.0 / 3.0);
+  q = fma(r, q, -0.5);
+  const double pl = fma(r * r, q, r);
+  return fma(ef, 0x1.62e42fee00000p-1, tab[64 + i] + pl) + ef * 0x1.a39ef35793c76p-33;
+}
+
+// ------------------------------------------------------------------------------------------------
 // update_phi (caviar.py:246-316).  The K-sums of the Newton iteration collapse onto per-stimulus-value sufficient
 // statistics because I[n,:] takes <= V distinct values.  nan_to_num is applied per ELEMENT in the reference objective
 // (quirk 11) so elements are classed by y == 0, y == 1, 0 < y < 1.
@@ -314,17 +420,24 @@ __device__ __forceinline__ void inv2x2(double h11, double h12, double h21, doubl
 //     the literal form produces log(0) = -inf and nan_to_num turns the element into -DBL_MAX (quirk 11) -- are restored by hand;
 //   * the barrier's log(phi_0) + log(phi_1) is evaluated by two lanes of the segment in one instruction stream (lane 0: phi_0,
 //     lane 1: phi_1) and enters the segment sum; negative phi gives NaN as in the literal form.
+// sigmoid with the table-driven exp (the library's beyond |x| = 700 and for NaN); phi_body's gradient / Hessian and the objective
+// must evaluate the SAME function (the accepted candidate's sigmoid is reused by the next Newton step)
+__device__ __forceinline__ double cm_sigmoid_tab(double x, const double* etab) {
+  const double e = fabs(x) < 700.0 ? cm_exp_tab(-x, etab) : exp(-x);
+  return 1.0 / (1.0 + e);
+}
 template <int SEG>
 __device__ __forceinline__ double phi_nll(double p0, double p1, double val, double n0, double n1, double smid, double nmid,
-                                          bool lane_on, int g, double pr0, double pr1, const double prec[4], double t, double* sig_out) {
+                                          bool lane_on, int g, double pr0, double pr1, const double prec[4], double t, double* sig_out,
+                                          const double* etab, const double* ltab) {
   double tot = 0.0;
   *sig_out = 0.0;
   if (lane_on) {
     const double x = p0 * val - p1;
-    const double s = cm_sigmoid(x);
+    const double s = cm_sigmoid_tab(x, etab);
     *sig_out = s;
     const bool pos = x > 0.0;
-    const double la = log(pos ? s : 1.0 - s);
+    const double la = cm_log_tab(pos ? s : 1.0 - s, ltab);
     double ls = pos ? la : la + x, l1s = pos ? la - x : la;
     if (s == 1.0) l1s = -INFINITY;                     // log(1 - s) = log(0)
     if (s == 0.0) ls = -INFINITY;                      // log(s) = log(0)
@@ -337,12 +450,12 @@ __device__ __forceinline__ double phi_nll(double p0, double p1, double val, doub
   }
   double barrier;
   if (SEG >= 2) {
-    tot += log(g == 0 ? p0 : (g == 1 ? p1 : 1.0)) / t;  // lanes 0, 1 of the segment: log(phi_0) / t, log(phi_1) / t; the others add log(1) = 0
+    tot += cm_log_tab(g == 0 ? p0 : (g == 1 ? p1 : 1.0), ltab) / t;  // lanes 0, 1 of the segment: log(phi_0) / t, log(phi_1) / t; the others add log(1) = 0
     tot = cm_seg_sum<SEG>(tot);
     barrier = 0.0;
   } else {
     tot = cm_seg_sum<SEG>(tot);
-    barrier = (log(p0) + log(p1)) / t;
+    barrier = (cm_log_tab(p0, ltab) + cm_log_tab(p1, ltab)) / t;
   }
   const double d0 = p0 - pr0, d1 = p1 - pr1;
   const double quad = d0 * (prec[0] * d0 + prec[1] * d1) + d1 * (prec[2] * d0 + prec[3] * d1);
@@ -362,6 +475,7 @@ __device__ __forceinline__ void phi_body(int n, int lane, const double* __restri
                                          const double* __restrict__ vals, int V,
                                          const double* __restrict__ phi_prior, const double* __restrict__ phi_cov_prior,
                                          double* __restrict__ phi, double* __restrict__ phi_cov, double out[4],
+                                         const double* etab, const double* ltab,
                                          const double* __restrict__ dead_phi = nullptr, const double* __restrict__ dead_cov = nullptr) {
   constexpr int E = CM_WAVE / SEG;
   const int g = lane % SEG, ev = lane / SEG;
@@ -412,7 +526,7 @@ __device__ __forceinline__ void phi_body(int n, int lane, const double* __restri
     double j1 = 0.0, j2 = 0.0, h11 = 0.0, h12 = 0.0, h22 = 0.0;
     if (on) {
       // the accepted candidate of the previous step evaluated exactly this sigmoid (same expression, same operands)
-      const double f = have_f ? fcur : cm_sigmoid(p0 * val - p1);
+      const double f = have_f ? fcur : cm_sigmoid_tab(p0 * val - p1, etab);
       const double r = sy - cnt * f;
       j1 = -val * r; j2 = r;
       const double ff = cnt * f * (1.0 - f);
@@ -437,7 +551,7 @@ __device__ __forceinline__ void phi_body(int n, int lane, const double* __restri
       const double st = is_f0 ? 0.0 : ldexp(1.0, -b);
       const double q0 = is_f0 ? p0 : p0 + st * v0, q1 = is_f0 ? p1 : p1 + st * v1;
       double sg;
-      const double fv = phi_nll<SEG>(q0, q1, val, n0, n1, smid, nmid, on, g, pr0, pr1, prec, t, &sg);
+      const double fv = phi_nll<SEG>(q0, q1, val, n0, n1, smid, nmid, on, g, pr0, pr1, prec, t, &sg, etab, ltab);
       if (first) f0 = cm_readlane_f64(fv, 0);
       const double rhs = f0 + alpha * st * Jv;
       const bool ok = !is_f0 && b <= 39 && !(isnan(fv) || fv > rhs);
@@ -586,48 +700,6 @@ __device__ __forceinline__ double cm_uniform64(uint32_t k0, uint32_t k1, int j, 
 // reference forms them, log(r) = x + log1p(r e - 1) up to the last-ulp error of e; r e - 1 is the rounding residue of those three
 // operations, a single fma away, and tiny for moderate |x| (|r e - 1| < 2e-7 below |x| = 20), where two terms of log1p are exact to
 // double precision.  Beyond, and for non-finite x, the literal form (with its saturation to +-inf) is evaluated.
-// exp(x) for the Monte-Carlo logit stream (|x| < 20: no overflow / underflow / NaN handling), table-driven:
-//   x = (64 m + j) ln2 / 64 + r,  |r| <= ln2 / 128:   exp(x) = 2^m * 2^(j/64) * (1 + r + r^2/2 + ... + r^5/120)
-// 16 instructions against ~30 of the library routine (whose degree-11 polynomial serves |r| <= ln2 / 2); 1.3 ulp worst case measured
-// over 2e6 arguments (library: 0.7) -- far inside what the consumer can see (see cm_logit_of_sigmoid: the error of e enters the logit as an
-// ABSOLUTE 1e-16).  `tab` = the 64 correctly rounded values 2^(j/64) in LDS (cm_exptab_init).
-static __device__ const double cm_exp2_64[64] = {
-    0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
-    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
-    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
-    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
-    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
-    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
-    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
-    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
-    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
-    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
-    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
-    0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
-    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
-    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
-    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
-    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0};
-__device__ __forceinline__ void cm_exptab_init(double* tab) {       // first 64 threads of the workgroup; the caller synchronises
-  if (threadIdx.x < 64) tab[threadIdx.x] = cm_exp2_64[threadIdx.x];
-}
-__device__ __forceinline__ double cm_exp_tab(double x, const double* tab) {
-  // k = rint(64 x / ln2) by the 1.5 * 2^52 shift: the sum's low word is k in two's complement, the difference is k as a double.
-  // (v_rndne_f64, v_cvt_i32_f64 and v_ldexp_f64 issue at a quarter of the fma rate: three of them cost more than the polynomial.)
-  const double y = fma(x, 0x1.71547652b82fep+6, 0x1.8p52);     // 64 / ln2
-  const double kf = y - 0x1.8p52;
-  const int k = __double2loint(y);
-  double r = fma(kf, -0x1.62e42fefa3000p-7, x);                // ln2 / 64, 41 significant bits: the product is exact
-  r = fma(kf, -0x1.3de6af278ece6p-48, r);
-  double q = fma(r, 1.0 / 120.0, 1.0 / 24.0);
-  q = fma(r, q, 1.0 / 6.0);
-  q = fma(r, q, 0.5);
-  q = fma(r, q, 1.0);
-  const double t = tab[k & 63];
-  const double v = fma(t, r * q, t);                           // in [1, 2): scaling by 2^(k >> 6) is an add to the exponent field
-  return __hiloint2double(__double2hiint(v) + ((k >> 6) << 20), __double2loint(v));
-}
-
 // saturating arguments (and non-finite ones): the literal form, out of line -- rare, and its logarithm and divisions would otherwise
 // set the register budget of every copy of the evaluation loop
 __device__ __noinline__ double cm_logit_literal(double x) {

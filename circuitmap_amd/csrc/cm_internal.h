@@ -250,7 +250,7 @@ struct cm_set {
   int small_cap_max = 0, max_row_len_max = 0, max_col_len_max = 0;
   size_t small_lds_max = 0;              // largest LDS need of the fused in-LDS solve over the circuits of the set
   long long nnz_max = 0, nnz_min = 0;
-  long long fact_launches = 0, fact_tile_updates = 0, fact_panel_tiles = 0;   // counters of the tiled solves (cm_timings)
+  long long fact_launches = 0, fact_tile_updates = 0, fact_panel_tiles = 0, fact_tri_tiles = 0, fact_products = 0;   // counters of the tiled solves (cm_timings)
   bool last_fact = false;                // the last cm_solve_launch ran a factorisation (and recorded its event pair)
   std::vector<int> na;                   // last active-set sizes read from the mailboxes
   int na_max = 0;

@@ -166,8 +166,9 @@ __global__ __launch_bounds__(CM_ITER_THREADS) void k_iter_mid(cm_parg<BATCH> pa,
     return;
   }
   if (!(a.roles & 2)) return;
-  __shared__ double etab[64];
+  __shared__ double etab[64], ltab[128];
   cm_exptab_init(etab);
+  cm_logtab_init(ltab);
   __syncthreads();                                   // (before any wavefront leaves)
   const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE;
   const int N = p.N;
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(CM_ITER_THREADS) void k_iter_mid(cm_parg<BATCH> pa,
     if (i < n_alive) {
       const int n = p.alive[1 + i];
       double pc[4];
-      phi_body<SEG>(n, lane, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, pc);
+      phi_body<SEG>(n, lane, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, pc, etab, ltab);
       if (a.do_mc) {
         const size_t off = ((size_t)a.nx * N + n) * 2 * a.S;      // (the table is stored by neuron)
         mc_logit_body<FULLMC>(n, lane, pc[0], pc[1], pc[2], pc[3], (const double2*)p.wtab + off, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE, etab, 0.0, 0.0, nullptr, p.mce_ld);
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(CM_ITER_THREADS) void k_iter_mid(cm_parg<BATCH> pa,
     dead_row = true;
     dead_phi_copy(p, n, lane, pc, &dc0, &dc1);
   } else if (a.do_phi) {
-    phi_body<SEG>(n, lane, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, pc);
+    phi_body<SEG>(n, lane, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, pc, etab, ltab);
   } else {
     pc[0] = p.phi[2 * n]; pc[1] = p.phi[2 * n + 1]; pc[2] = p.phi_cov[4 * n]; pc[3] = p.phi_cov[4 * n + 3];
   }
@@ -221,8 +222,9 @@ __global__ __launch_bounds__(CM_ITER_THREADS) void k_iter_mid(cm_parg<BATCH> pa,
 template <int SEG>
 __global__ __launch_bounds__(CM_ITER_THREADS) void k_iter_overflow(cm_parg<true> pa, IterDyn a, int first) {
   extern __shared__ double sm[];
-  __shared__ double etab[64];
+  __shared__ double etab[64], ltab[128];
   cm_exptab_init(etab);
+  cm_logtab_init(ltab);
   __syncthreads();
   const cm_pdev& p = pa.get();
   const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE;
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(CM_ITER_THREADS) void k_iter_overflow(cm_parg<true>
   for (int i = first + (int)blockIdx.x * (int)(blockDim.x / CM_WAVE) + wave; i < n_alive; i += total) {
     const int n = p.alive[1 + i];
     double pc[4];
-    phi_body<SEG>(n, lane, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, pc);
+    phi_body<SEG>(n, lane, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, pc, etab, ltab);
     if (a.do_mc) {
       const size_t off = ((size_t)a.nx * N + n) * 2 * a.S;
       mc_logit_body<false>(n, lane, pc[0], pc[1], pc[2], pc[3], (const double2*)p.wtab + off, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE, etab, 0.0, 0.0, nullptr, p.mce_ld);

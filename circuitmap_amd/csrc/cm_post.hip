@@ -197,23 +197,31 @@ int cm_wait_active(cm_ctx* ctx, cm_set& s) {
 // use_dead: rows found to be identically zero take the per-run constants (valid once k_phi_dead has run for the current priors)
 template <bool BATCH, int SEG>
 __global__ __launch_bounds__(256) void k_update_phi(cm_parg<BATCH> pa, int use_dead) {
+  __shared__ double etab[64], ltab[128];
+  cm_exptab_init(etab);
+  cm_logtab_init(ltab);
+  __syncthreads();                                   // (before any wavefront leaves)
   const cm_pdev& p = pa.get();
   const int n = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE;
   if (n >= p.N) return;
   double out[4];
   phi_body<SEG>(n, threadIdx.x % CM_WAVE, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, out,
-                use_dead ? p.phi_dead : nullptr, use_dead ? p.phi_cov_dead : nullptr);
+                etab, ltab, use_dead ? p.phi_dead : nullptr, use_dead ? p.phi_cov_dead : nullptr);
 }
 
 // the per-run constants: update_phi of neuron n for an all-zero lam row -> phi_dead / phi_cov_dead
 template <bool BATCH, int SEG>
 __global__ __launch_bounds__(256) void k_phi_dead(cm_parg<BATCH> pa) {
+  __shared__ double etab[64], ltab[128];
+  cm_exptab_init(etab);
+  cm_logtab_init(ltab);
+  __syncthreads();                                   // (before any wavefront leaves)
   const cm_pdev& p = pa.get();
   const int n = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE;
   if (n >= p.N) return;
   double out[4];
   phi_body<SEG, true>(n, threadIdx.x % CM_WAVE, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi_dead,
-                      p.phi_cov_dead, out);
+                      p.phi_cov_dead, out, etab, ltab);
   // the lower truncation points of the Monte-Carlo draws from this phi (caviar.py:212): constants of the run as well
   if (threadIdx.x % CM_WAVE == 0) {
     p.phi_c_dead[2 * n] = normcdf(-out[0] / out[2]);

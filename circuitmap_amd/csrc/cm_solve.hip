@@ -1258,6 +1258,8 @@ int cm_solve_launch(cm_ctx* ctx, cm_set& s, int skip_mode, hipEvent_t fact_begin
   for (int c = 0; c < s.B; ++c) {                  // bookkeeping for cm_timings: trailing-update passes and the tiles they read and rewrote
     const int nb = (s.na[c] + TS - 1) / TS;
     if (cm_solve_kind(s.na[c], s.ps[c]->small_cap, skip_mode >= 0) != 2) continue;
+    s.fact_tri_tiles += (long long)nb * (nb + 1) / 2;
+    for (long long t = 0; t < nb; ++t) s.fact_products += t + t * (t + 1) / 2;     // panel j with t = nb - j - 1 rows below it: t solves, t (t + 1) / 2 updates
     if (nb > large_min && ctx->chol_family == 1) {
       for (int j0 = 0; j0 + CM_GRP < nb; j0 += CM_GRP) {   // group: panel solve of t rows x 4 columns, rank-128 update of the t (t + 1) / 2 trailing tiles
         const long long t = nb - j0 - CM_GRP;

@@ -40,7 +40,7 @@ typedef enum cm_status {
 #define CM_MAX_VALS 64        /* distinct values of the stimulus matrix (0 and the laser powers) */
 
 /* ABI handshake.  Bumped whenever the layout of a struct of this header changes (history: 1 = round 1; 2 = cm_timings re-laid out
- * in round 2; 3 = this field + cm_timings.scan_*).  cm_options_default() writes it into cm_options.abi_version and every entry point
+ * in round 2; 3 = this field, cm_timings.fact_tri_tiles / fact_products).  cm_options_default() writes it into cm_options.abi_version and every entry point
  * that takes a cm_options refuses (CM_ERR_INVALID) a value other than the library's own: a caller compiled against another header
  * gets an error code instead of silently mis-read fields or an overrun cm_timings.  cm_abi_version() returns the library's value. */
 #define CM_ABI_VERSION 3
@@ -138,6 +138,10 @@ typedef struct cm_timings {
   int64_t fact_tile_updates; /* 32 x 32 fp64 tiles those passes read AND rewrote (16 KB each), summed over the circuits that took part */
   int64_t fact_panel_tiles;  /* further 8 KB tile transfers the same passes cannot avoid, each counted once per launch: panel tiles read,
                                 solved panel tiles written, the diagonal tile's inverse                                               */
+  int64_t fact_tri_tiles;    /* sum over the tiled solves of the run and the circuits that took part: 32 x 32 tiles of the active set's lower
+                                triangle, nb (nb + 1) / 2 -- the COMPULSORY traffic of a solve is 3 x 8 KB per such tile (precision matrix read once,
+                                factor and inverse written once), whatever the blocking                                                 */
+  int64_t fact_products;     /* 32 x 32 x 32 tile products (65 536 flop each, on the fp64 matrix cores) inside fact_ms: panel solves + trailing updates */
 } cm_timings;
 
 const char* cm_last_error(void);
