@@ -574,16 +574,31 @@ def main():
                 note="passes of the blocked fp64 Cholesky over the trailing matrix (four panels per pass: k_chol_gpanel + k_chol_wide, 64 x 64 "
                      "super-tiles; one circuit up to 48 tile rows: one panel per k_chol_panel launch): bound by the CU's fetch path and the "
                      "matrix cores together while the trailing matrix is large, launch-chain-bound in the last panels and for one circuit")
+        # (4) the tiled block_update_mu as a whole -- precision-matrix build, Cholesky passes, recursive-doubling inverse, mu / beta reductions --
+        #     timed by one event pair per solve.  Its work is GEMM-shaped on the fp64 matrix cores: the roof is the dense fp64 MFMA peak, achieved =
+        #     tile-product flops (factor + inverse, 65 536 per 32 x 32 x 32 product) / time.
+        tiled_total = mean_k("tiled_ms")
+        n_tiled = float(np.mean([t["tiled_solves"] for t in tms_k]))
+        tile_flops = (float(np.mean([t["fact_products"] for t in tms_k])) + float(np.mean([t["inv_products"] for t in tms_k]))) * 65536.0
+        if n_tiled > 0 and tiled_total > 0:
+            cands["tiled solve (k_build_precision, k_chol_*, k_inv_*, column sums)"] = dict(
+                total_ms=tiled_total, launches=n_tiled, bytes=0.0, bound="mfma", flops=tile_flops / n_tiled,
+                note="block_update_mu of the iterations whose active sets exceed the in-LDS solver (7 of 50 at this shape): sparse precision build, "
+                     "grouped fp64-MFMA Cholesky (rank-128 passes on 64 x 64 super-tiles), recursive-doubling inverse, column reductions; "
+                     "`roofline.solve` splits out the factor passes and sets them against the compulsory bytes")
         dom = max(cands, key=lambda k_: cands[k_]["total_ms"])
         for k_, c_ in cands.items():
             c_["avg_launch_ms"] = c_["total_ms"] / max(c_["launches"], 1)
-            c_["achieved"] = c_["bytes"] / max(c_["avg_launch_ms"] * 1e-3, 1e-12) / 1e9
+            if c_.get("bound") == "mfma":
+                c_["achieved"] = c_["flops"] / max(c_["avg_launch_ms"] * 1e-3, 1e-12) / 1e12        # TFLOP/s
+            else:
+                c_["achieved"] = c_["bytes"] / max(c_["avg_launch_ms"] * 1e-3, 1e-12) / 1e9          # GB/s
         d = cands[dom]
         # HBM traffic of that kernel from rocprofv3 PMC passes (profiles/, gfx950 correction FETCH_SIZE x 2 + WRITE_SIZE per the MI355X guide);
         # only quoted when a summary for THIS build, workload and batch size is committed -- otherwise null (see profiles/README.md)
         traffic, traffic_src = pmc_traffic(a.workload, Bl, dom)
         phase = {k: float(np.mean([t[k] for t in tms])) for k in ("total_ms", "iters_ms", "fn_scan_ms")}
-        phase.update({k: mean_k(k) for k in ("solve_ms", "sweep_indep_ms", "sweep_seq_ms", "mid_ms", "mc_dead_ms", "post_ms", "fact_ms")})
+        phase.update({k: mean_k(k) for k in ("solve_ms", "sweep_indep_ms", "sweep_seq_ms", "mid_ms", "mc_dead_ms", "post_ms", "fact_ms", "tiled_ms")})
         phase["steps_with_kernel_events"] = int(sum(1 for st_ in stamped if st_ or a.phases))
         out = {
             "metric": "CAVIaR iterations/sec (N=%d, K=%d, T=%d)" % (N, K, T),
@@ -596,15 +611,18 @@ def main():
                                                               "" if world == 1 else ", %d circuit sets rotated over the ranks" % world),
                        "circuits_per_gpu": B, "nnz_targeted": int(nnz), "distinct_powers": int(nvals) - 1,
                        "mean_active_set": float(np.mean([t["sum_active"] for t in tms])) / max(its, 1)},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": d["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": d["achieved"] / HBM_PEAK_GBS, "traffic": traffic,
+            "roofline": {"bound": d.get("bound", "hbm"), "kernel": dom, "achieved": d["achieved"],
+                         "peak": 78.6 if d.get("bound") == "mfma" else HBM_PEAK_GBS, "unit": "TFLOP/s" if d.get("bound") == "mfma" else "GB/s",
+                         "frac": d["achieved"] / (78.6 if d.get("bound") == "mfma" else HBM_PEAK_GBS), "traffic": traffic,
                          "avg_launch_ms": d["avg_launch_ms"], "launches_per_step": d["launches"], "total_ms_per_step": d["total_ms"],
-                         "algorithmic_bytes_per_launch": int(d["bytes"]), "note": d["note"],
+                         "algorithmic_bytes_per_launch": int(d["bytes"]), "algorithmic_flops_per_launch": int(d.get("flops", 0)), "note": d["note"],
                          "timing_note": "HIP event pair around each launch on the library's stream; the pair contains one dependent-launch "
                                         "boundary, so avg_launch_ms is an upper bound of the rocprof kernel average (profiles/README.md)",
                          "selection": "largest per-step total among the event-timed kernels",
-                         "other_kernels": {k_: {"avg_launch_ms": c_["avg_launch_ms"], "total_ms_per_step": c_["total_ms"],
-                                                "algorithmic_bytes_per_launch": int(c_["bytes"]), "achieved": c_["achieved"]}
+                         "other_kernels": {k_: {"avg_launch_ms": c_["avg_launch_ms"], "total_ms_per_step": c_["total_ms"], "bound": c_.get("bound", "hbm"),
+                                                "algorithmic_bytes_per_launch": int(c_["bytes"]), "achieved": c_["achieved"],
+                                                "unit": "TFLOP/s" if c_.get("bound") == "mfma" else "GB/s",
+                                                "frac": c_["achieved"] / (78.6 if c_.get("bound") == "mfma" else HBM_PEAK_GBS)}
                                            for k_, c_ in cands.items() if k_ != dom},
                          "pmc_source": traffic_src,
                          "k_iter_mid_table_bytes_per_launch": int(mid_table),
@@ -745,6 +763,9 @@ PMC_FAMILIES = {   # bench kernel / family -> (kernels whose traffic counts, the
     "k_sweep_par": (("k_sweep_par",), ("k_sweep_par",)),
     "k_chol_wide+k_chol_gpanel": (("k_chol_diag", "k_chol_gpanel", "k_chol_wide"), ("k_chol_wide",)),
     "k_chol_panel": (("k_chol_first", "k_chol_panel"), ("k_chol_panel",)),
+    "tiled solve (k_build_precision, k_chol_*, k_inv_*, column sums)": (
+        ("k_fill_prior", "k_build_precision", "k_chol_first", "k_chol_panel", "k_chol_diag", "k_chol_gpanel", "k_chol_wide", "k_inv_seed", "k_inv_T", "k_inv_X21",
+         "k_tri_matvec", "k_colsum_partial", "k_colsum_final"), ("k_build_precision",)),
 }
 
 

@@ -46,7 +46,7 @@ class CmTimings(C.Structure):
                 ("sweep_indep_ms", C.c_double), ("sweep_seq_ms", C.c_double), ("mid_ms", C.c_double), ("post_ms", C.c_double), ("mc_dead_ms", C.c_double), ("fact_ms", C.c_double),
                 ("iters", C.c_int32), ("batch", C.c_int32), ("last_active", C.c_int32), ("sum_active", C.c_int64), ("sum_seq_rows", C.c_int64), ("sum_seq_records", C.c_int64),
                 ("fact_launches", C.c_int64), ("fact_tile_updates", C.c_int64), ("fact_panel_tiles", C.c_int64),
-                ("fact_tri_tiles", C.c_int64), ("fact_products", C.c_int64)]
+                ("fact_tri_tiles", C.c_int64), ("fact_products", C.c_int64), ("inv_products", C.c_int64), ("tiled_ms", C.c_double), ("tiled_solves", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -684,7 +684,9 @@ static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_option
     bool any_big = false;
     for (int c = 0; c < B; ++c) { sum_active[c] += s.na[c]; last_act[c] = s.na[c]; any_big |= s.na[c] > s.ps[c]->small_cap; }
     if (ctx->mb_flag) { cm_set_error("iteration %d: weight precision matrix not positive definite", it); return CM_ERR_NOT_SPD; }
+    if (any_big && timed) CM_HIP(hipEventRecord(EV(it, 10), st));
     if (any_big) CM_TRY(cm_solve_launch(ctx, s, 0, timed ? EV(it, 6) : nullptr, timed ? EV(it, 7) : nullptr));   // :80 block_update_mu, large active sets (small ones: fused kernel)
+    if (any_big && timed) CM_HIP(hipEventRecord(EV(it, 11), st));
     fact_it[it] = any_big && s.last_fact;
     if (phases) CM_HIP(hipEventRecord(EV(it, 1), st));
     CM_TRY(cm_launch_sweep(ctx, s, it, o, timed ? EV(it, 3) : nullptr));  // :81  update_lam
@@ -804,7 +806,7 @@ static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_option
     memset(&t0, 0, sizeof(t0));
     t0.total_ms = a; t0.iters_ms = b; t0.fn_scan_ms = c; t0.iters = iters; t0.batch = B;
     t0.fact_launches = s.fact_launches; t0.fact_tile_updates = s.fact_tile_updates; t0.fact_panel_tiles = s.fact_panel_tiles;
-    t0.fact_tri_tiles = s.fact_tri_tiles; t0.fact_products = s.fact_products;
+    t0.fact_tri_tiles = s.fact_tri_tiles; t0.fact_products = s.fact_products; t0.inv_products = s.inv_products;
     for (int it = 0; timed && it < iters; ++it) {
       float d = 0;
       hipEventElapsedTime(&d, EV(it, 3), EV(it, 4));
@@ -817,6 +819,8 @@ static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_option
         t0.mid_ms += d;
       }
       if (fact_it[it] && hipEventElapsedTime(&d, EV(it, 6), EV(it, 7)) == hipSuccess) t0.fact_ms += d;
+      if (fact_it[it] && hipEventElapsedTime(&d, EV(it, 10), EV(it, 11)) == hipSuccess) t0.tiled_ms += d;
+      if (fact_it[it]) ++t0.tiled_solves;
       if (trace_iters && it > 0) {                                            // diagnostic: wall time of every iteration
         float e = 0;
         hipEventElapsedTime(&e, EV(it - 1, 9), EV(it, 9));

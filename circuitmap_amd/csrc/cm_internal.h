@@ -16,7 +16,7 @@
 #define CM_LD_PAD 0
 #endif
 //                  CM_LD_PAD: doubles added to the row stride of the solve matrices (8 was measured: no gain -- the trailing update is not channel-conflict bound)
-#define CM_EV_PER_IT 10
+#define CM_EV_PER_IT 12
 #define CM_MAX_BATCH 1024      // circuits in one lock-step group
 #define CM_MAILBOX_BATCH0 32   // 64-bit word index of the first per-circuit mailbox of a batch
 #define CM_STATUS_OFF (2 * (CM_MAILBOX_BATCH0 + CM_MAX_BATCH))   // int32 index of the end-of-run status words: 8 per circuit (n_act[0..3], chain rows, chain records, -, -)
@@ -250,7 +250,7 @@ struct cm_set {
   int small_cap_max = 0, max_row_len_max = 0, max_col_len_max = 0;
   size_t small_lds_max = 0;              // largest LDS need of the fused in-LDS solve over the circuits of the set
   long long nnz_max = 0, nnz_min = 0;
-  long long fact_launches = 0, fact_tile_updates = 0, fact_panel_tiles = 0, fact_tri_tiles = 0, fact_products = 0;   // counters of the tiled solves (cm_timings)
+  long long fact_launches = 0, fact_tile_updates = 0, fact_panel_tiles = 0, fact_tri_tiles = 0, fact_products = 0, inv_products = 0;   // counters of the tiled solves (cm_timings)
   bool last_fact = false;                // the last cm_solve_launch ran a factorisation (and recorded its event pair)
   std::vector<int> na;                   // last active-set sizes read from the mailboxes
   int na_max = 0;

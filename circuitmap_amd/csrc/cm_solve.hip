@@ -1260,6 +1260,12 @@ int cm_solve_launch(cm_ctx* ctx, cm_set& s, int skip_mode, hipEvent_t fact_begin
     if (cm_solve_kind(s.na[c], s.ps[c]->small_cap, skip_mode >= 0) != 2) continue;
     s.fact_tri_tiles += (long long)nb * (nb + 1) / 2;
     for (long long t = 0; t < nb; ++t) s.fact_products += t + t * (t + 1) / 2;     // panel j with t = nb - j - 1 rows below it: t solves, t (t + 1) / 2 updates
+    for (int b = 1; b < nb; b *= 2)                                                 // recursive doubling: per pair, T = L21 X11 and X21 = -X22 T over the existing rows
+      for (int q = 0; (2 * q + 1) * b < nb; ++q)
+        for (int r = (2 * q + 1) * b; r < std::min(nb, (2 * q + 2) * b); ++r) {
+          s.inv_products += (long long)b * (b + 1) / 2;                             // row r of T: sum over the b columns c of (b - c') steps
+          s.inv_products += (long long)b * (r - (2 * q + 1) * b + 1);               // row r of X21: (r - jbeg + 1) steps for each of the b columns
+        }
     if (nb > large_min && ctx->chol_family == 1) {
       for (int j0 = 0; j0 + CM_GRP < nb; j0 += CM_GRP) {   // group: panel solve of t rows x 4 columns, rank-128 update of the t (t + 1) / 2 trailing tiles
         const long long t = nb - j0 - CM_GRP;

@@ -142,6 +142,10 @@ typedef struct cm_timings {
                                 triangle, nb (nb + 1) / 2 -- the COMPULSORY traffic of a solve is 3 x 8 KB per such tile (precision matrix read once,
                                 factor and inverse written once), whatever the blocking                                                 */
   int64_t fact_products;     /* 32 x 32 x 32 tile products (65 536 flop each, on the fp64 matrix cores) inside fact_ms: panel solves + trailing updates */
+  int64_t inv_products;      /* tile products of the recursive-doubling inverse of the factor (k_inv_T, k_inv_X21) of the same solves          */
+  double tiled_ms;           /* timing >= 1, sum over the tiled solves of the run: precision-matrix build, factorisation, inverse, mu / beta
+                                reductions -- first to last launch of each block_update_mu that took the tiled path (event pair per solve)   */
+  int64_t tiled_solves;      /* iterations of the run whose block_update_mu took the tiled path (for at least one circuit of the set)              */
 } cm_timings;
 
 const char* cm_last_error(void);
