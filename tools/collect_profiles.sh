@@ -10,7 +10,7 @@ R=$(pwd)
 mkdir -p "$R/$out"
 export TMPDIR=/tmp
 cd /tmp
-A_ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-single-leg --streams-leg 0"
+A_ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-single-leg --streams-leg 0 --no-end-to-end"
 B_ARGS="--circuits-per-gpu 1 --batch-leg 0 --steps 3 --warmup 1 --no-cpu-baseline"
 C_ARGS="--workload cfg5 --steps 3 --warmup 1 --no-cpu-baseline"
 legs=${3:-a b c}
