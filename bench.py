@@ -569,11 +569,11 @@ def main():
             cands["k_mc_dead"] = dict(total_ms=dead_ms * its, launches=its, bytes=dead_bytes, note="fp64 VALU issue: the next Monte-Carlo logit of every all-zero row "
                                       "(S x P sigmoid-logit evaluations per row), one wavefront per row")
         if fl > 0:
-            cands["k_chol_wide+k_chol_gpanel" if (N > 48 * 32 or B > 1) else "k_chol_panel"] = dict(
+            cands["k_chol_wide+k_chol_gpanel" if B > 1 else ("k_chol_bulk+k_chol_trsm" if N > 48 * 32 else "k_chol_panel")] = dict(
                 total_ms=fact_total, launches=fl, bytes=(ft * 16384.0 + fp * 8192.0) / fl,
-                note="passes of the blocked fp64 Cholesky over the trailing matrix (four panels per pass: k_chol_gpanel + k_chol_wide, 64 x 64 "
-                     "super-tiles; one circuit up to 48 tile rows: one panel per k_chol_panel launch): bound by the CU's fetch path and the "
-                     "matrix cores together while the trailing matrix is large, launch-chain-bound in the last panels and for one circuit")
+                note="passes of the blocked fp64 Cholesky over the trailing matrix (batches: four panels per pass, k_chol_gpanel + k_chol_wide on 64 x 64 "
+                     "super-tiles; one circuit: one panel per k_chol_panel launch up to 48 tile rows, panel pairs k_chol_bulk + k_chol_trsm above): bound by "
+                     "the CU's fetch path and the matrix cores together while the trailing matrix is large, launch-chain-bound in the last panels and for one circuit")
         # (4) the tiled block_update_mu as a whole -- precision-matrix build, Cholesky passes, recursive-doubling inverse, mu / beta reductions --
         #     timed by one event pair per solve.  Its work is GEMM-shaped on the fp64 matrix cores: the roof is the dense fp64 MFMA peak, achieved =
         #     tile-product flops (factor + inverse, 65 536 per 32 x 32 x 32 product) / time.
@@ -763,8 +763,9 @@ PMC_FAMILIES = {   # bench kernel / family -> (kernels whose traffic counts, the
     "k_sweep_par": (("k_sweep_par",), ("k_sweep_par",)),
     "k_chol_wide+k_chol_gpanel": (("k_chol_diag", "k_chol_gpanel", "k_chol_wide"), ("k_chol_wide",)),
     "k_chol_panel": (("k_chol_first", "k_chol_panel"), ("k_chol_panel",)),
+    "k_chol_bulk+k_chol_trsm": (("k_chol_first", "k_chol_bulk", "k_chol_trsm"), ("k_chol_bulk<false, true>", "k_chol_bulk<true, true>")),   # one pair step per rank-64 pass
     "tiled solve (k_build_precision, k_chol_*, k_inv_*, column sums)": (
-        ("k_fill_prior", "k_build_precision", "k_chol_first", "k_chol_panel", "k_chol_diag", "k_chol_gpanel", "k_chol_wide", "k_inv_seed", "k_inv_T", "k_inv_X21",
+        ("k_fill_prior", "k_build_precision", "k_chol_first", "k_chol_panel", "k_chol_bulk", "k_chol_trsm", "k_chol_diag", "k_chol_gpanel", "k_chol_wide", "k_inv_seed", "k_inv_T", "k_inv_X21",
          "k_tri_matvec", "k_colsum_partial", "k_colsum_final"), ("k_build_precision",)),
 }
 
@@ -785,7 +786,7 @@ def pmc_traffic(workload, circuits_per_launch, family):
     members, counters = PMC_FAMILIES[family]
     base = lambda k: k.split("<")[0]
     tot = sum(v["calls"] * (2.0 * v["fetch_kb"] + v["write_kb"]) * 1024 for k, v in ent.items() if base(k) in members and flag in k)
-    n = sum(v["calls"] for k, v in ent.items() if base(k) in counters and flag in k)
+    n = sum(v["calls"] for k, v in ent.items() if any(k.startswith(c) and (len(c) > len(base(c)) or base(k) == c) for c in counters) and flag in k)
     if n == 0 or tot == 0:
         return None, None
     return int(tot / n), " + ".join(js.get("sources", {}).get(key, [])) + " (separate --pmc passes; tools/pmc_traffic.py)"

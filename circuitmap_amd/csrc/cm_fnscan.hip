@@ -220,9 +220,11 @@ static int fn_scan_shape(const cm_set& s, int* vmax_out, int* kmax_out) {
   return std::max(1, vmax - 1);
 }
 bool cm_fn_scan_fits(const cm_set& s) {
+  // the LDS-resident form only: on the global arrays every round is a chain of dependent loads, and with the dozens of rounds of a large
+  // circuit (N = 5000 / K = 10000: 7.7 ms measured) the host scan (0.7 ms incl. its copies) is the faster path -- the caller takes it
   int vmax, kmax;
   const int P = fn_scan_shape(s, &vmax, &kmax);
-  return vmax - 1 <= CM_FN_MAXP && fn_scan_lds(s.lead->N, kmax, P, std::max(1, s.max_row_len_max), false) <= 150 * 1024;
+  return vmax - 1 <= CM_FN_MAXP && s.max_row_len_max < 65536 && fn_scan_lds(s.lead->N, kmax, P, std::max(1, s.max_row_len_max), true) <= 150 * 1024;
 }
 int cm_launch_fn_scan(cm_ctx* ctx, cm_set& s, double minimax_spk_prob, double minimum_spike_count) {
   const int row_cap = std::max(1, s.max_row_len_max);

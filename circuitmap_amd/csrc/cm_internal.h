@@ -52,7 +52,7 @@ struct cm_ctx {
   bool use_mailbox = true;
   int solve_group = 0;           // circuits per group of the tiled solve of a batch (0: the whole batch in lock-step); CAVIAR_HIP_SOLVE_GROUP
   int xcd_mode = 3;              // cm_xcd_remap mode of the bandwidth-bound solve kernels; CAVIAR_HIP_XCD_MODE
-  int chol_family = 1;           // tiled Cholesky of batches and large matrices: 1 = grouped (four panels per pass, 64 x 64 super-tiles), 0 = panel pairs; CAVIAR_HIP_CHOL_FAMILY (both give bitwise the same factor)
+  int chol_family = 1;           // tiled Cholesky above large_min tile rows: 0 = panel pairs, 1 = grouped (four panels per pass, 64 x 64 super-tiles) for batches and pairs for one circuit, 2 = grouped everywhere; CAVIAR_HIP_CHOL_FAMILY (bitwise the same factor)
   int num_cus = 256;
   void* h_stage = nullptr;        // pinned staging buffer (priors upload, fn_scan round trip), grown on demand
   size_t h_stage_bytes = 0;

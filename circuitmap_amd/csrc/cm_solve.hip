@@ -1072,6 +1072,11 @@ int cm_solve_mu(cm_ctx* ctx, cm_set& s, int* n_active_out) {
   return cm_solve_launch(ctx, s, -1);
 }
 
+// Which family factors matrices above `large_min` tile rows: batches take the grouped one (throughput: 26 against 19 TFLOP/s at 128 x
+// n = 1000); one large matrix is bound by the chain of diagonal blocks, which the pair family walks in slightly shorter steps (cfg5: 11.0
+// against 12.0 ms per fit), so it stays there.  CAVIAR_HIP_CHOL_FAMILY: 0 = pairs everywhere, 1 = this default, 2 = grouped everywhere.
+static inline bool cm_use_grouped(const cm_ctx* ctx, bool single) { return ctx->chol_family == 2 || (ctx->chol_family == 1 && !single); }
+
 // One group of circuits through the tiled solve; `parts`: 1 = precision matrices, 2 = Cholesky, 4 = inverse of the factor, 8 = mu / beta.
 struct cm_solve_sub { int B; bool single; cm_pdev h0; const cm_pdev* d_arr; };
 static int cm_solve_group_launch(cm_ctx* ctx, const cm_solve_sub& g, int nblk, int na_g, int na1, int skip_le, int xflags, int large_min, int parts,
@@ -1093,7 +1098,7 @@ static int cm_solve_group_launch(cm_ctx* ctx, const cm_solve_sub& g, int nblk, i
   if (parts & 1) CM_LAUNCH_G(k_build_precision, ld, 64, build_prec_lds(ld + CM_LD_PAD), na1, skip_le);
   if (parts & 2) {
     if (fact_begin) CM_HIP(hipEventRecord(fact_begin, st));
-    if (large_g && ctx->chol_family == 1) {            // grouped family: four panels per pass over the trailing matrix, 64 x 64 super-tiles
+    if (large_g && cm_use_grouped(ctx, g.single)) {    // grouped family: four panels per pass over the trailing matrix, 64 x 64 super-tiles
       if (g.single) {
         CM_TRY(cm_raise_lds(ctx, CM_LDS_CHOL_DIAG, reinterpret_cast<const void*>(k_chol_diag<false>), CM_GROUP_LDS, 48 * 1024));
         CM_TRY(cm_raise_lds(ctx, CM_LDS_CHOL_GPANEL, reinterpret_cast<const void*>(k_chol_gpanel<false>), CM_GROUP_LDS, 48 * 1024));
@@ -1266,7 +1271,7 @@ int cm_solve_launch(cm_ctx* ctx, cm_set& s, int skip_mode, hipEvent_t fact_begin
           s.inv_products += (long long)b * (b + 1) / 2;                             // row r of T: sum over the b columns c of (b - c') steps
           s.inv_products += (long long)b * (r - (2 * q + 1) * b + 1);               // row r of X21: (r - jbeg + 1) steps for each of the b columns
         }
-    if (nb > large_min && ctx->chol_family == 1) {
+    if (nb > large_min && cm_use_grouped(ctx, s.B == 1)) {
       for (int j0 = 0; j0 + CM_GRP < nb; j0 += CM_GRP) {   // group: panel solve of t rows x 4 columns, rank-128 update of the t (t + 1) / 2 trailing tiles
         const long long t = nb - j0 - CM_GRP;
         s.fact_tile_updates += t * (t + 1) / 2;
@@ -1305,7 +1310,7 @@ int cm_solve_launch(cm_ctx* ctx, cm_set& s, int skip_mode, hipEvent_t fact_begin
       nblk = std::max(nblk, (s.na[c] + TS - 1) / TS); na_g = std::max(na_g, s.na[c]);
     }
     if (nblk == 0) continue;
-    s.fact_launches += nblk > large_min ? (ctx->chol_family == 1 ? (nblk - 1) / CM_GRP : nblk / 2) : std::max(0, nblk - 1);
+    s.fact_launches += nblk > large_min ? (cm_use_grouped(ctx, s.B == 1) ? (nblk - 1) / CM_GRP : nblk / 2) : std::max(0, nblk - 1);
     CM_TRY(cm_solve_group_launch(ctx, g, nblk, na_g, na1, skip_le, xflags, large_min, 15, first_group ? fact_begin : nullptr, fact_end));
     first_group = false;
   }

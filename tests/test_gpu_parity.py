@@ -706,7 +706,7 @@ def test_cholesky_families_bitwise_equal(ctx, monkeypatch, N, K, B, iters):
     pri = default_priors(N)
     opts = dict(iters=iters, seed=0, fn_scan=False)
     res = []
-    for fam in (1, 0):
+    for fam in (2, 0):                                    # 2 = grouped also for one circuit (the default keeps the pair family there)
         monkeypatch.setenv("CAVIAR_HIP_CHOL_FAMILY", str(fam))
         cx = _lib.Context(0)
         monkeypatch.delenv("CAVIAR_HIP_CHOL_FAMILY")
@@ -720,7 +720,7 @@ def test_cholesky_families_bitwise_equal(ctx, monkeypatch, N, K, B, iters):
             q.close()
         cx.close()
     for c in range(B):
-        _assert_same_fit(res[0][c], res[1][c], "family 1 vs 0, circuit %d" % c)
+        _assert_same_fit(res[0][c], res[1][c], "grouped vs pair family, circuit %d" % c)
     assert np.count_nonzero(res[0][0][0]) > 0
 
 
