@@ -582,7 +582,9 @@ def main():
         tile_flops = (float(np.mean([t["fact_products"] for t in tms_k])) + float(np.mean([t["inv_products"] for t in tms_k]))) * 65536.0
         if n_tiled > 0 and tiled_total > 0:
             cands["tiled solve (k_build_precision, k_chol_*, k_inv_*, column sums)"] = dict(
-                total_ms=tiled_total, launches=n_tiled, bytes=0.0, bound="mfma", flops=tile_flops / n_tiled,
+                total_ms=tiled_total, launches=n_tiled, bound="mfma", flops=tile_flops / n_tiled,
+                # its algorithmic bytes: the compulsory ones -- every active-set lower triangle read once, factor and inverse written once
+                bytes=float(np.mean([t["fact_tri_tiles"] for t in tms_k])) * 3 * 8192 / n_tiled,
                 note="block_update_mu of the iterations whose active sets exceed the in-LDS solver (7 of 50 at this shape): sparse precision build, "
                      "grouped fp64-MFMA Cholesky (rank-128 passes on 64 x 64 super-tiles), recursive-doubling inverse, column reductions; "
                      "`roofline.solve` splits out the factor passes and sets them against the compulsory bytes")
