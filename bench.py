@@ -6,12 +6,13 @@
 `--workload nwd` benchmarks the upstream NWD demixer forward pass instead (its own metric, traces/s; see bench_nwd).
 
 A "step" is one pass of the hot path over one batch of synthetic input: B independent circuits of the BASELINE shape (N=1000
-neurons, K=2000 trials, T=900 samples; default B = 128) fitted per GPU as ONE lock-step batch -- `iters` (50) CAVIaR iterations each plus
+neurons, K=2000 trials, T=900 samples; default B = 256) fitted per GPU as ONE lock-step batch -- `iters` (50) CAVIaR iterations each plus
 the false-negative scan and final phi update (reference circuitmap/optimise/caviar.py:79-98) -- through the C ABI's
-cm_caviar_run_batch: the circuit is the outer grid dimension of every kernel launch.  (`--batch-streams G` splits the B circuits into G
-lock-step batches on G contexts / HIP streams, one host thread each, so that the serial phases of one overlap the wide phases of the
-others: ~13 % more throughput, reported by the default run as the extra leg `interleaved_streams`; the headline keeps one batch per
-step so that every per-kernel figure -- HIP events, rocprof, PMC -- describes a kernel that had the GPU to itself.)  A single fit is a latency chain (N sequential
+cm_caviar_run_batch: the circuit is the outer grid dimension of every kernel launch.  (The library's own default for a batch, cm_options.interleave = 0,
+runs it as two halves in flight on two streams, so that the serial phases of one overlap the wide phases of the other: ~5 % more
+throughput, reported by the default run as the extra leg `interleaved` and timed instead of the headline with `--interleave`; the
+headline keeps one lock-step batch per step so that every per-kernel figure -- HIP events, rocprof, PMC -- describes a kernel that had
+the GPU to itself.)  A single fit is a latency chain (N sequential
 Gauss-Seidel steps, 31 dependent Cholesky panels, 10 dependent Newton steps) that occupies a few percent of an MI355X; the batch is
 what fills it, and it is the reference's own scale-out unit (independent circuits, one process each:
 scripts/generate_loho_cv_slurm_scripts.py:8-36).  Every circuit of a batch is bit-identical to its own single fit
@@ -365,14 +366,17 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--circuits-per-gpu", type=int, default=None, help="B: every step fits B independent circuits per GPU as ONE lock-step batch "
                     "(cm_caviar_run_batch: the circuit is the outer grid dimension of every launch); value counts all of their iterations.  "
-                    "Default 128 (1 for cfg5: one N=5000 circuit already fills the GPU); 1 = one circuit at a time (the latency form)")
+                    "Default 256 (1 for cfg5: one N=5000 circuit already fills the GPU); 1 = one circuit at a time (the latency form)")
+    ap.add_argument("--interleave", action="store_true", help="timed region with the library's default scheduling of a batch (cm_options.interleave = 0: two "
+                    "half-batches at a time on two streams, ~5 %% more throughput) instead of one lock-step batch per step; per-kernel durations -- and "
+                    "with them `roofline` -- are then those of kernels that share the GPU with the other half's")
     ap.add_argument("--batch-leg", type=int, default=16, help="with --circuits-per-gpu 1 on one GPU: also time a lock-step batch of this many "
                     "circuits after the main measurement and report it under `batch_throughput` (0 = skip)")
     ap.add_argument("--batch-streams", type=int, default=1, help="G (default 1): the B circuits of a step run as G lock-step batches of B / G circuits, each on its "
                     "own context (stream + mailboxes) driven by its own host thread, so that the latency-bound phases of one batch overlap the "
                     "wide phases of another")
-    ap.add_argument("--streams-leg", type=int, default=None, help="on one GPU with one lock-step batch per step: also time the same B circuits as "
-                    "this many interleaved batches on as many streams and report it under `interleaved_streams` (default 4; 0 = skip)")
+    ap.add_argument("--streams-leg", type=int, default=None, help="0: skip the `interleaved` leg (on one GPU with one lock-step batch per step the same B "
+                    "circuits are otherwise also timed with the library's default scheduling, two half-batches at a time on two streams)")
     ap.add_argument("--no-single-leg", action="store_true", help="with B > 1 on one GPU: skip the one-circuit-at-a-time measurement that is "
                     "otherwise reported beside the batch under `single_circuit`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -430,10 +434,10 @@ def main():
     wl = WORKLOADS[a.workload]
     N, K, T, H = wl["N"], wl["K"], wl["T"], wl["H"]
     if a.circuits_per_gpu is None:
-        a.circuits_per_gpu = 1 if a.workload == "cfg5" else 128
+        a.circuits_per_gpu = 1 if a.workload == "cfg5" else 256
     B = max(1, a.circuits_per_gpu)
     if a.streams_leg is None:
-        a.streams_leg = 4 if (B >= 16 and a.batch_streams == 1) else 0
+        a.streams_leg = 2 if (B >= 32 and a.batch_streams == 1 and not a.interleave) else 0
     pri = default_priors(N)
     # `world` sets of B independent circuits (seeds circuit_seed ...); every rank holds all sets in HBM and fits set (rank + step) mod
     # world at step `step`: at any moment the GPUs work on different circuits, and over the run every GPU sees the same mix, so the
@@ -488,8 +492,8 @@ def main():
         if B == 1:
             return probs[0].run(*run_args, timing=timing, **opts).as_dict()
         if G == 1:
-            return run_batch(probs, pri, timing=timing, **opts)[0].as_dict()
-        futs = [pool.submit(run_batch, probs[g::G], pri, timing=timing, **opts) for g in range(G)]
+            return run_batch(probs, pri, timing=timing, interleave=a.interleave, **opts)[0].as_dict()
+        futs = [pool.submit(run_batch, probs[g::G], pri, timing=timing, interleave=a.interleave, **opts) for g in range(G)]
         res = [f.result()[0].as_dict() for f in futs]
         return res[0]                                      # per-kernel times and counters: those of the first group (B / G circuits per launch)
 
@@ -535,7 +539,7 @@ def main():
         #     The ndtri(u) table row the MC logit reads (2 S x 8 B per neuron) is listed SEPARATELY (`table_bytes_per_launch`): the
         #     table is an artefact of this implementation (it replaces S quantile evaluations per neuron), not compulsory traffic.
         mid_ms = mean_k("mid_ms") / its
-        Bl = B // G if G > 1 else B                          # circuits per launch
+        Bl = int(tms_k[0].get("batch", B // G if G > 1 else B)) if tms_k else B      # circuits per launch (the library runs a batch as two interleaved halves by default)
         mid_bytes = Bl * (K * (8 + 8 + 1 + 1 + 8) + N * (8 + 8 + 32) + nnz * 9 + N * (8 + 4 * nvals + 48 + 48 + 4 + 8 + 8 * (nvals - 1)))
         mid_table = Bl * N * 2 * S * 16
         # (2) the Gauss-Seidel chain kernel (k_sweep_par), one launch per iteration: the records it actually streamed
@@ -609,7 +613,7 @@ def main():
             "dtype": "f64", "data": "synthetic" if gen_ms is None else "synthetic (generated on the GPU in %.2f ms per circuit)" % gen_ms,
             "config": {"workload": "%s: N=%d neurons, K=%d trials, T=%d, H=%d targets/trial, %d iterations + fn_scan per step, "
                                    "%s per GPU and step%s" % (a.workload, N, K, T, H, its,
-                                                              "1 circuit" if B == 1 else ("%d circuits as one lock-step batch" % B) if G == 1 else ("%d circuits as %d lock-step batches on %d streams" % (B, G, G)),
+                                                              "1 circuit" if B == 1 else ("%d circuits as one lock-step batch" % B) if (G == 1 and not a.interleave) else ("%d circuits as two interleaved half-batches (library default)" % B) if G == 1 else ("%d circuits as %d lock-step batches on %d streams" % (B, G, G)),
                                                               "" if world == 1 else ", %d circuit sets rotated over the ranks" % world),
                        "circuits_per_gpu": B, "nnz_targeted": int(nnz), "distinct_powers": int(nvals) - 1,
                        "mean_active_set": float(np.mean([t["sum_active"] for t in tms])) / max(its, 1)},
@@ -696,52 +700,42 @@ def main():
             del batch_res0, single_res0
         if world == 1 and B > 1 and not a.no_end_to_end and a.workload != "cfg5":
             out["end_to_end"] = end_to_end(_lib, ctx, local_rank, wl, pri, a, B)
-        if world == 1 and B > 1 and a.streams_leg and a.streams_leg > 1 and G == 1:
-            # the same B circuits as several lock-step batches in flight on separate contexts (HIP streams), one host thread each
-            for probs_ in sets:                              # (the main measurement's circuits are released first)
-                for q_ in probs_:
-                    q_.close()
-            sets = []
-            from concurrent.futures import ThreadPoolExecutor
-            from circuitmap_amd.simulation import simulate_device
-            Gs = a.streams_leg
-            lctx = [ctx] + [_lib.Context(local_rank) for _ in range(Gs - 1)]     # the main context + Gs - 1 more (as --batch-streams Gs creates them)
-            lprobs = [[] for _ in range(Gs)]
-            for j in range(B):
-                cx = lctx[j % Gs]
-                d = simulate_device(N=N, T=T, H=H, trials=K, seed=a.circuit_seed + j, device_id=local_rank, keep_on_device=True, ctx=cx)
-                lprobs[j % Gs].append(Problem(cx, None, None, device_ptrs=(N, K, T, d["psc_ptr"], d["stim_ptr"])))
-                cx.free(d["psc_ptr"]); cx.free(d["stim_ptr"])
-            with ThreadPoolExecutor(max_workers=Gs) as ex:
-                def lstep():
-                    for f in [ex.submit(run_batch, lprobs[g], pri, **opts) for g in range(Gs)]:
-                        f.result()
-                for _ in range(2):
-                    lstep()
-                for cx in lctx:
-                    cx.synchronize()
-                gc.collect(); gc.disable()
-                t1 = time.perf_counter()
-                lwall = []
-                for _ in range(6):
-                    ts_ = time.perf_counter()
-                    lstep()
-                    lwall.append((time.perf_counter() - ts_) * 1e3)
-                for cx in lctx:
-                    cx.synchronize()
-                ldt = time.perf_counter() - t1
-                if os.environ.get("CAVIAR_BENCH_TRACE_STEPS"):
-                    print("interleaved leg step wall ms:", " ".join("%.2f" % v for v in lwall), file=sys.stderr)
-                gc.enable()
-            for g in range(Gs):
-                for q in lprobs[g]:
-                    q.close()
+        if world == 1 and B > 1 and a.streams_leg and G == 1:
+            # the same B circuits with the library's default scheduling (cm_options.interleave = 0): two half-batches at a time, the second on the
+            # context's twin stream from the library's helper thread
+            probs = sets[0]
+            for _ in range(2):
+                run_batch(probs, pri, **opts)
+            ctx.synchronize()
+            gc.collect(); gc.disable()
+            t1 = time.perf_counter()
+            lwall = []
+            for _ in range(6):
+                ts_ = time.perf_counter()
+                ltm = run_batch(probs, pri, **opts)
+                lwall.append((time.perf_counter() - ts_) * 1e3)
+            ctx.synchronize()
+            ldt = time.perf_counter() - t1
+            gc.enable()
+            if os.environ.get("CAVIAR_BENCH_TRACE_STEPS"):
+                print("interleaved leg step wall ms:", " ".join("%.2f" % v for v in lwall), file=sys.stderr)
+            same = []
+            for ci in (0, B - 1):                              # one circuit of each half against its own single fit
+                got = probs[ci].fetch()
+                probs[ci].run(*run_args, **opts)
+                one = probs[ci].fetch()
+                same.append(bool(all(np.array_equal(np.asarray(x, dtype=float), np.asarray(y_, dtype=float), equal_nan=True) for x, y_ in zip(got[:8], one[:8]))))
+                del got, one
             lval = B * 6 * its / ldt
-            out["interleaved_streams"] = {"streams": Gs, "circuits_per_launch": B // Gs, "value": lval, "unit": "iterations/s", "steps": 6, "warmup": 2,
-                                          "ms_per_step": ldt / 6 * 1e3, "x_one_batch": lval / value,
-                                          "note": "the serial phases of one batch (Gauss-Seidel chains, Cholesky panels) overlap the wide phases of the "
-                                                  "others; per-kernel timings are then no longer those of a kernel alone on the GPU, which is why the "
-                                                  "headline keeps one batch per step"}
+            out["interleaved"] = {"value": lval, "unit": "iterations/s", "steps": 6, "warmup": 2, "ms_per_step": ldt / 6 * 1e3, "x_one_batch": lval / value,
+                                  "circuits_per_launch": sorted({int(t.batch) for t in ltm}), "equals_single": all(same),
+                                  "note": "cm_caviar_run_batch with its default scheduling: the batch as two halves in flight on two streams of the context, so "
+                                          "that the dependency-bound phases of one half (Gauss-Seidel chains, Newton steps, last Cholesky panels, false-negative "
+                                          "scan) overlap the wide phases of the other.  Kernels of the two halves then share the GPU and per-kernel durations "
+                                          "are no longer those of a kernel alone on the chip, which is why the timed region -- and `roofline` with it -- "
+                                          "keeps one lock-step batch per step (`--interleave` times this form instead)"}
+            if not all(same):
+                out["batch_equals_single"] = False
         if world == 1 and not a.no_cpu_baseline and sims:
             out["cpu_baseline"] = cpu_baseline(sims[0], pri, wl)
         emit(json.dumps(out))

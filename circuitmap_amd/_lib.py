@@ -16,7 +16,7 @@ CM_OK = 0
 CM_MEM_HOST, CM_MEM_DEVICE = 0, 1
 CM_RNG_THREEFRY, CM_RNG_EXPLICIT = 0, 1
 CM_MAX_VALS = 64
-CM_ABI_VERSION = 3          # include/caviar_hip.h; checked against the library at load()
+CM_ABI_VERSION = 4          # include/caviar_hip.h; checked against the library at load()
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -32,7 +32,7 @@ class CmOptions(C.Structure):
                 ("scale_factor", C.c_double), ("penalty", C.c_double), ("save_histories", C.c_int32),
                 ("max_backtrack_iters", C.c_int32), ("tol", C.c_double), ("spont_orthogonality", C.c_double),
                 ("fn_scan", C.c_int32), ("rng_mode", C.c_int32), ("update_orders", _ip), ("uniforms", _dp),
-                ("verbose", C.c_int32), ("timing", C.c_int32)]
+                ("verbose", C.c_int32), ("timing", C.c_int32), ("interleave", C.c_int32)]
 
 
 class CmResult(C.Structure):

@@ -140,7 +140,7 @@ def _scatter_circuits(circuits, n_total, shape, rank, world, device, group):
     return local
 
 
-def fit_batch(circuits, priors=None, fit_options=None, fit_fn=None, device=None, group=None, circuits_per_launch=128, streams=1, scatter=False):
+def fit_batch(circuits, priors=None, fit_options=None, fit_fn=None, device=None, group=None, circuits_per_launch=256, streams=1, scatter=False):
     """Fit a list of circuits [(psc K x T, stim N x K), ...] across the ranks of the default process group.
 
     Rank 0's `priors` / `fit_options` are broadcast to every rank.  Returns, on rank 0, a list of result dicts
@@ -154,12 +154,12 @@ def fit_batch(circuits, priors=None, fit_options=None, fit_fn=None, device=None,
     circuits must then have one shape (N, K, T).
 
     On a GPU each rank fits its share as LOCK-STEP BATCHES of up to `circuits_per_launch` circuits (C ABI cm_caviar_run_batch): one
-    set of kernel launches per phase for the whole batch, one Gauss-Seidel workgroup per circuit.  `streams` > 1 runs that many batches
-    at a time on separate contexts (HIP streams), the serial phases of one overlapping the wide phases of the others -- worth +10 %
-    while a batch left the GPU idle in its chains (round 2); since the chains, the false-negative scan and the tiled solve were
-    shortened one batch of 128 is the faster form (197 k against 182 k iterations/s at the headline shape), hence the defaults.  A single
-    fit is a latency chain that occupies a few percent of an MI355X; a batch of 128 delivers ~20x its iteration rate.  Every result is
-    bit-identical to the circuit's own fit.
+    set of kernel launches per phase for a whole batch, one Gauss-Seidel workgroup per circuit.  The library runs two batches at a time
+    (cm_options.interleave: a single batch of 32 circuits or more as two halves on two streams of the context), the dependency-bound phases
+    of one overlapping the wide phases of the other; `streams` > 1 adds that many contexts with a host thread each on top, which has not
+    paid since the chains, the false-negative scan and the tiled solve were shortened (round 3).  A single fit is a latency chain that
+    occupies a few percent of an MI355X; a batch of 256 delivers ~20x its iteration rate.  Every result is bit-identical to the circuit's
+    own fit.
     """
     import torch
     import torch.distributed as dist

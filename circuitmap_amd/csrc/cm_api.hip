@@ -92,7 +92,7 @@ extern "C" int cm_test_lds_race(uint64_t kernel_key, int32_t n_threads, int32_t 
   out[3] = applied;
   return CM_OK;
 }
-extern "C" const char* cm_version(void) { return "caviar_hip 0.3 (gfx950, ABI 3)"; }
+extern "C" const char* cm_version(void) { return "caviar_hip 0.3 (gfx950, ABI 4)"; }
 extern "C" int cm_abi_version(void) { return CM_ABI_VERSION; }
 
 extern "C" int cm_device_count(void) {
@@ -107,7 +107,7 @@ extern "C" void cm_options_default(cm_options* o) {   // caviar.py:21-23
   o->iters = 50; o->num_mc_samples = 100; o->seed = 0; o->y_xcorr_thresh = 1e-2; o->minimum_spike_count = 3;
   o->delay_spont_est = 1; o->msrmp = 0.3; o->scale_factor = 0.75; o->penalty = 5e0; o->save_histories = 0;
   o->max_backtrack_iters = 20; o->tol = 0.05; o->spont_orthogonality = 0.1; o->fn_scan = 1;
-  o->rng_mode = CM_RNG_THREEFRY; o->update_orders = nullptr; o->uniforms = nullptr; o->verbose = 0; o->timing = 0;
+  o->rng_mode = CM_RNG_THREEFRY; o->update_orders = nullptr; o->uniforms = nullptr; o->verbose = 0; o->timing = 0; o->interleave = 0;
 }
 
 extern "C" int cm_ctx_destroy(cm_ctx* c);
@@ -149,6 +149,8 @@ extern "C" int cm_ctx_create(int device_id, void* hip_stream, cm_ctx** out) {
 
 extern "C" int cm_ctx_destroy(cm_ctx* c) {
   if (!c) return CM_OK;
+  if (c->helper) { delete c->helper; c->helper = nullptr; }          // (idle: cm_caviar_run_batch waits for its task before it returns)
+  if (c->twin) { cm_ctx_destroy(c->twin); c->twin = nullptr; }
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
@@ -541,19 +543,73 @@ extern "C" int cm_caviar_run_batch(cm_ctx* ctx, int32_t n, cm_problem* const* pr
       if (problems[d] == problems[c]) { cm_set_error("cm_caviar_run_batch: problem %d appears twice", c); return CM_ERR_INVALID; }
   }
   CM_HIP(hipSetDevice(ctx->device));
+  struct job { cm_set s; std::vector<int> idx; std::vector<cm_priors> prs; std::vector<cm_timings> tms; };
+  std::vector<job> jobs;
   std::vector<char> done(n, 0);
-  for (int c0 = 0; c0 < n; ++c0) {
+  for (int c0 = 0; c0 < n; ++c0) {                                  // groups of circuits that can share launches
     if (done[c0]) continue;
-    cm_set s;
-    std::vector<int> idx;
-    for (int c = c0; c < n && (int)idx.size() < CM_MAX_BATCH; ++c)
-      if (!done[c] && cm_same_launch_config(problems[c0], problems[c])) { idx.push_back(c); done[c] = 1; s.ps.push_back(problems[c]); }
-    std::vector<cm_priors> prs(idx.size());
-    std::vector<cm_timings> tms(idx.size());
-    for (size_t i = 0; i < idx.size(); ++i) prs[i] = priors[idx[i]];
-    CM_TRY(run_guarded(ctx, s, prs.data(), o, timings ? tms.data() : nullptr));
-    if (timings) for (size_t i = 0; i < idx.size(); ++i) timings[idx[i]] = tms[i];
+    jobs.emplace_back();
+    job& j = jobs.back();
+    for (int c = c0; c < n && (int)j.idx.size() < CM_MAX_BATCH; ++c)
+      if (!done[c] && cm_same_launch_config(problems[c0], problems[c])) { j.idx.push_back(c); done[c] = 1; }
   }
+  // Two lock-step batches at a time: a batch leaves most of the GPU idle in its dependency-bound phases (one Gauss-Seidel workgroup per
+  // circuit, the Newton chains of k_iter_mid, the last panels of a factorisation, the false-negative scan), which a second, independent
+  // batch on another stream fills.  A single group is split in two halves; results do not depend on the grouping (every circuit is
+  // bit-identical to its own single fit).
+  static const bool env_off = getenv("CAVIAR_HIP_NO_INTERLEAVE") != nullptr;
+  const bool inter = o->interleave == 0 && !env_off && !o->verbose;
+  if (inter && jobs.size() == 1 && (int)jobs[0].idx.size() >= CM_INTERLEAVE_MIN) {
+    const size_t h = (jobs[0].idx.size() + 1) / 2;
+    jobs.emplace_back();
+    jobs[1].idx.assign(jobs[0].idx.begin() + h, jobs[0].idx.end());
+    jobs[0].idx.resize(h);
+  }
+  for (job& j : jobs) {
+    j.prs.resize(j.idx.size());
+    j.tms.resize(j.idx.size());
+    for (size_t i = 0; i < j.idx.size(); ++i) { j.prs[i] = priors[j.idx[i]]; j.s.ps.push_back(problems[j.idx[i]]); }
+  }
+  int rc = CM_OK;
+  if (!inter || jobs.size() < 2) {
+    for (job& j : jobs)
+      if ((rc = run_guarded(ctx, j.s, j.prs.data(), o, timings ? j.tms.data() : nullptr)) != CM_OK) return rc;
+  } else {
+    if (!ctx->twin) {
+      CM_TRY(cm_ctx_create(ctx->device, nullptr, &ctx->twin));
+      ctx->twin->solve_group = ctx->solve_group; ctx->twin->xcd_mode = ctx->xcd_mode; ctx->twin->chol_family = ctx->chol_family;
+      ctx->twin->use_mailbox = ctx->use_mailbox;
+    }
+    if (!ctx->helper) ctx->helper = new cm_helper();
+    cm_ctx* tw = ctx->twin;
+    CM_HIP(hipEventRecord(ctx->ev[9], ctx->stream));                 // whatever the caller queued on the context's stream comes first on both
+    CM_HIP(hipStreamWaitEvent(tw->stream, ctx->ev[9], 0));
+    std::atomic<int> next(0), failed(CM_OK);
+    std::string twin_msg;
+    auto worker = [&](cm_ctx* c, std::string* msg) {
+      if (hipSetDevice(c->device) != hipSuccess) { failed = CM_ERR_HIP; if (msg) *msg = "hipSetDevice failed in the helper thread"; return; }
+      for (;;) {
+        const int ji = next.fetch_add(1);
+        if (ji >= (int)jobs.size() || failed.load() != CM_OK) return;
+        job& j = jobs[ji];
+        const int r = run_guarded(c, j.s, j.prs.data(), o, timings ? j.tms.data() : nullptr);
+        if (r != CM_OK) { failed = r; if (msg) *msg = cm_last_error(); return; }
+      }
+    };
+    ctx->helper->start([&] { worker(tw, &twin_msg); });
+    worker(ctx, nullptr);
+    ctx->helper->wait();
+    hipStreamSynchronize(tw->stream);                                // (a finished run has synchronised already; an abandoned one has not)
+    if (tw->side) hipStreamSynchronize(tw->side);
+    rc = failed.load();
+    if (rc != CM_OK) {
+      if (!twin_msg.empty()) cm_set_error("%s", twin_msg.c_str());
+      return rc;
+    }
+  }
+  if (timings)
+    for (job& j : jobs)
+      for (size_t i = 0; i < j.idx.size(); ++i) timings[j.idx[i]] = j.tms[i];
   return CM_OK;
 }
 

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -39,6 +41,33 @@ void cm_set_error(const char* fmt, ...);
     if (_s != CM_OK) return _s;   \
   } while (0)
 
+// a host thread that runs one task at a time (cm_ctx::helper)
+struct cm_helper {
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  std::function<void()> task;
+  bool has = false, quit = false, idle = true;
+  cm_helper() {
+    th = std::thread([this] {
+      std::unique_lock<std::mutex> lk(m);
+      for (;;) {
+        cv.wait(lk, [this] { return has || quit; });
+        if (quit) return;
+        has = false;
+        lk.unlock();
+        task();
+        lk.lock();
+        idle = true;
+        cv.notify_all();
+      }
+    });
+  }
+  void start(std::function<void()> f) { std::lock_guard<std::mutex> lk(m); task = std::move(f); has = true; idle = false; cv.notify_all(); }
+  void wait() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [this] { return idle; }); }
+  ~cm_helper() { { std::lock_guard<std::mutex> lk(m); quit = true; cv.notify_all(); } th.join(); }
+};
+
 struct cm_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -62,6 +91,11 @@ struct cm_ctx {
   void* h_pdev = nullptr;
   size_t pdev_cap = 0;
   std::vector<hipEvent_t> pool;   // per-iteration events (CM_EV_PER_IT per iteration): phase stamps + cross-stream edges
+  // two lock-step batches at a time (cm_caviar_run_batch, cm_options.interleave): the second one runs on `twin` -- a context of its own on the
+  // same device (stream, mailboxes, events, scratch) driven by `helper`, a host thread that lives as long as the twin (a fresh thread per call
+  // would pay HIP's per-thread initialisation every time)
+  cm_ctx* twin = nullptr;
+  cm_helper* helper = nullptr;
 };
 
 // One circuit: encoded stimulus + observations + CAVIaR state.  All pointers are device memory.

@@ -15,7 +15,7 @@ _OPTION_NAMES = ["iters", "num_mc_samples", "seed", "y_xcorr_thresh", "minimum_s
 
 def make_options(lib, iters=50, num_mc_samples=100, seed=0, y_xcorr_thresh=1e-2, minimum_spike_count=3,
                  delay_spont_est=1, msrmp=0.3, scale_factor=0.75, penalty=5e0, save_histories=False,
-                 max_backtrack_iters=20, tol=0.05, spont_orthogonality=0.1, fn_scan=True, verbose=0, timing=0):
+                 max_backtrack_iters=20, tol=0.05, spont_orthogonality=0.1, fn_scan=True, verbose=0, timing=0, interleave=True):
     o = _lib.CmOptions()
     lib.cm_options_default(C.byref(o))
     o.iters, o.num_mc_samples, o.seed = int(iters), int(num_mc_samples), int(seed)
@@ -24,6 +24,7 @@ def make_options(lib, iters=50, num_mc_samples=100, seed=0, y_xcorr_thresh=1e-2,
     o.save_histories, o.max_backtrack_iters, o.tol = int(bool(save_histories)), int(max_backtrack_iters), float(tol)
     o.spont_orthogonality, o.fn_scan, o.verbose = float(spont_orthogonality), int(bool(fn_scan)), int(verbose)
     o.timing = int(timing)
+    o.interleave = 0 if interleave else 1
     return o
 
 
@@ -129,11 +130,14 @@ def _priors_struct(N, mu_prior, beta_prior, shape_prior, rate_prior, phi_prior, 
     return _lib.CmPriors(_lib.dptr(arrs[0]), _lib.dptr(arrs[1]), float(shape_prior), float(rate_prior), _lib.dptr(arrs[2]), _lib.dptr(arrs[3]))
 
 
-def run_batch(problems, priors, update_orders=None, uniforms=None, verbose=0, timing=0, **fit_options):
+def run_batch(problems, priors, update_orders=None, uniforms=None, verbose=0, timing=0, interleave=True, **fit_options):
     """cm_caviar_run_batch: fit several `Problem`s of ONE context in lock-step (the circuit is the outer grid dimension of every
     launch).  `priors`: one dict (shared) or a list of dicts with keys mu, beta, shape, rate, phi, phi_cov.  Results stay in HBM
     (`Problem.fetch`), each bit-identical to the circuit's own `Problem.run`.  `update_orders` [iters, N] / `uniforms`
-    [iters, N, S, 2]: explicit RNG streams, shared by all circuits (which must then have the same N).  Returns the device timings."""
+    [iters, N, S, 2]: explicit RNG streams, shared by all circuits (which must then have the same N).  `interleave` (default): two
+    lock-step batches at a time -- a group of 32 circuits or more is split in two halves that run on two streams of the context, the
+    dependency-bound phases of one overlapping the wide phases of the other (cm_options.interleave); False: one batch at a time
+    (kernel-level profiling).  Results are identical either way.  Returns the device timings."""
     if not problems:
         return []
     ctx = problems[0].ctx
@@ -142,7 +146,7 @@ def run_batch(problems, priors, update_orders=None, uniforms=None, verbose=0, ti
     unknown = set(fit_options) - set(_OPTION_NAMES)
     if unknown:
         raise TypeError("caviar() got an unexpected keyword argument '%s'" % sorted(unknown)[0])
-    o = make_options(ctx.lib, verbose=verbose, timing=timing, **fit_options)
+    o = make_options(ctx.lib, verbose=verbose, timing=timing, interleave=interleave, **fit_options)
     n = len(problems)
     plist = [priors] * n if isinstance(priors, dict) else list(priors)
     keep = []

@@ -40,10 +40,10 @@ typedef enum cm_status {
 #define CM_MAX_VALS 64        /* distinct values of the stimulus matrix (0 and the laser powers) */
 
 /* ABI handshake.  Bumped whenever the layout of a struct of this header changes (history: 1 = round 1; 2 = cm_timings re-laid out
- * in round 2; 3 = this field, cm_timings.fact_tri_tiles / fact_products).  cm_options_default() writes it into cm_options.abi_version and every entry point
+ * in round 2; 3 = this field, cm_timings.fact_tri_tiles / fact_products; 4 = cm_options.interleave).  cm_options_default() writes it into cm_options.abi_version and every entry point
  * that takes a cm_options refuses (CM_ERR_INVALID) a value other than the library's own: a caller compiled against another header
  * gets an error code instead of silently mis-read fields or an overrun cm_timings.  cm_abi_version() returns the library's value. */
-#define CM_ABI_VERSION 3
+#define CM_ABI_VERSION 4
 
 typedef enum cm_mem_kind { CM_MEM_HOST = 0, CM_MEM_DEVICE = 1 } cm_mem_kind;
 typedef enum cm_rng_mode {
@@ -90,7 +90,15 @@ typedef struct cm_options {
   int32_t timing;                  /* cm_timings detail.  0: fit totals only (4 events per fit, the default: per-kernel events cost ~2 us
                                       of launch boundary each, ~8 % of a fit); 1: + events around the chain kernel and the mid-iteration
                                       kernel of every iteration (sweep_seq_ms, mid_ms); 2: + all phase stamps                                  */
+  int32_t interleave;              /* cm_caviar_run_batch / cm_caviar_fit_batch.  0 (default): two lock-step batches at a time -- a group of
+                                      >= CM_INTERLEAVE_MIN circuits is split in two halves, the second half (or every other group) runs on a
+                                      second stream of the context from a helper thread, so that the dependency-bound phases of one batch
+                                      (Gauss-Seidel chains, Newton steps, last Cholesky panels, false-negative scan) overlap the wide phases
+                                      of the other.  1: one lock-step batch at a time on the context's
+                                      stream (kernel-level profiling; the per-kernel cm_timings are then free of cross-stream contention).
+                                      Results are identical either way.                                                                          */
 } cm_options;
+#define CM_INTERLEAVE_MIN 32       /* smallest group that is split in two halves */
 
 /* Caller-allocated host output buffers (any pointer may be NULL = not wanted).  Replaces the 17-tuple of caviar.py:100. */
 typedef struct cm_result {

@@ -68,6 +68,7 @@ def test_defaults_are_the_reference_defaults(lib):
     for k, v in ref.items():
         assert getattr(o, k) == v, k
     assert o.rng_mode == _lib.CM_RNG_THREEFRY
+    assert o.interleave == 0 and o.timing == 0 and o.verbose == 0          # two lock-step batches at a time is the default of the batch entry points
 
 
 def test_host_side_pava_matches_golden(lib):

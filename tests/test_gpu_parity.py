@@ -601,8 +601,8 @@ def test_caviar_vs_golden_cfg2():
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
-# The launch configuration bench.py times: lock-step batches with SEVERAL circuits per XCD (B = 16, 128), the listed-rows grid at
-# that size, the host scan pool, and the same circuits as 4 x 32 on four contexts.  (Unit of scale-out this replaces: one process
+# The launch configuration bench.py times: lock-step batches with SEVERAL circuits per XCD (B = 16 ... 256), the listed-rows grid at
+# that size, the library's default scheduling (two interleaved half-batches), and the same circuits as 4 x 32 on four contexts.  (Unit of scale-out this replaces: one process
 # per circuit, reference scripts/generate_loho_cv_slurm_scripts.py:8-36.)
 # ---------------------------------------------------------------------------------------------------------------------------------
 def _device_circuits(cx, N, K, B, seed0, T=900, host_copy_of=()):
@@ -619,23 +619,30 @@ def _device_circuits(cx, N, K, B, seed0, T=900, host_copy_of=()):
     return probs, host
 
 
-@pytest.mark.parametrize("N,K,B,iters", [(200, 400, 16, 14), (200, 400, 128, 14), (1000, 2000, 16, 50), (1000, 2000, 128, 50)])
+@pytest.mark.parametrize("N,K,B,iters", [(200, 400, 16, 14), (200, 400, 33, 14), (200, 400, 128, 14), (1000, 2000, 16, 50), (1000, 2000, 256, 50)])
 def test_run_batch_many_per_xcd(ctx, N, K, B, iters):
     """cm_caviar_run_batch with 2 and 16 circuits per XCD (cm_xcd_remap mode 3 with per > 1, which needs gridDim.y % 8 == 0): every
     circuit bit-identical to its own cm_caviar_run; circuit 0 within 1e-6 of the running-residual oracle (the small shape; the
     N = 1000 oracle trajectory is test_caviar_vs_oracle_bench_sizes).  N = 200 / K = 400 starts with a 7-tile-row tiled solve;
-    (1000, 2000, 128) is bench.py's default step."""
+    (1000, 2000, 256) is bench.py's default step: timed as one lock-step batch, and as the two interleaved half-batches that are the
+    library's default scheduling (cm_options.interleave) -- both forms are checked."""
     from circuitmap_amd.optimise.caviar import run_batch
     from oracle import caviar_oracle as co
     pri = default_priors(N)
     opts = dict(iters=iters, seed=0)
     probs, host = _device_circuits(ctx, N, K, B, 4000, host_copy_of=(0,) if N <= 200 else ())
-    tms = run_batch(probs, pri, **opts)
+    tms = run_batch(probs, pri, interleave=False, **opts)                 # one lock-step batch of B
     assert all(t.batch == B for t in tms)
     batch = [q.fetch() for q in probs]
+    tms = run_batch(probs, pri, **opts)                                   # the default: two half-batches at a time on two streams (B >= 32)
+    halves = [B] * B if B < 32 else [(B + 1) // 2] * ((B + 1) // 2) + [B // 2] * (B // 2)
+    assert [t.batch for t in tms] == halves
+    inter = [q.fetch() for q in probs]
     for c, q in enumerate(probs):
         q.run(*prior_args(pri), **opts)
-        _assert_same_fit(batch[c], q.fetch(), "B=%d circuit %d" % (B, c))
+        single = q.fetch()
+        _assert_same_fit(batch[c], single, "B=%d circuit %d" % (B, c))
+        _assert_same_fit(inter[c], single, "B=%d (two interleaved halves) circuit %d" % (B, c))
     if host:
         ref = co.caviar(host[0][0], host[0][1], *prior_args(pri), literal=False, **opts)
         for i, nm in enumerate(OUT_NAMES):
@@ -671,8 +678,9 @@ def test_run_batch_xcd_placement_never_matters(ctx, monkeypatch, mode):
 
 
 def test_fit_batch_128_as_4x32_streams(ctx):
-    """bench.py's `interleaved_streams` leg and fit_batch's default: 128 circuits of the headline shape as 4 lock-step batches of 32 on
-    four contexts (HIP streams + mailboxes), one host thread each -- every circuit bit-identical to its own single fit."""
+    """fit_batch(streams=4): 128 circuits of the headline shape as 4 lock-step batches of 32 on four contexts (HIP streams + mailboxes),
+    one host thread each -- and each of those batches as the library's two interleaved halves on its context's twin stream (eight
+    batches in flight, four helper threads): every circuit bit-identical to its own single fit."""
     from circuitmap_amd import batch
     from circuitmap_amd.optimise.caviar import Problem
     from circuitmap_amd.simulation import simulate_device
