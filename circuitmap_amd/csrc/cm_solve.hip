@@ -35,7 +35,10 @@
 #define CM_LARGE_TILES 48     // more tile rows than this: panel solve + lean trailing-update kernels (bandwidth-bound regime)
 
 #define CM_LINV_THREADS 1024  // threads that run the diagonal-tile elimination (256 was measured slower: 4 elements per thread)
-#define TP (CM_TILE + 1)   // padded LDS row (doubles)
+#define TP (CM_TILE + 2)   // padded LDS row (doubles): even, so that a thread's pair of neighbours moves with one 16-byte LDS store.  The matrix-core operand reads
+                          // are tile[row = lane & 15][k = lane >> 4] (ds_read_b64, banked over the 32 lanes of a half-wave on 64 dword banks): a pitch of
+                          // 68 dwords puts the 32 (row, k) pairs on 32 distinct bank pairs, where 32 + 1 made (row, 1) collide with (row + 1, 0)
+#define TPN (CM_TILE + 16) // pitch of a tile read as B[k = lane >> 4][col = lane & 15] (blk_mfma_nn): 96 dwords = 32 mod 64 keeps k = 0 / 1 on disjoint banks
 
 // ------------------------------------------------------------------------------------------------
 // precision matrix over the active set; one wave per (padded) row, accumulator row in LDS.
@@ -191,18 +194,46 @@ __device__ __forceinline__ void cm_gstore(double* base, unsigned byte_off, doubl
 // kernel that needs several tiles fetches all of them before the first tile_put (a load-and-store loop per tile costs one memory
 // round trip per element and tile -- measured: 8 dependent round trips in front of a 0.2 us tile product).  NT = threads of the
 // workgroup taking part (compile time).
-template <int NT = 256>
-__device__ __forceinline__ void tile_fetch(double (&r)[TS * TS / NT], const double* __restrict__ src, int ld) {
-#pragma unroll
-  for (int q = 0; q < TS * TS / NT; ++q) {
-    const unsigned i = threadIdx.x + NT * q;
-    r[q] = cm_gload(src, ((i / TS) * (unsigned)ld + (i % TS)) * (unsigned)sizeof(double));    // (a tile spans < 32 rows: far below 4 GB)
-  }
+// NT = 256: a thread moves two pairs of neighbours -- 16 B per lane and load (a wave-instruction covers four 256-byte tile rows; the texture
+// addresser works per lane, 8-byte lanes need twice the instructions for the same bytes) and one 16-byte LDS store per pair.  Measured on 128 x
+// n = 1000: Cholesky 1.65 -> 1.55 ms, inverse 1.29 -> 1.21 ms (the change of the LDS pitch alone: nothing -- the operand reads are not the bound).
+typedef double cm_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cm_d2 cm_gload2(const double* base, unsigned byte_off) {
+  return *(const __attribute__((address_space(1))) cm_d2*)((const __attribute__((address_space(1))) char*)base + byte_off);
 }
 template <int NT = 256>
-__device__ __forceinline__ void tile_put(double (*dst)[TP], const double (&r)[TS * TS / NT]) {
+__device__ __forceinline__ void tile_fetch(double (&r)[TS * TS / NT], const double* __restrict__ src, int ld) {
+  constexpr int E = TS * TS / NT;
+  if constexpr (E % 2 == 0) {
 #pragma unroll
-  for (int q = 0; q < TS * TS / NT; ++q) { const int i = threadIdx.x + NT * q; dst[i / TS][i % TS] = r[q]; }
+    for (int q = 0; q < E / 2; ++q) {
+      const unsigned i = threadIdx.x + NT * q;
+      const cm_d2 v = cm_gload2(src, ((i / (TS / 2)) * (unsigned)ld + 2 * (i % (TS / 2))) * (unsigned)sizeof(double));   // (a tile spans < 32 rows: far below 4 GB)
+      r[2 * q] = v.x; r[2 * q + 1] = v.y;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      const unsigned i = threadIdx.x + NT * q;
+      r[q] = cm_gload(src, ((i / TS) * (unsigned)ld + (i % TS)) * (unsigned)sizeof(double));
+    }
+  }
+}
+template <int NT = 256, int PITCH = TP>
+__device__ __forceinline__ void tile_put(double (*dst)[PITCH], const double (&r)[TS * TS / NT]) {
+  constexpr int E = TS * TS / NT;
+  static_assert(PITCH % 2 == 0, "16-byte LDS stores need an even pitch");
+  if constexpr (E % 2 == 0) {
+#pragma unroll
+    for (int q = 0; q < E / 2; ++q) {
+      const int i = threadIdx.x + NT * q;
+      cm_d2 v; v.x = r[2 * q]; v.y = r[2 * q + 1];
+      *reinterpret_cast<cm_d2*>(&dst[i / (TS / 2)][2 * (i % (TS / 2))]) = v;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < E; ++q) { const int i = threadIdx.x + NT * q; dst[i / TS][i % TS] = r[q]; }
+  }
 }
 __device__ __forceinline__ void tile_store(double* __restrict__ dst, int ld, const double (*src)[TP]) {
   for (int i = threadIdx.x; i < TS * TS; i += blockDim.x) dst[(size_t)(i / TS) * ld + (i % TS)] = src[i / TS][i % TS];
@@ -222,7 +253,7 @@ __device__ __forceinline__ cm_d4 blk_mfma_nt(cm_d4 acc, const double (*A)[TP], c
   return acc;
 }
 // acc += A[16 rb .., :] * B[:, 16 cb ..]
-__device__ __forceinline__ cm_d4 blk_mfma_nn(cm_d4 acc, const double (*A)[TP], const double (*B)[TP], int rb, int cb, int lane) {
+__device__ __forceinline__ cm_d4 blk_mfma_nn(cm_d4 acc, const double (*A)[TP], const double (*B)[TPN], int rb, int cb, int lane) {
   const int r = lane & 15, kk = lane >> 4;
 #pragma unroll
   for (int ks = 0; ks < TS / 4; ++ks)
@@ -429,7 +460,7 @@ __global__ __launch_bounds__(256) void k_chol_first(cm_parg<BATCH> pa, int na_ar
   double* __restrict__ A = p.A;
   double* __restrict__ Dinv = p.Dinv;
   int* __restrict__ flag = p.n_act + 1;
-  __shared__ double C[TS][TP], Li[TS][TP];
+  __shared__ __attribute__((aligned(16))) double C[TS][TP], Li[TS][TP];
   double rc[4];
   tile_fetch(rc, A, ld);
   tile_put(C, rc);
@@ -446,7 +477,7 @@ __global__ __launch_bounds__(256) void k_chol_trsm(cm_parg<BATCH> pa, int na_arg
   const double* __restrict__ A = p.A;
   double* __restrict__ Lf = p.Lf;
   const double* __restrict__ Dinv = p.Dinv;
-  __shared__ double P[TS][TP], Li[TS][TP];
+  __shared__ __attribute__((aligned(16))) double P[TS][TP], Li[TS][TP];
   const int i = j + 1 + blockIdx.x;
   double rp[4], rl[4];
   tile_fetch(rp, A + (size_t)i * TS * ld + (size_t)j * TS, ld);
@@ -483,7 +514,7 @@ __global__ __launch_bounds__(256) void k_chol_bulk(cm_parg<BATCH> pa, int na_arg
   const double* __restrict__ Lf = p.Lf;
   double* __restrict__ Dinv = p.Dinv;
   int* __restrict__ flag = p.n_act + 1;
-  __shared__ double Sm[WIDE ? 2 : 3][TS][TP];        // two tiles (17 KB; the thin pass also stages L_jj^-1): LDS is not what limits the workgroups per CU
+  __shared__ __attribute__((aligned(16))) double Sm[WIDE ? 2 : 3][TS][TP];        // two tiles (17 KB; the thin pass also stages L_jj^-1): LDS is not what limits the workgroups per CU
   const int t = bx;                                  // id 0 is the pass's diagonal tile
   int i, l;
   if (WIDE) {                                        // linear id -> (i, l), j + 2 <= l <= i
@@ -669,7 +700,7 @@ __global__ __launch_bounds__(256) void k_chol_diag(cm_parg<BATCH> pa, int na_arg
   CM_SOLVE_PROLOGUE(2)
   (void)large_min;                                   // (a one-tile matrix of a batch is factored here too: nothing else touches it)
   if (na == 0 || j0 >= nblk) return;
-  extern __shared__ double sm_dyn[];
+  extern __shared__ __attribute__((aligned(16))) double sm_dyn[];
   chol_diag_block(p, sm_dyn, j0, min(CM_GRP, nblk - j0), ld);
 }
 
@@ -685,7 +716,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_gpanel(cm_parg<BATCH> pa, int n
   const double* __restrict__ A = p.A;
   double* __restrict__ Lf = p.Lf;
   const double* __restrict__ Dinv = p.Dinv;
-  extern __shared__ double sm_dyn[];
+  extern __shared__ __attribute__((aligned(16))) double sm_dyn[];
   const int i = j0 + CM_GRP + bx;
   const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE, rb = wave >> 1, cb = wave & 1;
   double a[CM_GRP][4], rl[CM_GRP * (CM_GRP - 1) / 2][4], rd[CM_GRP][4];
@@ -793,7 +824,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_wide(cm_parg<BATCH> pa, int na_
   const int t = nblk - j0 - CM_GRP;                  // trailing tile rows
   if (nblk <= large_min || t <= 0) return;
   const int ns = (t + 1) >> 1, nst = ns * (ns + 1) / 2;   // super-rows, super-tiles (lower triangle, row-major: id = I (I + 1) / 2 + L)
-  extern __shared__ double sm_dyn[];
+  extern __shared__ __attribute__((aligned(16))) double sm_dyn[];
   if (bx > 0) {
     const int id = bx + 2;                           // workgroup 0 owns super-tiles 0, 1, 2
     if (id >= nst) return;
@@ -832,7 +863,7 @@ __global__ __launch_bounds__(1024) void k_chol_panel(cm_parg<BATCH> pa, int na_a
   double* __restrict__ Lf = p.Lf;
   double* __restrict__ Dinv = p.Dinv;
   int* __restrict__ flag = p.n_act + 1;
-  __shared__ double Pi[TS][TP], Pl[TS][TP], Li[TS][TP], Xi[TS][TP], Xl[TS][TP];
+  __shared__ __attribute__((aligned(16))) double Pi[TS][TP], Pl[TS][TP], Li[TS][TP], Xi[TS][TP], Xl[TS][TP];
   const int t = blockIdx.x;
   int ip = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
   while ((ip + 1) * (ip + 2) / 2 <= t) ++ip;
@@ -905,7 +936,7 @@ __global__ __launch_bounds__(256) void k_inv_seed(cm_parg<BATCH> pa, int na_arg,
   tile_fetch(r, Dinv + (size_t)d * TS * TS, TS);
   double* dst = X + (size_t)d * TS * ld + (size_t)d * TS;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) { const int i = threadIdx.x + 256 * q; dst[(size_t)(i / TS) * ld + (i % TS)] = r[q]; }
+  for (int q = 0; q < 4; ++q) { const int i = threadIdx.x + 256 * (q >> 1); dst[(size_t)(i / (TS / 2)) * ld + 2 * (i % (TS / 2)) + (q & 1)] = r[q]; }   // (tile_fetch's element map)
 }
 
 template <bool BATCH>
@@ -916,7 +947,7 @@ __global__ __launch_bounds__(256) void k_inv_T(cm_parg<BATCH> pa, int na_arg, in
   double* __restrict__ A = p.A;
   const double* __restrict__ Lf = p.Lf;
   const double* __restrict__ X = p.X;
-  __shared__ double Lt[TS][TP], Xt[TS][TP];
+  __shared__ __attribute__((aligned(16))) double Lt[TS][TP], Xt[TS][TPN];
   const int per = b * b;
   const int q = bx / per, rem = bx % per;
   const int j2 = (2 * q + 1) * b + rem / b;     // tile row in the second half
@@ -931,7 +962,7 @@ __global__ __launch_bounds__(256) void k_inv_T(cm_parg<BATCH> pa, int na_arg, in
   for (int j1 = c; j1 < jend; ++j1) {
     __syncthreads();
     tile_put(Lt, ra);
-    tile_put(Xt, rx);
+    tile_put<256, TPN>(Xt, rx);
     __syncthreads();
     if (j1 + 1 < jend) {
       tile_fetch(ra, Lf + (size_t)j2 * TS * ld + (size_t)(j1 + 1) * TS, ld);
@@ -951,7 +982,7 @@ __global__ __launch_bounds__(256) void k_inv_X21(cm_parg<BATCH> pa, int na_arg, 
   CM_SOLVE_PROLOGUE_AT(2, pa.get(circ))
   const double* __restrict__ A = p.A;
   double* __restrict__ X = p.X;
-  __shared__ double Xa[TS][TP], Tt[TS][TP];
+  __shared__ __attribute__((aligned(16))) double Xa[TS][TP], Tt[TS][TPN];
   const int per = b * b;
   const int q = bx / per, rem = bx % per;
   const int i = (2 * q + 1) * b + rem / b;
@@ -966,7 +997,7 @@ __global__ __launch_bounds__(256) void k_inv_X21(cm_parg<BATCH> pa, int na_arg, 
   for (int j2 = jbeg; j2 <= i; ++j2) {
     __syncthreads();
     tile_put(Xa, ra);
-    tile_put(Tt, rx);
+    tile_put<256, TPN>(Tt, rx);
     __syncthreads();
     if (j2 + 1 <= i) {
       tile_fetch(ra, X + (size_t)i * TS * ld + (size_t)(j2 + 1) * TS, ld);
