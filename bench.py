@@ -294,7 +294,7 @@ def end_to_end(_lib, ctx, local_rank, wl, pri, a, B):
     mu / beta / phi / phi_cov / z, cm_problem_destroy -- and (b) from host arrays through the C entry point cm_caviar_fit_batch (upload over
     PCIe included; the dense N x K lam is not requested).  Never `value`: the headline keeps inputs resident."""
     import numpy as np
-    from circuitmap_amd.optimise.caviar import Problem, run_batch, make_options, _priors_struct
+    from circuitmap_amd.optimise.caviar import Problem, run_batch, fetch_batch, make_options, _priors_struct
     from circuitmap_amd.simulation import simulate_device
     N, K, T, H = wl["N"], wl["K"], wl["T"], wl["H"]
     opts = dict(iters=a.iters, seed=0)
@@ -303,11 +303,11 @@ def end_to_end(_lib, ctx, local_rank, wl, pri, a, B):
 
     def dev_pass():
         t = [time.perf_counter()]
-        probs = [Problem(ctx, None, None, device_ptrs=(N, K, T, d["psc_ptr"], d["stim_ptr"])) for d in devs]
+        probs = Problem.create_batch(ctx, [("device", N, K, T, d["psc_ptr"], d["stim_ptr"]) for d in devs])
         ctx.synchronize(); t.append(time.perf_counter())
         run_batch(probs, pri, **opts)
         ctx.synchronize(); t.append(time.perf_counter())
-        outs = [q.fetch(want_lam=False) for q in probs]
+        outs = fetch_batch(probs)
         t.append(time.perf_counter())
         for q in probs:
             q.close()
@@ -322,8 +322,9 @@ def end_to_end(_lib, ctx, local_rank, wl, pri, a, B):
     tot = sum(best)
     res["device_resident"] = {"ms": tot, "value": B * a.iters / tot * 1e3, "unit": "iterations/s", "create_ms": best[0], "create_ms_per_circuit": best[0] / B,
                               "fit_ms": best[1], "fetch_ms": best[2], "destroy_ms": best[3],
-                              "note": "inputs in HBM: cm_problem_create(CM_MEM_DEVICE) x B (two allocations + one host wait each), one lock-step batch, "
-                                      "fetch of mu / beta / phi / phi_cov / z per circuit, destroy; best of 3"}
+                              "note": "inputs in HBM: cm_problem_create_batch(CM_MEM_DEVICE) (the prologue kernels once per group of 64, memory from the context's pool), "
+                                      "cm_caviar_run_batch with its default scheduling, cm_caviar_fetch_batch (mu / beta / phi / phi_cov / z / shape / rate of all "
+                                      "circuits with one device-to-host copy), destroy (memory back to the pool); best of 3"}
     # (b) host arrays through the C entry point
     hosts = [(ctx.download(d["psc_ptr"], np.empty((K, T))), ctx.download(d["stim_ptr"], np.empty((N, K)))) for d in devs]
     for d in devs:

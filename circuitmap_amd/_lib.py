@@ -94,10 +94,14 @@ SYMBOLS = {
     "cm_ctx_create": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "cm_ctx_destroy": (C.c_int, [C.c_void_p]),
     "cm_ctx_synchronize": (C.c_int, [C.c_void_p]),
+    "cm_ctx_release_cache": (C.c_int, [C.c_void_p]),
     "cm_mem_alloc": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "cm_mem_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cm_mem_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),
     "cm_problem_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "cm_problem_create_batch": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_void_p),
+                                          C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)]),
+    "cm_caviar_fetch_batch": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(CmResult)]),
     "cm_problem_destroy": (C.c_int, [C.c_void_p]),
     "cm_problem_nnz": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "cm_caviar_run": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(CmPriors), C.POINTER(CmOptions), C.POINTER(CmTimings)]),
@@ -194,6 +198,11 @@ class Context:
     def synchronize(self):
         with self.lock:
             check(self.lib.cm_ctx_synchronize(self.handle))
+
+    def release_cache(self):
+        """Return the device memory the context keeps from destroyed problems (its pool) to the driver."""
+        with self.lock:
+            check(self.lib.cm_ctx_release_cache(self.handle))
 
     # device buffers without torch (cm_mem_*): addresses are plain ints.  Every entry into the library on this context takes the
     # context's lock (caviar_hip.h: calls on one cm_ctx must be serialised; contexts are shared with worker threads in fit_batch / bench).

@@ -58,23 +58,24 @@ def _fit_lockstep(circuits, mine, priors, fit_options, device_id, max_group, str
     the latency-bound phases of one batch (its Gauss-Seidel chains, its Cholesky panels) then overlap the wide phases of the
     others.  Returns the result dicts in the order of `mine`."""
     from . import _lib
-    from .optimise.caviar import Problem, run_batch
+    from .optimise.caviar import Problem, fetch_batch, run_batch
     names = ["mu", "beta", "lam", "shape", "rate", "phi", "phi_cov", "z"]
     groups = [mine[g0:g0 + max_group] for g0 in range(0, len(mine), max_group)]
     out = {}
 
-    def make_problem(ctx, c):
-        if len(c) == 2:
-            return Problem(ctx, *c)                                   # host arrays (psc, stim)
-        _, t, N, K, T = c                                             # ("device", float64 CUDA tensor [K*T + N*K], N, K, T): a scattered circuit, never on this host
-        return Problem(ctx, None, None, device_ptrs=(N, K, T, t.data_ptr(), t.data_ptr() + K * T * 8))
+    def make_problems(ctx, idx):
+        cs = [circuits[ci] for ci in idx]
+        if len(cs[0]) == 2:
+            return Problem.create_batch(ctx, cs)                     # host arrays (psc, stim): one encoding pass for the group
+        # ("device", float64 CUDA tensor [K*T + N*K], N, K, T): scattered circuits, never on this host
+        return Problem.create_batch(ctx, [("device", N, K, T, t.data_ptr(), t.data_ptr() + K * T * 8) for _, t, N, K, T in cs])
 
     def fit_group(ctx, idx):
-        probs = [make_problem(ctx, circuits[ci]) for ci in idx]
+        probs = make_problems(ctx, idx)
         try:
             run_batch(probs, priors, **fit_options)
-            for ci, q in zip(idx, probs):
-                out[ci] = dict(zip(names, q.fetch(want_lam=False)[:8]))
+            for ci, res in zip(idx, fetch_batch(probs)):             # one device-to-host copy for the group
+                out[ci] = dict(zip(names, res))
         finally:
             for q in probs:
                 q.close()

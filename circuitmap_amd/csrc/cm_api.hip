@@ -141,6 +141,8 @@ extern "C" int cm_ctx_create(int device_id, void* hip_stream, cm_ctx** out) {
   CM_HIP(hipSetDevice(device_id));
   cm_ctx* c = new cm_ctx();
   c->device = device_id;
+  c->root = c;
+  if (const char* e = getenv("CAVIAR_HIP_POOL_GB")) c->mem.cap_bytes = (size_t)(atof(e) * (double)((size_t)1 << 30));
   const int rc = ctx_init(c, device_id, hip_stream);
   if (rc != CM_OK) { cm_ctx_destroy(c); return rc; }      // a half-built context is released, not leaked
   *out = c;
@@ -160,6 +162,7 @@ extern "C" int cm_ctx_destroy(cm_ctx* c) {
   if (c->h_stage) hipHostFree(c->h_stage);
   if (c->h_pdev) hipHostFree(c->h_pdev);
   if (c->d_pdev) hipFree(c->d_pdev);
+  if (c->root == c) cm_pool_trim(c, 0);                               // the idle slabs of the pool (a twin allocates from its parent's)
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   delete c;
   return CM_OK;
@@ -204,6 +207,76 @@ static int dmalloc(T** p, size_t n) {
   return CM_OK;
 }
 
+// ---- device-memory pool (cm_internal.h)
+static size_t pool_class(size_t b) {                // next size of the form m * 2^e, m in 8..15 (classes 12.5 % apart), at least 64 KB
+  if (b <= ((size_t)64 << 10)) return (size_t)64 << 10;
+  int e = 0;
+  while ((b >> e) > 15) ++e;
+  size_t c = ((b + (((size_t)1 << e) - 1)) >> e) << e;
+  return c;
+}
+int cm_pool_alloc(cm_ctx* ctx, void** out, size_t bytes) {
+  cm_pool& pl = ctx->root->mem;
+  const size_t c = pool_class(bytes ? bytes : 1);
+  {
+    std::lock_guard<std::mutex> lk(pl.m);
+    auto it = pl.idle.find(c);
+    if (it != pl.idle.end()) {
+      *out = it->second;
+      pl.idle.erase(it);
+      pl.idle_bytes -= c;
+      pl.live[*out] = c;
+      return CM_OK;
+    }
+  }
+  hipError_t e = hipMalloc(out, c);
+  if (e != hipSuccess) {                              // out of memory with idle slabs around: give them back and try once more
+    (void)hipGetLastError();
+    cm_pool_trim(ctx, 0);
+    e = hipMalloc(out, c);
+  }
+  if (e != hipSuccess) { *out = nullptr; cm_set_error("out of device memory (%zu bytes): %s", c, hipGetErrorString(e)); return CM_ERR_HIP; }
+  std::lock_guard<std::mutex> lk(pl.m);
+  pl.live[*out] = c;
+  return CM_OK;
+}
+void cm_pool_free(cm_ctx* ctx, void* ptr) {
+  if (!ptr) return;
+  cm_pool& pl = ctx->root->mem;
+  size_t c = 0;
+  {
+    std::lock_guard<std::mutex> lk(pl.m);
+    auto it = pl.live.find(ptr);
+    if (it == pl.live.end()) { hipFree(ptr); return; }      // not from the pool
+    c = it->second;
+    pl.live.erase(it);
+    if (pl.idle_bytes + c <= pl.cap_bytes) { pl.idle.emplace(c, ptr); pl.idle_bytes += c; return; }
+  }
+  hipFree(ptr);
+}
+void cm_pool_trim(cm_ctx* ctx, size_t keep_bytes) {
+  cm_pool& pl = ctx->root->mem;
+  std::vector<void*> drop;
+  {
+    std::lock_guard<std::mutex> lk(pl.m);
+    while (pl.idle_bytes > keep_bytes && !pl.idle.empty()) {
+      auto it = std::prev(pl.idle.end());            // largest first
+      drop.push_back(it->second);
+      pl.idle_bytes -= it->first;
+      pl.idle.erase(it);
+    }
+  }
+  for (void* q : drop) hipFree(q);
+}
+template <typename T>
+static int pmalloc(cm_ctx* ctx, T** p, size_t n) { return cm_pool_alloc(ctx, (void**)p, (n ? n : 1) * sizeof(T)); }
+extern "C" int cm_ctx_release_cache(cm_ctx* c) {
+  if (!c) { cm_set_error("cm_ctx_release_cache: NULL context"); return CM_ERR_INVALID; }
+  CM_HIP(hipSetDevice(c->device));
+  cm_pool_trim(c, 0);
+  return CM_OK;
+}
+
 static void free_hist(cm_problem* p) {
   double** h[] = {&p->h_mu, &p->h_beta, &p->h_lam, &p->h_shape, &p->h_rate, &p->h_phi, &p->h_phi_cov, &p->h_z};
   for (auto q : h) { if (*q) hipFree(*q); *q = nullptr; }
@@ -216,7 +289,7 @@ extern "C" int cm_problem_destroy(cm_problem* p) {
   hipStreamSynchronize(p->ctx->stream);
   // the two slabs hold every static / state buffer; the random tables of a run (sized by iters, S) are allocated by the run
   void* ptrs[] = {p->slabA, p->slabB, p->orders_all, p->orders_tmp, p->inv_all, p->wtab, p->keys, p->uexp};
-  for (void* q : ptrs) if (q) hipFree(q);
+  for (void* q : ptrs) cm_pool_free(p->ctx, q);                      // (the stream is idle: nothing queued still reads them)
   free_hist(p);
   delete p;
   return CM_OK;
@@ -235,7 +308,7 @@ static void carve_a(cm_problem* p, cm_carver& c) {           // sizes known from
   c.take(&p->rs, 4 * N); c.take(&p->act_idx, N); c.take(&p->act_inv, N); c.take(&p->n_act, 4); c.take(&p->alive, N + 1);
   c.take(&p->A, ld * (ld + CM_LD_PAD)); c.take(&p->X, ld * (ld + CM_LD_PAD)); c.take(&p->Lf, ld * (ld + CM_LD_PAD)); c.take(&p->Dinv, ld * CM_TILE);
   c.take(&p->rhs, 2 * ld); c.take(&p->seq_n, N); c.take(&p->seq_off, N + 1); c.take(&p->seq_pos, N); c.take(&p->seq_meta, 8);
-  c.take(&p->enc_table, CM_MAX_VALS); c.take(&p->enc_flags, 8); c.take(&p->enc_row_nnz, N); c.take(&p->enc_col_cnt, K);
+  c.take(&p->enc_table, CM_MAX_VALS); c.take(&p->enc_flags, 8); c.take(&p->enc_row_nnz, N); c.take(&p->enc_col_cnt, K); c.take(&p->enc_cursor, K);
 }
 static void carve_b(cm_problem* p, cm_carver& c) {           // sizes that need nnz
   const size_t N = p->N, K = p->K, nnz = p->nnz > 0 ? (size_t)p->nnz : 1;
@@ -245,59 +318,127 @@ static void carve_b(cm_problem* p, cm_carver& c) {           // sizes that need 
   char* pk = nullptr; c.take(&pk, (N + nnz) * 32); if (c.base) p->packed = pk;
 }
 
+static int stage_reserve(cm_ctx* ctx, size_t bytes);
+// A group of circuits at once: every kernel of the encoding is launched once for the group (cm_encode_stage1 / 2), the host waits twice per
+// group (sizes of the nnz-dependent slabs; completion) instead of twice per circuit, and the memory comes from the context's pool.  Host
+// inputs are staged through pooled device buffers, at most CM_CREATE_CHUNK circuits at a time (30 MB per circuit at the headline shape).
+#define CM_CREATE_CHUNK 64
+static int create_chunk(cm_ctx* ctx, int n, const int32_t* N, const int32_t* K, const int32_t* T, const double* const* psc, const double* const* stim,
+                        int mem_kind, cm_problem** out) {
+  hipStream_t st = ctx->stream;
+  std::vector<cm_problem*> ps(n, nullptr);
+  std::vector<void*> tmp;                                             // staged host inputs + descriptor / report buffers (pool)
+  int rc = CM_OK;
+  auto cleanup = [&](int code) {
+    hipStreamSynchronize(st);
+    for (void* q : tmp) cm_pool_free(ctx, q);
+    if (code != CM_OK) for (cm_problem* p : ps) if (p) cm_problem_destroy(p);
+    return code;
+  };
+  std::vector<cm_enc> enc(n);
+  int N_max = 0, K_max = 0;
+  for (int c = 0; c < n; ++c) {
+    cm_problem* p = ps[c] = new cm_problem();
+    p->ctx = ctx; p->N = N[c]; p->K = K[c]; p->T = T[c];
+    p->ld = ((N[c] + CM_TILE - 1) / CM_TILE) * CM_TILE;
+    cm_carver sz;
+    carve_a(p, sz);
+    if (cm_pool_alloc(ctx, &p->slabA, sz.off) != CM_OK) return cleanup(CM_ERR_HIP);
+    cm_carver cv; cv.base = (char*)p->slabA;
+    carve_a(p, cv);
+    const double *d_psc = psc[c], *d_stim = stim[c];
+    if (mem_kind == CM_MEM_HOST) {
+      void *a = nullptr, *b = nullptr;
+      const size_t nb_psc = (size_t)K[c] * T[c] * sizeof(double), nb_stim = (size_t)N[c] * K[c] * sizeof(double);
+      if (cm_pool_alloc(ctx, &a, nb_psc) != CM_OK) return cleanup(CM_ERR_HIP);
+      tmp.push_back(a);
+      if (cm_pool_alloc(ctx, &b, nb_stim) != CM_OK) return cleanup(CM_ERR_HIP);
+      tmp.push_back(b);
+      if (hipMemcpyAsync(a, psc[c], nb_psc, hipMemcpyHostToDevice, st) != hipSuccess || hipMemcpyAsync(b, stim[c], nb_stim, hipMemcpyHostToDevice, st) != hipSuccess) {
+        cm_set_error("upload of psc/stim failed");
+        return cleanup(CM_ERR_HIP);
+      }
+      d_psc = (const double*)a; d_stim = (const double*)b;
+    }
+    cm_enc& e = enc[c];
+    memset(&e, 0, sizeof(e));
+    e.psc = d_psc; e.stim = d_stim; e.N = N[c]; e.K = K[c]; e.T = T[c];
+    e.y = p->y; e.ss = p->ss; e.vals = p->vals; e.mcE = p->mcE; e.table = p->enc_table; e.flags = p->enc_flags; e.rowcnt = p->rowcnt;
+    e.row_nnz = p->enc_row_nnz; e.row_ptr = p->row_ptr; e.col_cnt = p->enc_col_cnt; e.cursor = p->enc_cursor; e.col_ptr = p->col_ptr; e.alive = p->alive;
+    N_max = std::max(N_max, (int)N[c]); K_max = std::max(K_max, (int)K[c]);
+  }
+  // descriptors and the report live in pooled device memory; their host side in the context's pinned staging buffer
+  const size_t enc_bytes = (size_t)n * sizeof(cm_enc), rep_bytes = (size_t)n * 8 * sizeof(int);
+  void *d_enc = nullptr, *d_rep = nullptr;
+  if (cm_pool_alloc(ctx, &d_enc, enc_bytes) != CM_OK) return cleanup(CM_ERR_HIP);
+  tmp.push_back(d_enc);
+  if (cm_pool_alloc(ctx, &d_rep, rep_bytes) != CM_OK) return cleanup(CM_ERR_HIP);
+  tmp.push_back(d_rep);
+  if ((rc = stage_reserve(ctx, enc_bytes + rep_bytes)) != CM_OK) return cleanup(rc);
+  cm_enc* h_enc = (cm_enc*)ctx->h_stage;
+  int* h_rep = (int*)((char*)ctx->h_stage + enc_bytes);
+  memcpy(h_enc, enc.data(), enc_bytes);
+  if (hipMemcpyAsync(d_enc, h_enc, enc_bytes, hipMemcpyHostToDevice, st) != hipSuccess) return cleanup(CM_ERR_HIP);
+  if ((rc = cm_encode_stage1(ctx, (const cm_enc*)d_enc, n, N_max, K_max, (int*)d_rep)) != CM_OK) return cleanup(rc);
+  if (hipMemcpyAsync(h_rep, d_rep, rep_bytes, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+    cm_set_error("encoding (stage 1) failed: %s", hipGetErrorString(hipGetLastError()));
+    return cleanup(CM_ERR_HIP);
+  }
+  long long nnz_max = 0;
+  for (int c = 0; c < n; ++c) {                                       // (too many values?, V, longest row, -, nnz)
+    cm_problem* p = ps[c];
+    const int* h = h_rep + 8 * c;
+    if (h[0]) { cm_set_error("stimulus matrix has more than %d distinct values", CM_MAX_VALS); return cleanup(CM_ERR_TOO_MANY_POWERS); }
+    p->V = h[1]; p->max_row_len = h[2]; p->nnz = h[4];
+    p->small_cap = cm_small_cap(p);
+    nnz_max = std::max<long long>(nnz_max, p->nnz);
+    cm_carver sz;
+    carve_b(p, sz);
+    if (cm_pool_alloc(ctx, &p->slabB, sz.off) != CM_OK) return cleanup(CM_ERR_HIP);
+    cm_carver cv; cv.base = (char*)p->slabB;
+    carve_b(p, cv);
+    cm_enc& e = h_enc[c];                                             // (the copy of stage 1 has completed: the staging buffer is free again)
+    e.nnz = p->nnz; e.col = p->col; e.grp = p->grp; e.csc_row = p->csc_row; e.csc_pos = p->csc_pos; e.csc_grp = p->csc_grp;
+    const size_t Nz = p->N;
+    p->mu = p->slab; p->beta = p->slab + Nz; p->z = p->slab + 2 * Nz; p->lam = p->slab + 2 * Nz + p->K;
+    p->mu_prior = p->pslab; p->beta_prior = p->pslab + Nz; p->phi_prior = p->pslab + 2 * Nz;
+    p->phi_cov_prior = p->pslab + 4 * Nz; p->scal = p->pslab + 8 * Nz;
+  }
+  if (hipMemcpyAsync(d_enc, h_enc, enc_bytes, hipMemcpyHostToDevice, st) != hipSuccess) return cleanup(CM_ERR_HIP);
+  if ((rc = cm_encode_stage2(ctx, (const cm_enc*)d_enc, n, N_max, K_max, nnz_max, (int*)d_rep)) != CM_OK) return cleanup(rc);
+  if (hipMemcpyAsync(h_rep, d_rep, rep_bytes, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+    cm_set_error("encoding (stage 2) failed: %s", hipGetErrorString(hipGetLastError()));
+    return cleanup(CM_ERR_HIP);
+  }
+  for (int c = 0; c < n; ++c) { ps[c]->max_col_len = h_rep[8 * c + 3]; out[c] = ps[c]; }
+  return cleanup(CM_OK);
+}
+
+extern "C" int cm_problem_create_batch(cm_ctx* ctx, int32_t n, const int32_t* N, const int32_t* K, const int32_t* T, const double* const* psc,
+                                       const double* const* stim, int mem_kind, cm_problem** out) {
+  if (!ctx || !N || !K || !T || !psc || !stim || !out || n < 1) { cm_set_error("cm_problem_create_batch: NULL argument or n < 1"); return CM_ERR_INVALID; }
+  for (int c = 0; c < n; ++c) {
+    out[c] = nullptr;
+    if (!psc[c] || !stim[c]) { cm_set_error("cm_problem_create_batch: NULL psc / stim (circuit %d)", c); return CM_ERR_INVALID; }
+    if (N[c] < 2 || K[c] < 1 || T[c] < 1) { cm_set_error("cm_problem_create_batch: need N >= 2, K >= 1, T >= 1 (circuit %d: %d, %d, %d)", c, N[c], K[c], T[c]); return CM_ERR_INVALID; }
+  }
+  CM_HIP(hipSetDevice(ctx->device));
+  for (int c0 = 0; c0 < n; c0 += CM_CREATE_CHUNK) {
+    const int m = std::min(CM_CREATE_CHUNK, n - c0);
+    const int rc = create_chunk(ctx, m, N + c0, K + c0, T + c0, psc + c0, stim + c0, mem_kind, out + c0);
+    if (rc != CM_OK) {
+      for (int c = 0; c < c0; ++c) { cm_problem_destroy(out[c]); out[c] = nullptr; }
+      return rc;
+    }
+  }
+  return CM_OK;
+}
+
 extern "C" int cm_problem_create(cm_ctx* ctx, int32_t N, int32_t K, int32_t T, const double* psc, const double* stim, int mem_kind,
                                  cm_problem** out) {
   if (!ctx || !psc || !stim || !out) { cm_set_error("cm_problem_create: NULL argument"); return CM_ERR_INVALID; }
   if (N < 2 || K < 1 || T < 1) { cm_set_error("cm_problem_create: need N >= 2, K >= 1, T >= 1 (got %d, %d, %d)", N, K, T); return CM_ERR_INVALID; }
-  CM_HIP(hipSetDevice(ctx->device));
-  hipStream_t st = ctx->stream;
-  cm_problem* p = new cm_problem();
-  p->ctx = ctx; p->N = N; p->K = K; p->T = T;
-  p->ld = ((N + CM_TILE - 1) / CM_TILE) * CM_TILE;
-  int rc = CM_OK;
-  double *d_psc = nullptr, *d_stim = nullptr;
-  auto fail = [&](int code) { if (mem_kind == CM_MEM_HOST) { if (d_psc) hipFree(d_psc); if (d_stim) hipFree(d_stim); } cm_problem_destroy(p); return code; };
-  // Two allocations per circuit instead of ~50 (each hipMalloc is tens of microseconds of driver time; creating the 128 circuits of a
-  // batch was 0.2 s in front of a 35 ms fit): slab A holds everything N and K size, slab B what needs nnz.
-  {
-    cm_carver sz;
-    carve_a(p, sz);
-    if (hipMalloc(&p->slabA, sz.off) != hipSuccess) { cm_set_error("cm_problem_create: out of device memory (%zu bytes)", sz.off); return fail(CM_ERR_HIP); }
-    cm_carver c; c.base = (char*)p->slabA;
-    carve_a(p, c);
-  }
-  if (mem_kind == CM_MEM_HOST) {
-    if ((rc = dmalloc(&d_psc, (size_t)K * T)) || (rc = dmalloc(&d_stim, (size_t)N * K))) return fail(rc);
-    if (hipMemcpyAsync(d_psc, psc, (size_t)K * T * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipMemcpyAsync(d_stim, stim, (size_t)N * K * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) {
-      cm_set_error("upload of psc/stim failed");
-      return fail(CM_ERR_HIP);
-    }
-  } else {
-    d_psc = const_cast<double*>(psc);
-    d_stim = const_cast<double*>(stim);
-  }
-  if ((rc = cm_launch_psc_prologue(ctx, K, T, d_psc, p->y, p->ss))) return fail(rc);
-  if ((rc = cm_encode_stim_stage1(ctx, p, d_stim))) return fail(rc);          // (the one host wait in the middle: nnz)
-  {
-    cm_carver sz;
-    carve_b(p, sz);
-    if (hipMalloc(&p->slabB, sz.off) != hipSuccess) { cm_set_error("cm_problem_create: out of device memory (%zu bytes)", sz.off); return fail(CM_ERR_HIP); }
-    cm_carver c; c.base = (char*)p->slabB;
-    carve_b(p, c);
-  }
-  if ((rc = cm_encode_stim_stage2(ctx, p, d_stim))) return fail(rc);
-  const size_t Nz = N;
-  p->mu = p->slab; p->beta = p->slab + Nz; p->z = p->slab + 2 * Nz; p->lam = p->slab + 2 * Nz + K;
-  p->mu_prior = p->pslab; p->beta_prior = p->pslab + Nz; p->phi_prior = p->pslab + 2 * Nz;
-  p->phi_cov_prior = p->pslab + 4 * Nz; p->scal = p->pslab + 8 * Nz;
-  if (hipMemsetAsync(p->mcE, 0, Nz * CM_MAX_VALS * sizeof(double), st) != hipSuccess ||
-      hipMemsetAsync(p->alive, 0, (Nz + 1) * sizeof(int), st) != hipSuccess) return fail(CM_ERR_HIP);
-  if (hipStreamSynchronize(st) != hipSuccess) { cm_set_error("prologue failed: %s", hipGetErrorString(hipGetLastError())); return fail(CM_ERR_HIP); }
-  p->max_col_len = ctx->h_pinned[8 + 3];
-  if (mem_kind == CM_MEM_HOST) { hipFree(d_psc); hipFree(d_stim); d_psc = d_stim = nullptr; }
-  *out = p;
-  return CM_OK;
+  return cm_problem_create_batch(ctx, 1, &N, &K, &T, &psc, &stim, mem_kind, out);
 }
 
 extern "C" int cm_problem_nnz(const cm_problem* p, int64_t* nnz, int32_t* n_vals) {
@@ -579,6 +720,7 @@ extern "C" int cm_caviar_run_batch(cm_ctx* ctx, int32_t n, cm_problem* const* pr
       CM_TRY(cm_ctx_create(ctx->device, nullptr, &ctx->twin));
       ctx->twin->solve_group = ctx->solve_group; ctx->twin->xcd_mode = ctx->xcd_mode; ctx->twin->chol_family = ctx->chol_family;
       ctx->twin->use_mailbox = ctx->use_mailbox;
+      ctx->twin->root = ctx;                                         // one pool per user-visible context
     }
     if (!ctx->helper) ctx->helper = new cm_helper();
     cm_ctx* tw = ctx->twin;
@@ -642,25 +784,25 @@ static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_option
   // RNG streams: sweep orders of all iterations live in orders_all (uploaded, or generated below in one batched launch).  They are
   // data independent: the circuits of a batch share the leader's tables (same seed, N, S).
   if (p->orders_cap < iters) {
-    if (p->orders_all) hipFree(p->orders_all);
-    if (p->orders_tmp) hipFree(p->orders_tmp);
-    if (p->inv_all) hipFree(p->inv_all);
+    cm_pool_free(ctx, p->orders_all);                 // (tables of an earlier, completed run)
+    cm_pool_free(ctx, p->orders_tmp);
+    cm_pool_free(ctx, p->inv_all);
     p->orders_all = p->orders_tmp = p->inv_all = nullptr;
     p->orders_cap = 0;
-    CM_TRY(dmalloc(&p->orders_all, (size_t)iters * N));
-    CM_TRY(dmalloc(&p->orders_tmp, (size_t)iters * N));
-    CM_TRY(dmalloc(&p->inv_all, (size_t)iters * N));
+    CM_TRY(pmalloc(ctx, &p->orders_all, (size_t)iters * N));
+    CM_TRY(pmalloc(ctx, &p->orders_tmp, (size_t)iters * N));
+    CM_TRY(pmalloc(ctx, &p->inv_all, (size_t)iters * N));
     p->orders_cap = iters;
   }
   if (p->wtab_cap < (size_t)iters * N * S * 4) {           // (ndtri(u), u) for each of the iters x N x S x 2 uniforms
-    if (p->wtab) hipFree(p->wtab);
+    cm_pool_free(ctx, p->wtab);
     p->wtab = nullptr; p->wtab_cap = 0;
-    CM_TRY(dmalloc(&p->wtab, (size_t)iters * N * S * 4));
+    CM_TRY(pmalloc(ctx, &p->wtab, (size_t)iters * N * S * 4));
     p->wtab_cap = (size_t)iters * N * S * 4;
   }
   if (o->rng_mode == CM_RNG_EXPLICIT) {
-    if (p->uexp) { hipFree(p->uexp); p->uexp = nullptr; }
-    CM_TRY(dmalloc(&p->uexp, (size_t)iters * N * S * 2));
+    cm_pool_free(ctx, p->uexp); p->uexp = nullptr;
+    CM_TRY(pmalloc(ctx, &p->uexp, (size_t)iters * N * S * 2));
     CM_HIP(hipMemcpyAsync(p->uexp, o->uniforms, (size_t)iters * N * S * 2 * sizeof(double), hipMemcpyHostToDevice, st));
     CM_HIP(hipMemcpyAsync(p->orders_all, o->update_orders, (size_t)iters * N * sizeof(int32_t), hipMemcpyHostToDevice, st));
   }
@@ -672,9 +814,9 @@ static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_option
   if (o->rng_mode == CM_RNG_THREEFRY && iters > 0) {
     keys.assign(key_per * iters, 0u);
     if (p->keys_iters < iters) {
-      if (p->keys) hipFree(p->keys);
+      cm_pool_free(ctx, p->keys);
       p->keys = nullptr; p->keys_iters = 0;
-      CM_TRY(dmalloc(&p->keys, keys.size()));
+      CM_TRY(pmalloc(ctx, &p->keys, keys.size()));
       p->keys_iters = iters;
     }
   }
@@ -955,6 +1097,84 @@ extern "C" int cm_caviar_fetch(cm_ctx* ctx, cm_problem* p, cm_result* r) {
   return CM_OK;
 }
 
+// Results of a group of circuits with ONE device-to-host copy: a kernel packs mu, beta, phi, phi_cov, z, shape, rate of every circuit
+// into one buffer (per-circuit fetches are six small copies and a wait each: 0.1 ms per circuit, half the time of fitting it in a batch).
+// Circuits whose result asks for lam or histories go through cm_caviar_fetch.
+struct cm_fetch_desc { const double *mu, *beta, *phi, *phi_cov, *z, *scal; int N, K; long long off; };
+__global__ __launch_bounds__(256) void k_pack_results(const cm_fetch_desc* __restrict__ arr, double* __restrict__ out) {
+  const cm_fetch_desc& d = arr[blockIdx.y];
+  const long long N = d.N, K = d.K, L = 8 * N + K + 2;
+  double* o = out + d.off;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (long long)gridDim.x * blockDim.x) {
+    double v;
+    if (i < N) v = d.mu[i];
+    else if (i < 2 * N) v = d.beta[i - N];
+    else if (i < 4 * N) v = d.phi[i - 2 * N];
+    else if (i < 8 * N) v = d.phi_cov[i - 4 * N];
+    else if (i < 8 * N + K) v = d.z[i - 8 * N];
+    else v = d.scal[i - 8 * N - K == 0 ? CM_S_SHAPE : CM_S_RATE];
+    o[i] = v;
+  }
+}
+extern "C" int cm_caviar_fetch_batch(cm_ctx* ctx, int32_t n, cm_problem* const* problems, cm_result* results) {
+  if (!ctx || !problems || !results || n < 1) { cm_set_error("cm_caviar_fetch_batch: NULL argument or n < 1"); return CM_ERR_INVALID; }
+  CM_HIP(hipSetDevice(ctx->device));
+  std::vector<int> packed;
+  std::vector<cm_fetch_desc> desc;
+  long long total = 0, L_max = 0;
+  for (int c = 0; c < n; ++c) {
+    cm_problem* p = problems[c];
+    cm_result& r = results[c];
+    if (!p) { cm_set_error("cm_caviar_fetch_batch: problem %d is NULL", c); return CM_ERR_INVALID; }
+    if (!p->ran) { cm_set_error("cm_caviar_fetch_batch: no completed run on problem %d", c); return CM_ERR_STATE; }
+    const bool hist = p->hist_iters > 0 && (r.mu_hist || r.beta_hist || r.lam_hist || r.shape_hist || r.rate_hist || r.phi_hist || r.phi_cov_hist || r.z_hist);
+    if (r.lam || hist) continue;                                      // below, one by one
+    const long long L = 8ll * p->N + p->K + 2;
+    desc.push_back({p->mu, p->beta, p->phi, p->phi_cov, p->z, p->scal, p->N, p->K, total});
+    packed.push_back(c);
+    total += L; L_max = std::max(L_max, L);
+  }
+  if (!packed.empty()) {
+    hipStream_t st = ctx->stream;
+    const size_t dbytes = desc.size() * sizeof(cm_fetch_desc), obytes = (size_t)total * sizeof(double);
+    void *d_desc = nullptr, *d_out = nullptr;
+    CM_TRY(cm_pool_alloc(ctx, &d_desc, dbytes));
+    if (cm_pool_alloc(ctx, &d_out, obytes) != CM_OK) { cm_pool_free(ctx, d_desc); return CM_ERR_HIP; }
+    auto done = [&](int code) { hipStreamSynchronize(st); cm_pool_free(ctx, d_desc); cm_pool_free(ctx, d_out); return code; };
+    int rc = stage_reserve(ctx, dbytes + obytes);
+    if (rc != CM_OK) return done(rc);
+    char* h = (char*)ctx->h_stage;
+    memcpy(h, desc.data(), dbytes);
+    if (hipMemcpyAsync(d_desc, h, dbytes, hipMemcpyHostToDevice, st) != hipSuccess) return done(CM_ERR_HIP);
+    hipLaunchKernelGGL(k_pack_results, dim3((unsigned)std::min<long long>((L_max + 255) / 256, 64), (unsigned)desc.size()), dim3(256), 0, st,
+                       (const cm_fetch_desc*)d_desc, (double*)d_out);
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(h + dbytes, d_out, obytes, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+      cm_set_error("cm_caviar_fetch_batch: %s", hipGetErrorString(hipGetLastError()));
+      return done(CM_ERR_HIP);
+    }
+    const double* ho = (const double*)(h + dbytes);
+    for (size_t i = 0; i < packed.size(); ++i) {
+      cm_result& r = results[packed[i]];
+      const cm_fetch_desc& d = desc[i];
+      const size_t N = d.N, K = d.K;
+      const double* o = ho + d.off;
+      if (r.mu) memcpy(r.mu, o, N * 8);
+      if (r.beta) memcpy(r.beta, o + N, N * 8);
+      if (r.phi) memcpy(r.phi, o + 2 * N, 2 * N * 8);
+      if (r.phi_cov) memcpy(r.phi_cov, o + 4 * N, 4 * N * 8);
+      if (r.z) memcpy(r.z, o + 8 * N, K * 8);
+      r.shape = o[8 * N + K]; r.rate = o[8 * N + K + 1];
+    }
+    done(CM_OK);
+  }
+  size_t pi = 0;
+  for (int c = 0; c < n; ++c) {
+    if (pi < packed.size() && packed[pi] == c) { ++pi; continue; }
+    CM_TRY(cm_caviar_fetch(ctx, problems[c], &results[c]));
+  }
+  return CM_OK;
+}
+
 extern "C" int cm_caviar_fit(cm_ctx* ctx, int32_t N, int32_t K, int32_t T, const double* psc, const double* stim, const cm_priors* pr,
                              const cm_options* o, cm_result* r, cm_timings* tm) {
   cm_problem* p = nullptr;
@@ -983,18 +1203,24 @@ extern "C" int cm_caviar_fit_batch(int32_t n, const int32_t* N, const int32_t* K
     cm_ctx* ctx = nullptr;
     int rc = cm_ctx_create(device_ids[d], nullptr, &ctx);
     if (rc) return fail(rc);
-    std::vector<cm_problem*> ps;
+    std::vector<cm_problem*> ps(mine.size(), nullptr);
     std::vector<cm_priors> prs;
-    for (int c : mine) {
-      cm_problem* q = nullptr;
-      if ((rc = cm_problem_create(ctx, N[c], K[c], T[c], psc[c], stim[c], CM_MEM_HOST, &q))) break;
-      ps.push_back(q);
+    std::vector<int32_t> n_(mine.size()), k_(mine.size()), t_(mine.size());
+    std::vector<const double*> psc_(mine.size()), stim_(mine.size());
+    std::vector<cm_result> res_(mine.size());
+    for (size_t i = 0; i < mine.size(); ++i) {
+      const int c = mine[i];
+      n_[i] = N[c]; k_[i] = K[c]; t_[i] = T[c]; psc_[i] = psc[c]; stim_[i] = stim[c];
       prs.push_back(priors[c]);
+      res_[i] = results[c];
     }
+    if (!mine.empty()) rc = cm_problem_create_batch(ctx, (int)mine.size(), n_.data(), k_.data(), t_.data(), psc_.data(), stim_.data(), CM_MEM_HOST, ps.data());
+    if (rc) ps.clear();
     std::vector<cm_timings> tms(mine.size());
-    if (!rc) rc = cm_caviar_run_batch(ctx, (int)ps.size(), ps.data(), prs.data(), o, timings ? tms.data() : nullptr);
+    if (!rc && !ps.empty()) rc = cm_caviar_run_batch(ctx, (int)ps.size(), ps.data(), prs.data(), o, timings ? tms.data() : nullptr);
+    if (!rc && !ps.empty()) rc = cm_caviar_fetch_batch(ctx, (int)ps.size(), ps.data(), res_.data());
     for (size_t i = 0; !rc && i < mine.size(); ++i) {
-      rc = cm_caviar_fetch(ctx, ps[i], &results[mine[i]]);
+      results[mine[i]].shape = res_[i].shape; results[mine[i]].rate = res_[i].rate;
       if (timings) timings[mine[i]] = tms[i];
     }
     if (rc) fail(rc);

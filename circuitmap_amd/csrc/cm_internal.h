@@ -6,7 +6,9 @@
 #include <functional>
 #include <mutex>
 #include <string>
+#include <map>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/caviar_hip.h"
@@ -40,6 +42,20 @@ void cm_set_error(const char* fmt, ...);
     int _s = (expr);              \
     if (_s != CM_OK) return _s;   \
   } while (0)
+
+// Device-memory pool of a context: the slabs of destroyed problems and the random tables of their runs are kept for the next problem of
+// that size class instead of going back to the driver -- hipMalloc / hipFree are 50-200 us of driver time each (hipFree also waits for the
+// device), four to six of them per circuit, which made creating and destroying the 256 circuits of a batch cost as much as fitting them.
+// Only the MEMORY is reused, never contents.  Size classes are 12.5 % apart; idle bytes are capped (CAVIAR_HIP_POOL_GB, default 64).
+struct cm_pool {
+  std::mutex m;
+  std::unordered_map<void*, size_t> live;          // handed out: pointer -> class size
+  std::multimap<size_t, void*> idle;               // class size -> pointer
+  size_t idle_bytes = 0, cap_bytes = (size_t)64 << 30;
+};
+int cm_pool_alloc(cm_ctx* ctx, void** out, size_t bytes);
+void cm_pool_free(cm_ctx* ctx, void* ptr);        // (the caller has made sure no queued work still uses it)
+void cm_pool_trim(cm_ctx* ctx, size_t keep_bytes);
 
 // a host thread that runs one task at a time (cm_ctx::helper)
 struct cm_helper {
@@ -96,6 +112,8 @@ struct cm_ctx {
   // would pay HIP's per-thread initialisation every time)
   cm_ctx* twin = nullptr;
   cm_helper* helper = nullptr;
+  cm_ctx* root = nullptr;         // the context whose pool this one allocates from (itself; a twin: its parent)
+  cm_pool mem;
 };
 
 // One circuit: encoded stimulus + observations + CAVIaR state.  All pointers are device memory.
@@ -124,7 +142,7 @@ struct cm_problem {
   // host mirror of the CSR (for reconnect_spont_cells and dense expansion)
   bool have_mirror = false;       // the vectors below are filled (cm_host_mirror)
   void *slabA = nullptr, *slabB = nullptr;   // the two allocations behind every static / state pointer below (sizes from N, K; from nnz)
-  unsigned long long* enc_table = nullptr; int32_t *enc_flags = nullptr, *enc_row_nnz = nullptr, *enc_col_cnt = nullptr;   // scratch of the encoding (slab A)
+  unsigned long long* enc_table = nullptr; int32_t *enc_flags = nullptr, *enc_row_nnz = nullptr, *enc_col_cnt = nullptr, *enc_cursor = nullptr;   // scratch of the encoding (slab A)
   std::vector<int32_t> h_row_ptr, h_col, h_col_ptr, h_csc_row;
   std::vector<uint8_t> h_grp;
   std::vector<double> h_vals;
@@ -434,8 +452,18 @@ inline int cm_raise_lds(cm_ctx* ctx, int slot, const void* fn, size_t bytes, siz
 // phase launchers (each enqueues kernels on ctx->stream; no host sync unless stated)
 // ------------------------------------------------------------------------------------------------
 int cm_launch_psc_prologue(cm_ctx* ctx, int K, int T, const double* d_psc, double* d_y, double* d_ss);
-int cm_encode_stim_stage1(cm_ctx* ctx, cm_problem* p, const double* d_stim);        // syncs once: V, nnz, longest row
-int cm_encode_stim_stage2(cm_ctx* ctx, cm_problem* p, const double* d_stim);        // enqueues the nnz-sized part (no wait)
+// one circuit of a group being encoded (cm_problem_create_batch): inputs, and where the pieces of its two slabs are
+struct cm_enc {
+  const double *psc, *stim;
+  int N, K, T;
+  long long nnz;                                   // filled by the host between the stages
+  double *y, *ss, *vals, *mcE;
+  unsigned long long* table;
+  int *flags, *rowcnt, *row_nnz, *row_ptr, *col_cnt, *cursor, *col_ptr, *col, *csc_row, *csc_pos, *alive;
+  uint8_t *grp, *csc_grp;
+};
+int cm_encode_stage1(cm_ctx* ctx, const cm_enc* d_arr, int n, int N_max, int K_max, int* d_report);                       // enqueues; the caller copies the report and waits
+int cm_encode_stage2(cm_ctx* ctx, const cm_enc* d_arr, int n, int N_max, int K_max, long long nnz_max, int* d_report);    // enqueues the nnz-sized part
 int cm_host_mirror(cm_ctx* ctx, cm_problem* p);                                      // host copy of the compressed rows, on first use
 int cm_launch_entry_copies(cm_ctx* ctx, cm_set& s);                                  // ye / me from the current y / mask (after a test hook uploaded either)
 int cm_launch_init_state(cm_ctx* ctx, cm_set& s, double y_xcorr_thresh);             // state from the uploaded priors, lam0, mask, z, counters

@@ -9,7 +9,7 @@
 // One wavefront per trial row; lanes stride the row so every wave-load is 512 contiguous bytes.
 // HBM-bound: reads K*T*8 bytes once.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_psc_prologue(const double* __restrict__ psc, int K, int T,
+__device__ __forceinline__ void psc_prologue_body(const double* __restrict__ psc, int K, int T,
                                                        double* __restrict__ y, double* __restrict__ ss) {
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE;
   const int lane = threadIdx.x % CM_WAVE;
@@ -40,6 +40,9 @@ __device__ __forceinline__ void sum_y_body(const double* __restrict__ y, int K, 
   }
 }
 
+__global__ __launch_bounds__(256) void k_psc_prologue(const double* __restrict__ psc, int K, int T, double* __restrict__ y, double* __restrict__ ss) {
+  psc_prologue_body(psc, K, T, y, ss);
+}
 int cm_launch_psc_prologue(cm_ctx* ctx, int K, int T, const double* d_psc, double* d_y, double* d_ss) {
   const int waves_per_block = 256 / CM_WAVE;
   const int blocks = (K + waves_per_block - 1) / waves_per_block;
@@ -68,7 +71,7 @@ __device__ __forceinline__ bool cm_set_insert(unsigned long long* table, int cap
   return false;
 }
 
-__global__ __launch_bounds__(256) void k_stim_distinct(const double* __restrict__ stim, size_t n,
+__device__ __forceinline__ void stim_distinct_body(const double* __restrict__ stim, size_t n,
                                                         unsigned long long* __restrict__ table, int* __restrict__ overflow) {
   __shared__ unsigned long long cache[CM_MAX_VALS];
   for (int i = threadIdx.x; i < CM_MAX_VALS; i += blockDim.x) cache[i] = CM_EMPTY;
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(256) void k_stim_distinct(const double* __restrict_
   }
 }
 
-__global__ void k_vals_finalize(const unsigned long long* __restrict__ table, double* __restrict__ vals, int* __restrict__ nvals) {
+__device__ __forceinline__ void vals_finalize_body(const unsigned long long* __restrict__ table, double* __restrict__ vals, int* __restrict__ nvals) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   int n = 0;
   for (int s = 0; s < CM_MAX_VALS; ++s) {
@@ -105,7 +108,7 @@ __device__ __forceinline__ int cm_val_index(const double* vals, int V, double v)
 }
 
 // per-row counts of each distinct value and of targeted (stim > 0) trials; one wave per row
-__global__ __launch_bounds__(256) void k_stim_rowcount(const double* __restrict__ stim, int N, int K, const double* __restrict__ vals_g,
+__device__ __forceinline__ void stim_rowcount_body(const double* __restrict__ stim, int N, int K, const double* __restrict__ vals_g,
                                                         const int* __restrict__ nvals, int* __restrict__ rowcnt, int* __restrict__ row_nnz) {
   __shared__ double vals[CM_MAX_VALS];
   const int V = *nvals;
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(256) void k_stim_rowcount(const double* __restrict_
 }
 
 // exclusive scan of n counts into ptr[0..n]; single workgroup
-__global__ __launch_bounds__(1024) void k_exclusive_scan(const int* __restrict__ cnt, int n, int* __restrict__ ptr) {
+__device__ __forceinline__ void exclusive_scan_body(const int* __restrict__ cnt, int n, int* __restrict__ ptr) {
   __shared__ int part[1024];
   __shared__ int carry;
   if (threadIdx.x == 0) carry = 0;
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(1024) void k_exclusive_scan(const int* __restrict__
 }
 
 // CSR fill, one wave per row, ordered compaction by ballot prefix
-__global__ __launch_bounds__(256) void k_stim_fill_csr(const double* __restrict__ stim, int N, int K, const double* __restrict__ vals_g,
+__device__ __forceinline__ void stim_fill_csr_body(const double* __restrict__ stim, int N, int K, const double* __restrict__ vals_g,
                                                         const int* __restrict__ nvals, const int* __restrict__ row_ptr,
                                                         int* __restrict__ col, uint8_t* __restrict__ grp) {
   __shared__ double vals[CM_MAX_VALS];
@@ -189,12 +192,12 @@ __global__ __launch_bounds__(256) void k_stim_fill_csr(const double* __restrict_
 // CSC from the CSR entries (nnz-sized work; the dense matrix is not read again): count the entries of every trial column,
 // scan, scatter (neuron, CSR position) pairs through per-column cursors, then order each column by neuron so that the
 // summation order downstream is deterministic (the cursor order is not).
-__global__ __launch_bounds__(256) void k_csc_count(const int* __restrict__ row_ptr, const int* __restrict__ col, int N, int* __restrict__ col_cnt) {
+__device__ __forceinline__ void csc_count_body(const int* __restrict__ row_ptr, const int* __restrict__ col, int N, int* __restrict__ col_cnt) {
   const int n = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE, lane = threadIdx.x % CM_WAVE;
   if (n >= N) return;
   for (int e = row_ptr[n] + lane; e < row_ptr[n + 1]; e += CM_WAVE) atomicAdd(&col_cnt[col[e]], 1);
 }
-__global__ __launch_bounds__(256) void k_csc_scatter(const int* __restrict__ row_ptr, const int* __restrict__ col, int N,
+__device__ __forceinline__ void csc_scatter_body(const int* __restrict__ row_ptr, const int* __restrict__ col, int N,
                                                       const int* __restrict__ col_ptr, int* __restrict__ cursor,
                                                       int* __restrict__ csc_row, int* __restrict__ csc_pos) {
   const int n = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE, lane = threadIdx.x % CM_WAVE;
@@ -207,11 +210,11 @@ __global__ __launch_bounds__(256) void k_csc_scatter(const int* __restrict__ row
   }
 }
 // power code of every CSC entry (csc_grp[ce] = grp[csc_pos[ce]]): lets a walk over a trial's column read the codes without the dependent gather
-__global__ __launch_bounds__(256) void k_csc_grp(const int* __restrict__ csc_pos, const uint8_t* __restrict__ grp, long long nnz, uint8_t* __restrict__ csc_grp) {
+__device__ __forceinline__ void csc_grp_body(const int* __restrict__ csc_pos, const uint8_t* __restrict__ grp, long long nnz, uint8_t* __restrict__ csc_grp) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < nnz) csc_grp[i] = grp[csc_pos[i]];
 }
-__global__ __launch_bounds__(256) void k_csc_sort(const int* __restrict__ col_ptr, int K, int* __restrict__ csc_row, int* __restrict__ csc_pos) {
+__device__ __forceinline__ void csc_sort_body(const int* __restrict__ col_ptr, int K, int* __restrict__ csc_row, int* __restrict__ csc_pos) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= K) return;
   const int b = col_ptr[k], e = col_ptr[k + 1];
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(256) void k_csc_sort(const int* __restrict__ col_pt
 }
 
 // longest row / column of a CSR / CSC pointer array -> *out (atomicMax; out zeroed by the caller)
-__global__ __launch_bounds__(256) void k_max_len(const int* __restrict__ ptr, int n, int* __restrict__ out) {
+__device__ __forceinline__ void max_len_body(const int* __restrict__ ptr, int n, int* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   int v = i < n ? ptr[i + 1] - ptr[i] : 0;
 #pragma unroll
@@ -232,55 +235,124 @@ __global__ __launch_bounds__(256) void k_max_len(const int* __restrict__ ptr, in
   if (threadIdx.x % CM_WAVE == 0 && v > 0) atomicMax(out, v);
 }
 
-// The encoding in two stages around ONE host wait.  Stage 1 (everything whose size N and K give): distinct values, per-row value counts,
-// row pointers, longest row -> the host reads (too many values?, V, nnz, longest row) from host-mapped memory.  Stage 2 (sized by nnz, in the
-// second slab): CSR entries, CSC, power codes of the CSC entries, longest column -- enqueued, not waited for (cm_problem_create's final
-// synchronisation covers it).  All buffers live in the problem's two slabs: no allocation here.
-int cm_encode_stim_stage1(cm_ctx* ctx, cm_problem* p, const double* d_stim) {
-  const int N = p->N, K = p->K;
+// ------------------------------------------------------------------------------------------------
+// The encoding of a GROUP of circuits in two stages around ONE host wait: every kernel above is launched once for the group (blockIdx.y
+// = circuit, descriptor cm_enc), where one launch sequence per circuit cost ~25 host API calls and two waits each -- creating the 256
+// circuits of a batch took as long as fitting them.  Stage 1 (everything whose size N and K give): PSC integrals, distinct values, per-row
+// value counts, row pointers, longest row -> the host reads (too many values?, V, longest row, nnz) of all circuits with one copy.  Stage 2
+// (sized by nnz, in the second slab): CSR entries, CSC, power codes of the CSC entries, longest column, cleared state.
+// ------------------------------------------------------------------------------------------------
+#define CM_ENC(K) const cm_enc& e = arr[blockIdx.y];
+__global__ __launch_bounds__(256) void k_enc_clear1(const cm_enc* __restrict__ arr) {
+  CM_ENC()
+  const size_t n_rc = (size_t)e.N * CM_MAX_VALS;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rc; i += (size_t)gridDim.x * blockDim.x) e.rowcnt[i] = 0;
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < CM_MAX_VALS) e.table[threadIdx.x] = CM_EMPTY;
+    if (threadIdx.x < 8) e.flags[threadIdx.x] = 0;
+  }
+}
+__global__ __launch_bounds__(256) void kb_psc_prologue(const cm_enc* __restrict__ arr) {
+  CM_ENC()
+  psc_prologue_body(e.psc, e.K, e.T, e.y, e.ss);
+}
+__global__ __launch_bounds__(256) void kb_stim_distinct(const cm_enc* __restrict__ arr) {
+  CM_ENC()
+  stim_distinct_body(e.stim, (size_t)e.N * e.K, e.table, e.flags);
+}
+__global__ void kb_vals_finalize(const cm_enc* __restrict__ arr) {
+  CM_ENC()
+  vals_finalize_body(e.table, e.vals, e.flags + 1);
+}
+__global__ __launch_bounds__(256) void kb_stim_rowcount(const cm_enc* __restrict__ arr) {
+  CM_ENC()
+  stim_rowcount_body(e.stim, e.N, e.K, e.vals, e.flags + 1, e.rowcnt, e.row_nnz);
+}
+__global__ __launch_bounds__(1024) void kb_scan_rows(const cm_enc* __restrict__ arr) {
+  CM_ENC()
+  exclusive_scan_body(e.row_nnz, e.N, e.row_ptr);
+}
+__global__ __launch_bounds__(256) void kb_max_row(const cm_enc* __restrict__ arr) {
+  CM_ENC()
+  max_len_body(e.row_ptr, e.N, e.flags + 2);
+}
+// (too many values, V, longest row, longest column) and nnz of every circuit, side by side for one copy to the host
+__global__ __launch_bounds__(64) void k_enc_report(const cm_enc* __restrict__ arr, int n, int* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  const cm_enc& e = arr[c];
+  for (int j = 0; j < 4; ++j) out[8 * c + j] = e.flags[j];
+  out[8 * c + 4] = e.row_ptr[e.N];
+}
+__global__ __launch_bounds__(256) void k_enc_clear2(const cm_enc* __restrict__ arr) {
+  CM_ENC()
+  const size_t n_mc = (size_t)e.N * CM_MAX_VALS;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_mc; i += (size_t)gridDim.x * blockDim.x) e.mcE[i] = 0.0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)e.N + 1; i += (size_t)gridDim.x * blockDim.x) e.alive[i] = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)e.K; i += (size_t)gridDim.x * blockDim.x) { e.col_cnt[i] = 0; e.cursor[i] = 0; }
+}
+__global__ __launch_bounds__(256) void kb_stim_fill_csr(const cm_enc* __restrict__ arr) {
+  CM_ENC()
+  stim_fill_csr_body(e.stim, e.N, e.K, e.vals, e.flags + 1, e.row_ptr, e.col, e.grp);
+}
+__global__ __launch_bounds__(256) void kb_csc_count(const cm_enc* __restrict__ arr) {
+  CM_ENC()
+  csc_count_body(e.row_ptr, e.col, e.N, e.col_cnt);
+}
+__global__ __launch_bounds__(1024) void kb_scan_cols(const cm_enc* __restrict__ arr) {
+  CM_ENC()
+  exclusive_scan_body(e.col_cnt, e.K, e.col_ptr);
+}
+__global__ __launch_bounds__(256) void kb_csc_scatter(const cm_enc* __restrict__ arr) {
+  CM_ENC()
+  csc_scatter_body(e.row_ptr, e.col, e.N, e.col_ptr, e.cursor, e.csc_row, e.csc_pos);
+}
+__global__ __launch_bounds__(256) void kb_csc_sort(const cm_enc* __restrict__ arr) {
+  CM_ENC()
+  csc_sort_body(e.col_ptr, e.K, e.csc_row, e.csc_pos);
+}
+__global__ __launch_bounds__(256) void kb_csc_grp(const cm_enc* __restrict__ arr) {
+  CM_ENC()
+  csc_grp_body(e.csc_pos, e.grp, e.nnz, e.csc_grp);
+}
+__global__ __launch_bounds__(256) void kb_max_col(const cm_enc* __restrict__ arr) {
+  CM_ENC()
+  max_len_body(e.col_ptr, e.K, e.flags + 3);
+}
+
+int cm_encode_stage1(cm_ctx* ctx, const cm_enc* d_arr, int n, int N_max, int K_max, int* d_report) {
   hipStream_t st = ctx->stream;
-  CM_HIP(hipMemsetAsync(p->enc_table, 0xFF, CM_MAX_VALS * sizeof(unsigned long long), st));
-  CM_HIP(hipMemsetAsync(p->enc_flags, 0, 8 * sizeof(int), st));
-  CM_HIP(hipMemsetAsync(p->rowcnt, 0, (size_t)N * CM_MAX_VALS * sizeof(int), st));
-  const size_t total = (size_t)N * K;
+  const dim3 b256(256);
+  const size_t total = (size_t)N_max * K_max;
   int blocks = (int)((total + 255) / 256);
-  if (blocks > ctx->num_cus * 8) blocks = ctx->num_cus * 8;
-  hipLaunchKernelGGL(k_stim_distinct, dim3(blocks), dim3(256), 0, st, d_stim, total, p->enc_table, p->enc_flags);
-  hipLaunchKernelGGL(k_vals_finalize, dim3(1), dim3(64), 0, st, p->enc_table, p->vals, p->enc_flags + 1);
-  const int row_blocks = (N + 3) / 4;
-  hipLaunchKernelGGL(k_stim_rowcount, dim3(row_blocks), dim3(256), 0, st, d_stim, N, K, p->vals, p->enc_flags + 1, p->rowcnt, p->enc_row_nnz);
-  hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, st, p->enc_row_nnz, N, p->row_ptr);
-  hipLaunchKernelGGL(k_max_len, dim3((N + 255) / 256), dim3(256), 0, st, p->row_ptr, N, p->enc_flags + 2);
+  const int cap = std::max(1, ctx->num_cus * 8 / std::max(1, std::min(n, 8)));      // grid-stride loops: enough workgroups to fill the chip, not one per 256 elements
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(k_enc_clear1, dim3(std::max(1, (N_max * CM_MAX_VALS + 255) / 256), n), b256, 0, st, d_arr);
+  hipLaunchKernelGGL(kb_psc_prologue, dim3((K_max + 3) / 4, n), b256, 0, st, d_arr);
+  hipLaunchKernelGGL(kb_stim_distinct, dim3(blocks, n), b256, 0, st, d_arr);
+  hipLaunchKernelGGL(kb_vals_finalize, dim3(1, n), dim3(64), 0, st, d_arr);
+  hipLaunchKernelGGL(kb_stim_rowcount, dim3((N_max + 3) / 4, n), b256, 0, st, d_arr);
+  hipLaunchKernelGGL(kb_scan_rows, dim3(1, n), dim3(1024), 0, st, d_arr);
+  hipLaunchKernelGGL(kb_max_row, dim3((N_max + 255) / 256, n), b256, 0, st, d_arr);
+  hipLaunchKernelGGL(k_enc_report, dim3((n + 63) / 64), dim3(64), 0, st, d_arr, n, d_report);
   CM_HIP(hipGetLastError());
-  // (too many values, V, longest row, -) and nnz = row_ptr[N] into the context's pinned scratch words [8..15], then the one wait
-  int* h = ctx->h_pinned + 8;
-  CM_HIP(hipMemcpyAsync(h, p->enc_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
-  CM_HIP(hipMemcpyAsync(h + 4, p->row_ptr + N, sizeof(int), hipMemcpyDeviceToHost, st));
-  CM_HIP(hipStreamSynchronize(st));
-  if (h[0]) { cm_set_error("stimulus matrix has more than %d distinct values", CM_MAX_VALS); return CM_ERR_TOO_MANY_POWERS; }
-  p->V = h[1];
-  p->max_row_len = h[2];
-  p->nnz = h[4];
-  p->small_cap = cm_small_cap(p);
   return CM_OK;
 }
 
-int cm_encode_stim_stage2(cm_ctx* ctx, cm_problem* p, const double* d_stim) {
-  const int N = p->N, K = p->K;
+int cm_encode_stage2(cm_ctx* ctx, const cm_enc* d_arr, int n, int N_max, int K_max, long long nnz_max, int* d_report) {
   hipStream_t st = ctx->stream;
-  const int row_blocks = (N + 3) / 4;
-  const size_t nnz_alloc = p->nnz > 0 ? (size_t)p->nnz : 1;
-  hipLaunchKernelGGL(k_stim_fill_csr, dim3(row_blocks), dim3(256), 0, st, d_stim, N, K, p->vals, p->enc_flags + 1, p->row_ptr, p->col, p->grp);
-  CM_HIP(hipMemsetAsync(p->enc_col_cnt, 0, (size_t)K * sizeof(int), st));
-  hipLaunchKernelGGL(k_csc_count, dim3(row_blocks), dim3(256), 0, st, p->row_ptr, p->col, N, p->enc_col_cnt);
-  hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, st, p->enc_col_cnt, K, p->col_ptr);
-  CM_HIP(hipMemsetAsync(p->enc_col_cnt, 0, (size_t)K * sizeof(int), st));            // reused as the per-column cursors
-  hipLaunchKernelGGL(k_csc_scatter, dim3(row_blocks), dim3(256), 0, st, p->row_ptr, p->col, N, p->col_ptr, p->enc_col_cnt, p->csc_row, p->csc_pos);
-  hipLaunchKernelGGL(k_csc_sort, dim3((K + 255) / 256), dim3(256), 0, st, p->col_ptr, K, p->csc_row, p->csc_pos);
-  hipLaunchKernelGGL(k_csc_grp, dim3((unsigned)((nnz_alloc + 255) / 256)), dim3(256), 0, st, p->csc_pos, p->grp, (long long)p->nnz, p->csc_grp);
-  hipLaunchKernelGGL(k_max_len, dim3((K + 255) / 256), dim3(256), 0, st, p->col_ptr, K, p->enc_flags + 3);
+  const dim3 b256(256);
+  const int row_blocks = (N_max + 3) / 4;
+  hipLaunchKernelGGL(k_enc_clear2, dim3(std::max(1, (N_max * CM_MAX_VALS + 255) / 256), n), b256, 0, st, d_arr);
+  hipLaunchKernelGGL(kb_stim_fill_csr, dim3(row_blocks, n), b256, 0, st, d_arr);
+  hipLaunchKernelGGL(kb_csc_count, dim3(row_blocks, n), b256, 0, st, d_arr);
+  hipLaunchKernelGGL(kb_scan_cols, dim3(1, n), dim3(1024), 0, st, d_arr);
+  hipLaunchKernelGGL(kb_csc_scatter, dim3(row_blocks, n), b256, 0, st, d_arr);
+  hipLaunchKernelGGL(kb_csc_sort, dim3((K_max + 255) / 256, n), b256, 0, st, d_arr);
+  hipLaunchKernelGGL(kb_csc_grp, dim3((unsigned)((std::max<long long>(nnz_max, 1) + 255) / 256), n), b256, 0, st, d_arr);
+  hipLaunchKernelGGL(kb_max_col, dim3((K_max + 255) / 256, n), b256, 0, st, d_arr);
+  hipLaunchKernelGGL(k_enc_report, dim3((n + 63) / 64), dim3(64), 0, st, d_arr, n, d_report);
   CM_HIP(hipGetLastError());
-  CM_HIP(hipMemcpyAsync(ctx->h_pinned + 8 + 3, p->enc_flags + 3, sizeof(int), hipMemcpyDeviceToHost, st));   // longest column: read after the caller's synchronisation
   return CM_OK;
 }
 

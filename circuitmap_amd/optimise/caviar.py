@@ -54,6 +54,44 @@ class Problem:
                                                   kind, C.byref(self.handle)))
         self._keep = None
 
+    @classmethod
+    def create_batch(cls, ctx, circuits):
+        """cm_problem_create_batch: `circuits` = [(psc K x T, stim N x K), ...] host arrays or [("device", N, K, T, psc_ptr, stim_ptr), ...]
+        (all of one kind) -> list of Problems; the prologue kernels run once for the group."""
+        n = len(circuits)
+        if n == 0:
+            return []
+        dev = len(circuits[0]) != 2
+        keep, dims, ptrs = [], [], []
+        for c in circuits:
+            if (len(c) != 2) != dev:
+                raise ValueError("create_batch: host and device circuits cannot be mixed")
+            if dev:
+                _, N, K, T, psc_ptr, stim_ptr = c
+            else:
+                psc, stim = _lib.f64(c[0]), _lib.f64(c[1])
+                if psc.ndim != 2 or stim.ndim != 2 or psc.shape[0] != stim.shape[1]:
+                    raise ValueError("y_psc must be K x T and I must be N x K (got %s, %s)" % (psc.shape, stim.shape))
+                keep += [psc, stim]
+                N, K, T = stim.shape[0], stim.shape[1], psc.shape[1]
+                psc_ptr, stim_ptr = psc.ctypes.data, stim.ctypes.data
+            dims.append((int(N), int(K), int(T)))
+            ptrs.append((psc_ptr, stim_ptr))
+        i32 = C.c_int32 * n
+        vp = C.c_void_p * n
+        handles = vp()
+        with ctx.lock:
+            _lib.check(ctx.lib.cm_problem_create_batch(ctx.handle, n, i32(*[d[0] for d in dims]), i32(*[d[1] for d in dims]), i32(*[d[2] for d in dims]),
+                                                       vp(*[p[0] for p in ptrs]), vp(*[p[1] for p in ptrs]),
+                                                       _lib.CM_MEM_DEVICE if dev else _lib.CM_MEM_HOST, handles))
+        out = []
+        for d, h in zip(dims, handles):
+            q = cls.__new__(cls)
+            q.ctx, q.lib, q.handle, q._keep = ctx, ctx.lib, C.c_void_p(h), None
+            q.N, q.K, q.T = d
+            out.append(q)
+        return out
+
     @property
     def nnz(self):
         nnz, nv = C.c_int64(), C.c_int32()
@@ -122,6 +160,24 @@ class Problem:
             self.close()
         except Exception:
             pass
+
+
+def fetch_batch(problems):
+    """cm_caviar_fetch_batch: (mu, beta, None, shape, rate, phi, phi_cov, z) of every problem (one context, no lam, no histories) with one
+    device-to-host copy."""
+    if not problems:
+        return []
+    ctx = problems[0].ctx
+    n = len(problems)
+    outs = [dict(mu=np.empty(q.N), beta=np.empty(q.N), phi=np.empty((q.N, 2)), phi_cov=np.empty((q.N, 2, 2)), z=np.empty(q.K)) for q in problems]
+    rs = (_lib.CmResult * n)()
+    for r, o in zip(rs, outs):
+        for k, v in o.items():
+            setattr(r, k, _lib.dptr(v))
+    handles = (C.c_void_p * n)(*[q.handle for q in problems])
+    with ctx.lock:
+        _lib.check(ctx.lib.cm_caviar_fetch_batch(ctx.handle, n, handles, rs))
+    return [(o["mu"], o["beta"], None, np.float64(r.shape), np.float64(r.rate), o["phi"], o["phi_cov"], o["z"]) for r, o in zip(rs, outs)]
 
 
 def _priors_struct(N, mu_prior, beta_prior, shape_prior, rate_prior, phi_prior, phi_cov_prior, keep):

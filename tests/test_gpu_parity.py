@@ -652,6 +652,56 @@ def test_run_batch_many_per_xcd(ctx, N, K, B, iters):
         q.close()
 
 
+def test_create_batch_and_fetch_batch(ctx):
+    """cm_problem_create_batch (prologue kernels once for a group, circuits of different shapes, host arrays and device pointers) gives the
+    encoding of cm_problem_create -- the fits are bitwise the same -- and cm_caviar_fetch_batch the numbers of cm_caviar_fetch; a failing
+    circuit (too many distinct stimulus values) fails the whole call with the reference's error and leaves nothing behind."""
+    from circuitmap_amd import _lib
+    from circuitmap_amd.optimise.caviar import Problem, fetch_batch, run_batch
+    shapes = [(40, 120), (120, 400), (40, 120), (200, 400), (120, 400)]
+    sims = [_sim_case(N, K, 900 + i)[0] for i, (N, K) in enumerate(shapes)]
+    pris = [default_priors(N) for N, _ in shapes]
+    opts = dict(iters=10, seed=3)
+    one_by_one = [Problem(ctx, sim["psc"], sim["stim_matrix"]) for sim in sims]
+    grouped = Problem.create_batch(ctx, [(sim["psc"], sim["stim_matrix"]) for sim in sims])
+    assert [q.nnz for q in grouped] == [q.nnz for q in one_by_one]
+    run_batch(one_by_one, pris, **opts)
+    run_batch(grouped, pris, **opts)
+    packed = fetch_batch(grouped)
+    for a, b, pk in zip(one_by_one, grouped, packed):
+        ra, rb = a.fetch(), b.fetch()
+        _assert_same_fit(ra, rb, "create_batch")
+        for i, nm in enumerate(OUT_NAMES):
+            if nm != "lam":
+                np.testing.assert_array_equal(np.asarray(rb[i], dtype=float), np.asarray(pk[i], dtype=float), err_msg="fetch_batch " + nm)
+    for q in one_by_one + grouped:
+        q.close()
+    # device pointers (the path of fit_batch(scatter=True) and of bench.py's end-to-end leg)
+    N, K = shapes[1]
+    dev = []
+    for sim in sims[1::3]:
+        psc, stim = np.ascontiguousarray(sim["psc"], dtype=float), np.ascontiguousarray(sim["stim_matrix"], dtype=float)
+        pp, sp = ctx.alloc(psc.nbytes), ctx.alloc(stim.nbytes)
+        ctx.upload(pp, psc); ctx.upload(sp, stim)
+        dev.append(("device", N, K, psc.shape[1], pp, sp))
+    dprobs = Problem.create_batch(ctx, dev)
+    for d in dev:
+        ctx.free(d[4]); ctx.free(d[5])                                   # the problems keep their own encoding
+    hprobs = [Problem(ctx, sim["psc"], sim["stim_matrix"]) for sim in sims[1::3]]
+    run_batch(dprobs, pris[1], **opts)
+    run_batch(hprobs, pris[1], **opts)
+    for a, b in zip(hprobs, dprobs):
+        _assert_same_fit(a.fetch(), b.fetch(), "device create_batch")
+    for q in dprobs + hprobs:
+        q.close()
+    bad = sims[0]["stim_matrix"].astype(float).copy()
+    bad[0, :100] = np.arange(1, 101) * 0.5                               # 100 distinct powers > CM_MAX_VALS
+    with pytest.raises(_lib.CaviarHipError) as ei:
+        Problem.create_batch(ctx, [(sims[1]["psc"], sims[1]["stim_matrix"]), (sims[0]["psc"], bad)])
+    assert "distinct values" in str(ei.value)
+    ctx.release_cache()                                                  # the pool hands everything back
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_run_batch_xcd_placement_never_matters(ctx, monkeypatch, mode):
     """CAVIAR_HIP_XCD_MODE = 0 (plain grid), 1 (interleaved), 2 (circuit-major) give bitwise the results of the default mode 3:
