@@ -570,32 +570,36 @@ __global__ __launch_bounds__(256) void k_seq_pack(cm_parg<BATCH> pa, int gated, 
   const int* __restrict__ col_ptr = p.col_ptr;
   const int* __restrict__ csc_row = p.csc_row;
   SeqRec* __restrict__ packed = (SeqRec*)p.packed;
-  const int j = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE;
   const int lane = threadIdx.x % CM_WAVE;
-  if (j >= p.seq_meta[0]) return;
-  const int n = seq_n[j], off = seq_off[j];
-  const int beg = a.row_ptr[n], len = a.row_ptr[n + 1] - beg;
+  const int nseq = p.seq_meta[0];
   const double sig = a.scal[CM_S_SHAPE] / a.scal[CM_S_RATE];
-  const double mu = a.mu[n], be = a.beta[n];
-  if (lane == 0) {
-    SeqRec h;
-    h.a = (uint32_t)n; h.b = len; h.x = mu; h.y = sig * (mu * mu + be * be); h.z = 0.0;   // caviar.py:206
-    packed[off] = h;
-  }
-  if (len <= CM_WAVE && lane < len) {
-    const int e = beg + lane;
-    const int k = a.col[e], g = a.grp[e];
-    SeqRec r;
-    r.a = (uint32_t)k | ((uint32_t)g << 24) | ((uint32_t)(a.me[e] != 0) << 31);
-    int turn = 0;
-    if (turns)     // (gathering four neurons at a time was measured slower than this plain loop: 28.3 vs 26.8 us at 128 circuits, 6.6 vs 5.4 us for one)
-      for (int ce = col_ptr[k]; ce < col_ptr[k + 1]; ++ce) { const int q = seq_pos[csc_row[ce]]; turn += (q >= 0 && q < j); }
-    if (turns == 2 && j == 1 && lane == 0) turn = (turn + 1) & 0xFF;   // fault injection (CAVIAR_HIP_TEST_BAD_TICKET): a turn that never comes
-    r.b = e | (turn << 24);
-    r.x = a.lam[e];
-    r.y = a.mcE[(size_t)n * a.mld + g];
-    r.z = -2.0 * sig * a.ye[e] * mu;                                                      // caviar.py:205, first term (ye[e] = y[k])
-    packed[off + 1 + lane] = r;
+  // The grid is sized by the host for twice the largest active set of the batch (the chain rows, mu != 0, are normally among the rows the last
+  // solve covered: a wavefront then takes one row); whatever lies beyond it -- a prior mean that is not zero makes every row a chain row -- is
+  // reached by the stride.  A grid of N / 4 workgroups per circuit, of which 95 % found nothing to do, was most of this kernel's time in a batch.
+  for (int j = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE; j < nseq; j += (int)(gridDim.x * blockDim.x) / CM_WAVE) {
+    const int n = seq_n[j], off = seq_off[j];
+    const int beg = a.row_ptr[n], len = a.row_ptr[n + 1] - beg;
+    const double mu = a.mu[n], be = a.beta[n];
+    if (lane == 0) {
+      SeqRec h;
+      h.a = (uint32_t)n; h.b = len; h.x = mu; h.y = sig * (mu * mu + be * be); h.z = 0.0;   // caviar.py:206
+      packed[off] = h;
+    }
+    if (len <= CM_WAVE && lane < len) {
+      const int e = beg + lane;
+      const int k = a.col[e], g = a.grp[e];
+      SeqRec r;
+      r.a = (uint32_t)k | ((uint32_t)g << 24) | ((uint32_t)(a.me[e] != 0) << 31);
+      int turn = 0;
+      if (turns)     // (gathering four neurons at a time was measured slower than this plain loop: 28.3 vs 26.8 us at 128 circuits, 6.6 vs 5.4 us for one)
+        for (int ce = col_ptr[k]; ce < col_ptr[k + 1]; ++ce) { const int q = seq_pos[csc_row[ce]]; turn += (q >= 0 && q < j); }
+      if (turns == 2 && j == 1 && lane == 0) turn = (turn + 1) & 0xFF;   // fault injection (CAVIAR_HIP_TEST_BAD_TICKET): a turn that never comes
+      r.b = e | (turn << 24);
+      r.x = a.lam[e];
+      r.y = a.mcE[(size_t)n * a.mld + g];
+      r.z = -2.0 * sig * a.ye[e] * mu;                                                      // caviar.py:205, first term (ye[e] = y[k])
+      packed[off + 1 + lane] = r;
+    }
   }
 }
 
@@ -881,7 +885,8 @@ int cm_launch_sweep(cm_ctx* ctx, cm_set& s, int it, const cm_options* o, hipEven
     else CM_LAUNCH_SET_T(k_presweep, (false), s, nbIq + nbC + 1, 1024, 0, st, (table_it < 0 ? it : table_it), gated, msrmp, min_count, nbIq, nbC, split ? (1 << pass) : 7, gran, quiescent);
   }
   static const bool bad_ticket = getenv("CAVIAR_HIP_TEST_BAD_TICKET") != nullptr;   // test hook: exercises the bounded wait + error report of the ticketed chain
-  CM_LAUNCH_SET(k_seq_pack, s, (N + 3) / 4, 256, 0, st, gated, msrmp, min_count, par ? (bad_ticket ? 2 : 1) : 0);
+  const int pack_rows = s.B > 1 ? std::min(N, std::max(64, 2 * s.na_max)) : N;      // (one circuit: the N / 4 workgroups are not what its 5 us are made of)
+  CM_LAUNCH_SET(k_seq_pack, s, (pack_rows + 3) / 4, 256, 0, st, gated, msrmp, min_count, par ? (bad_ticket ? 2 : 1) : 0);
   if (mid) CM_HIP(hipEventRecord(mid, st));
   const size_t lds = (size_t)p->K * sizeof(double);
   const long long nrec = (long long)p->N + s.nnz_min;          // smallest allocation of `packed` (records) and of the chunk table in the set

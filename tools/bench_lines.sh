@@ -6,5 +6,5 @@ run() { name=$1; shift; timeout -k 10 500 python bench.py "$@" > "$out/${tag}_$n
 run default_bench_with_cpu_baseline &&
 run bench_cfg3_B1 --circuits-per-gpu 1 --no-cpu-baseline &&
 run bench_cfg2_B1 --workload cfg2 --circuits-per-gpu 1 --no-cpu-baseline &&
-run bench_cfg2_B128 --workload cfg2 --no-cpu-baseline &&
+run bench_cfg2_B256 --workload cfg2 --no-cpu-baseline &&
 run bench_cfg5 --workload cfg5 --steps 4 --warmup 1 --no-cpu-baseline
