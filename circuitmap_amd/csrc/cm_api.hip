@@ -288,7 +288,7 @@ extern "C" int cm_problem_destroy(cm_problem* p) {
   hipSetDevice(p->ctx->device);
   hipStreamSynchronize(p->ctx->stream);
   // the two slabs hold every static / state buffer; the random tables of a run (sized by iters, S) are allocated by the run
-  void* ptrs[] = {p->slabA, p->slabB, p->orders_all, p->orders_tmp, p->inv_all, p->wtab, p->keys, p->uexp};
+  void* ptrs[] = {p->slabA, p->slabB, p->orders_all, p->orders_tmp, p->inv_all, p->wtab, p->wstat, p->keys, p->uexp};
   for (void* q : ptrs) cm_pool_free(p->ctx, q);                      // (the stream is idle: nothing queued still reads them)
   free_hist(p);
   delete p;
@@ -480,7 +480,7 @@ void cm_fill_pdev(const cm_problem* p, const cm_problem* r, int* mailbox, cm_pde
   d->phi_cov_prior = p->phi_cov_prior; d->act_idx = p->act_idx; d->act_inv = p->act_inv; d->n_act = p->n_act; d->alive = p->alive; d->seq_n = p->seq_n;
   d->seq_off = p->seq_off; d->seq_pos = p->seq_pos; d->chunk_first = p->chunk_first; d->seq_meta = p->seq_meta; d->packed = p->packed;
   d->A = p->A; d->X = p->X; d->Lf = p->Lf; d->Dinv = p->Dinv; d->rhs = p->rhs; d->mailbox = mailbox;
-  d->orders_all = r->orders_all; d->inv_all = r->inv_all; d->wtab = r->wtab; d->uexp = r->uexp; d->keys = r->keys;
+  d->orders_all = r->orders_all; d->inv_all = r->inv_all; d->wtab = r->wtab; d->wstat = r->wstat; d->uexp = r->uexp; d->keys = r->keys;
 }
 
 static void set_limits(cm_set* s) {
@@ -796,8 +796,10 @@ static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_option
   }
   if (p->wtab_cap < (size_t)iters * N * S * 4) {           // (ndtri(u), u) for each of the iters x N x S x 2 uniforms
     cm_pool_free(ctx, p->wtab);
-    p->wtab = nullptr; p->wtab_cap = 0;
+    cm_pool_free(ctx, p->wstat);
+    p->wtab = p->wstat = nullptr; p->wtab_cap = 0;
     CM_TRY(pmalloc(ctx, &p->wtab, (size_t)iters * N * S * 4));
+    CM_TRY(pmalloc(ctx, &p->wstat, (size_t)iters * N * CM_WSTAT));
     p->wtab_cap = (size_t)iters * N * S * 4;
   }
   if (o->rng_mode == CM_RNG_EXPLICIT) {

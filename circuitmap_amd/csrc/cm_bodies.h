@@ -682,6 +682,32 @@ __device__ __forceinline__ void solve_small_body(double* sm, const double* __res
 }
 
 
+// The closed-form gate of a row that is identically zero with mu == 0 (cm_sweep.hip: quiescent_gate), from the P mean logits `mce` of its powers:
+// est_p = sigmoid(mce_p - sigma beta^2 / 2) on its unmasked trials, rate_p = m_p est_p / trials_p, total = sum_p m_p est_p, isotonic last value
+// max_j mean(rate[j:]), the two tests of caviar.py:220.  qrow[q] = unmasked trials << 16 | trials of power q.  Monotone in every mce_p.
+__device__ __forceinline__ bool cm_quiescent_gate_core(int P, double arg, double thresh, double min_count, const int* __restrict__ qrow, const double (&mce)[8]) {
+  double sr[8], total = 0.0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    sr[q] = 0.0;
+    if (q < P) {
+      const double est = cm_sigmoid(mce[q] - 0.5 * arg);
+      const int packed = qrow[q], cnt = packed & 0xFFFF;
+      const double num = (double)(packed >> 16) * est;
+      total += num;
+      sr[q] = num / ((double)cnt + 1e-4 * (double)(cnt == 0));                  // caviar.py:183
+    }
+  }
+  double S = 0.0, best = -1.0;
+  int c = 0;
+#pragma unroll
+  for (int j = 7; j >= 0; --j) {
+    if (j < P) { S += sr[j]; ++c; const double m = S / (double)c; best = m > best ? m : best; }
+  }
+  const double iso = P > 0 ? best : 0.0;
+  return iso >= thresh && total >= min_count;                                   // caviar.py:220
+}
+
 // ------------------------------------------------------------------------------------------------
 // Monte-Carlo logit pieces shared by cm_sweep.hip (table kernel) and cm_iter.hip (fused kernel)
 // ------------------------------------------------------------------------------------------------

@@ -21,6 +21,7 @@
 #endif
 //                  CM_LD_PAD: doubles added to the row stride of the solve matrices (8 was measured: no gain -- the trailing update is not channel-conflict bound)
 #define CM_EV_PER_IT 12
+#define CM_WSTAT 6             // doubles per row of cm_pdev::wstat
 #define CM_MAX_BATCH 1024      // circuits in one lock-step group
 #define CM_MAILBOX_BATCH0 32   // 64-bit word index of the first per-circuit mailbox of a batch
 #define CM_STATUS_OFF (2 * (CM_MAILBOX_BATCH0 + CM_MAX_BATCH))   // int32 index of the end-of-run status words: 8 per circuit (n_act[0..3], chain rows, chain records, -, -)
@@ -182,6 +183,7 @@ struct cm_problem {
   int32_t* inv_all = nullptr;    // [iters*N] inverse of every sweep order: position of neuron n in iteration it
   double* wtab = nullptr;        // [iters*N*2S*2] (ndtri(u), u) for every uniform of the run (data independent)
   size_t wtab_cap = 0;
+  double* wstat = nullptr;        // statistics of the table rows (allocated with wtab)
   int32_t orders_cap = 0;     // iterations the two buffers are sized for
   int32_t* seq_n = nullptr;   // [N]   neurons with mu != 0 in sweep order
   int32_t* seq_off = nullptr; // [N+1] record offset of each such row in `packed`
@@ -239,6 +241,7 @@ struct cm_pdev {
   // random tables: data independent, shared by all circuits of a batch (same seed, N, S -> same streams)
   const int *orders_all, *inv_all;
   const double *wtab, *uexp;
+  const double* wstat;           // [iters x N x CM_WSTAT] per table row (stored by neuron): mean and max of the phi_0 quantiles, mean and min of the phi_1 quantiles, smallest phi_0 uniform (k_ndtri_table)
   const uint32_t* keys;
 };
 

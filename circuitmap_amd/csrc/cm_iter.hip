@@ -23,6 +23,7 @@
 
 struct IterDyn {     // what changes from iteration to iteration (common to all circuits of a batch)
   int it, max_iters; double penalty, scale_factor, tol; int do_sigma, seq, do_solve, stage_ok, do_phi, do_mc, S, roles, nx, explicit_rng, skip_dead;
+  int mc_screen; double msrmp, min_count;   // k_mc_dead: the next sweep is gated -> all-zero rows whose gate cannot pass need no Monte-Carlo logit
   long long* dbg;      // diagnostic (CAVIAR_HIP_TRACE_BLOCK0): device clock at the phase boundaries of block 0, 8 words per launch
 };
 
@@ -42,100 +43,152 @@ __device__ __forceinline__ void dead_phi_copy(const cm_pdev& p, int n, int lane,
 }
 
 // Batches: the all-zero rows of every circuit (95 % of the rows in the steady state) in a kernel of their own -- copy of the
-// constants + the next Monte-Carlo logit, nothing else, so that no workgroup waits for a Newton iteration.  TWO rows per wavefront, one
-// per 32-lane half: the per-row overhead (constants, address arithmetic, the reductions' instruction streams, the division) is issued
-// once for two rows -- the launch was bound by instruction issue at ~340 vector instructions per row, of which the evaluations
-// themselves were a fifth.  Every row's sums are bitwise those of mc_logit_body (one row per wavefront): there lane l accumulates the
-// samples l, l + 64 and cm_wave_sum reduces the 64 lanes as four 16-lane rows, (r0 + r1) + (r2 + r3); here physical lane j of a half
-// carries the two virtual lanes j (samples j, j + 64) and j + 32 (samples j + 32, j + 96) in separate accumulators, the 16-lane
-// reductions run on both sets, and the four row sums are combined in the same order.  A lane's samples never leave its registers: no LDS.
-// Rows with lam != 0 leave at once (k_iter_mid takes them); more than four powers or more than 128 samples: the general body, row by row.
+// constants + the next Monte-Carlo logit, nothing else, so that no workgroup waits for a Newton iteration.  Rows with lam != 0 are not
+// touched (k_iter_mid takes them).
+// PHASE 1, one row per THREAD (rows_per_wg = 256 rows per workgroup while the next sweep applies the gate): copy of the constants, then the
+// SCREENING.  The logit of an all-zero row is only ever read by the gate of the next sweep (mu = 0 there as long as the prior mean is zero: the
+// row is outside the active set of the next solve), and for nearly all of these rows that gate fails by a wide margin -- which a bound shows
+// without the S x P evaluations: with q0_s, q1_s the row's tabulated quantiles, every draw of phi_1 is at least mean1 + sd1 q1_s (its
+// truncation point only moves a quantile up), so while no sample reaches the residue range (x < 8: the logit is x itself) the mean logit of
+// power v is at most v (mean0 + sd0 mean(q0)) - (mean1 + sd1 mean(q1)) -- two row statistics the table kernel leaves (wstat).  If the gate
+// fails even on these upper bounds (it is monotone in every logit; sigma, the spontaneous rate and the row's beta = prior are final by now), the
+// row stays zero whatever its exact logits are: -inf is stored and the evaluations are skipped.  Rows the bound cannot decide are LISTED in
+// LDS and take the exact path (PHASE 2).  Decisions, and with them every output, are those of the unscreened run.
 template <bool BATCH>
-__global__ __launch_bounds__(256) void k_mc_dead(cm_parg<BATCH> pa, IterDyn a) {
+__global__ __launch_bounds__(256) void k_mc_dead(cm_parg<BATCH> pa, IterDyn a, int rows_per_wg) {
   extern __shared__ double sm[];
   __shared__ double etab[64];
+  __shared__ int list[256], nlist;
   cm_exptab_init(etab);
+  if (threadIdx.x == 0) nlist = 0;
   __syncthreads();                                   // (before any wavefront leaves)
   const cm_pdev& p = pa.get();
   const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE, h = lane >> 5, j = lane & 31;
   const int N = p.N, S = a.S;
-  const int n = 2 * ((int)blockIdx.x * (int)(blockDim.x / CM_WAVE) + wave) + h;
-  const bool in = n < N;
-  const int nn = in ? n : N - 1;
-  // The launch is also latency-bound (one short dependent chain per wavefront): everything a row needs is requested BEFORE the test of
-  // its state -- the flag, the per-run constants, its table row (stored by neuron: no look-up of the sweep position in front of it).
-  const double flag = p.rs[(size_t)nn * 4 + 3];
-  const double2* __restrict__ wu = (const double2*)p.wtab + ((size_t)a.nx * N + nn) * 2 * S;
-  double2 t[4][2];
+  {
+    const int n = (int)blockIdx.x * rows_per_wg + (int)threadIdx.x;
+    const bool in = (int)threadIdx.x < rows_per_wg && n < N;
+    const int nn = in ? n : N - 1;
+    const bool dead = in && p.rs[(size_t)nn * 4 + 3] < 0.0;
+    bool need = false;
+    if (dead) {
+      const double* __restrict__ pd = p.phi_dead + 2 * (size_t)n;
+      const double* __restrict__ cd = p.phi_cov_dead + 4 * (size_t)n;
+      const double mean0 = pd[0], mean1 = pd[1], sd0 = cd[0], c01 = cd[1], c10 = cd[2], sd1 = cd[3];
+      p.phi[2 * n] = mean0; p.phi[2 * n + 1] = mean1;
+      p.phi_cov[4 * n] = sd0; p.phi_cov[4 * n + 1] = c01; p.phi_cov[4 * n + 2] = c10; p.phi_cov[4 * n + 3] = sd1;
+      need = a.do_mc != 0;
+      const int Pq = p.V - 1;
+      if (need && a.mc_screen && Pq >= 1 && Pq <= 8 && p.max_row_len < 65536 && p.vals[0] == 0.0) {   // (the conditions of the closed-form gate: sweep_args)
+        const double* __restrict__ ws = p.wstat + ((size_t)a.nx * N + n) * CM_WSTAT;
+        const double qbar0 = ws[0], qmax0 = ws[1], qbar1 = ws[2], qmin1 = ws[3], umin0 = ws[4];
+        const double c0 = p.phi_c_dead[2 * (size_t)n];
+        // c0 below half an ulp of the row's smallest phi_0 uniform: arg = c0 + u (1 - c0) is u bit for bit for every sample, the phi_0 draws ARE
+        // the tabulated quantiles (the test mc_logit_body makes sample by sample)
+        bool ok = p.mu_prior[n] == 0.0 && c0 >= 0.0 && c0 < 0x1p-54 * umin0 && sd0 >= 0.0 && sd1 >= 0.0;
+        const double a0 = mean0 + sd0 * qbar0, a0max = mean0 + sd0 * qmax0, b1 = mean1 + sd1 * qbar1, b1min = mean1 + sd1 * qmin1;
+        double ub[8];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int s_ = j + 32 * (q >> 1) + 64 * (q & 1);               // slots: j, j + 64 (virtual lane j), j + 32, j + 96 (virtual lane j + 32)
-#pragma unroll
-    for (int comp = 0; comp < 2; ++comp) t[q][comp] = (a.do_mc && s_ < S) ? wu[2 * s_ + comp] : make_double2(0.0, 0.0);
+        for (int q = 0; q < 8; ++q) {
+          ub[q] = 0.0;
+          if (q < Pq) {
+            const double v = p.vals[q + 1];
+            ok = ok && (a0max * v - b1min < CM_LOGIT_RESIDUE_FROM - 1e-6);                          // every sample of this power below the residue range
+            ub[q] = (a0 * v - b1) + 1e-9 * (1.0 + fabs(a0 * v) + fabs(b1));                         // (summation order, the rounding of the two means)
+          }
+        }
+        const double b0 = p.beta_prior[n], be = b0 * b0;                                            // beta of a row outside the active set (k_fill_prior)
+        const double sig = p.scal[CM_S_SHAPE] / p.scal[CM_S_RATE], thresh = a.msrmp + p.scal[CM_S_SPONT_RATE];
+        if (ok && !cm_quiescent_gate_core(Pq, sig * (be * be), thresh, a.min_count, p.qcnt + (size_t)n * 8, ub)) {
+          for (int q = 0; q < Pq; ++q) p.mcE[(size_t)n * p.mce_ld + q + 1] = -INFINITY;
+          need = false;
+        }
+      }
+    }
+    const unsigned long long m = __ballot(need);     // ordered append of the wavefront's rows
+    int base = 0;
+    if (lane == 0 && m) base = atomicAdd(&nlist, __popcll(m));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (need) list[base + __popcll(m & ((1ull << lane) - 1ull))] = n;
   }
-  const double* __restrict__ pd = p.phi_dead + 2 * (size_t)nn;
-  const double* __restrict__ cd = p.phi_cov_dead + 4 * (size_t)nn;
-  const double* __restrict__ cc = p.phi_c_dead + 2 * (size_t)nn;
-  const double mean0 = pd[0], mean1 = pd[1], sd0 = cd[0], c01 = cd[1], c10 = cd[2], sd1 = cd[3], c0 = cc[0], c1 = cc[1];
-  const bool dead = in && flag < 0.0;
-  if (!__any(dead)) return;
-  if (dead && j == 0) {
-    p.phi[2 * n] = mean0; p.phi[2 * n + 1] = mean1;
-    p.phi_cov[4 * n] = sd0; p.phi_cov[4 * n + 1] = c01; p.phi_cov[4 * n + 2] = c10; p.phi_cov[4 * n + 3] = sd1;
-  }
-  if (!a.do_mc) return;
+  __syncthreads();
+  const int nl = nlist;
+  if (nl == 0 || !a.do_mc) return;
+  // PHASE 2: the exact Monte-Carlo logit of the listed rows, TWO rows per wavefront, one per 32-lane half: the per-row overhead (constants,
+  // address arithmetic, the reductions' instruction streams, the division) is issued once for two rows.  Every row's sums are bitwise those
+  // of mc_logit_body (one row per wavefront): there lane l accumulates the samples l, l + 64 and cm_wave_sum reduces the 64 lanes as four
+  // 16-lane rows, (r0 + r1) + (r2 + r3); here physical lane j of a half carries the two virtual lanes j (samples j, j + 64) and j + 32
+  // (samples j + 32, j + 96) in separate accumulators, the 16-lane reductions run on both sets, and the four row sums are combined in the
+  // same order.  A lane's samples never leave its registers: no LDS.  More than four powers or more than 128 samples: the general body.
   int gi[4] = {0, 0, 0, 0}, P = 0;
   for (int g = 0; g < p.V; ++g)
     if (p.vals[g] > 0.0) { if (P < 4) gi[P] = g; ++P; }
-  if (P > 4 || S > 2 * CM_WAVE) {                    // rare shapes: the general body, one row after the other on the whole wavefront
-    for (int hh = 0; hh < 2; ++hh) {
-      const int src = 32 * hh;
-      if (!__builtin_amdgcn_readlane((int)dead, src)) continue;
-      const int row = __builtin_amdgcn_readlane(n, src);
-      mc_logit_body<false, true>(row, lane, cm_readlane_f64(mean0, src), cm_readlane_f64(mean1, src), cm_readlane_f64(sd0, src), cm_readlane_f64(sd1, src),
-                                 (const double2*)p.wtab + ((size_t)a.nx * N + row) * 2 * S, p.vals, p.V, S, sm + (size_t)wave * 2 * S, p.mcE, etab,
-                                 cm_readlane_f64(c0, src), cm_readlane_f64(c1, src), nullptr, p.mce_ld);
-    }
-    return;
-  }
   double vk[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) vk[k] = p.vals[gi[k]];
-  const bool tiny0 = c0 < 0x1p-106, tiny1 = c1 < 0x1p-106;
-  double acc[4][2] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int s_ = j + 32 * (q >> 1) + 64 * (q & 1);
-    if (dead && s_ < S) {
-      // the draw of mc_logit_body<false> (caviar.py:212): the tabulated quantile whenever arg = c + u (1 - c) is u bit for bit
-      double qq[2];
-#pragma unroll
-      for (int comp = 0; comp < 2; ++comp) {
-        const double c = comp ? c1 : c0;
-        const bool tiny = comp ? tiny1 : tiny0;
-        const double2 tt = t[q][comp];
-        if (tiny) qq[comp] = (tt.x == -INFINITY && c != 0.0) ? cm_quantile_slow(c) : tt.x;
-        else { const double arg = c + tt.y * (1.0 - c); qq[comp] = (arg == tt.y) ? tt.x : cm_quantile_slow(arg); }
+  const int nwaves = (int)blockDim.x / CM_WAVE;
+  for (int i0 = 2 * wave; i0 < nl; i0 += 2 * nwaves) {
+    const bool need = i0 + h < nl;
+    const int n = list[need ? i0 + h : i0];
+    const double* __restrict__ pd = p.phi_dead + 2 * (size_t)n;
+    const double* __restrict__ cd = p.phi_cov_dead + 4 * (size_t)n;
+    const double* __restrict__ cc = p.phi_c_dead + 2 * (size_t)n;
+    const double mean0 = pd[0], mean1 = pd[1], sd0 = cd[0], sd1 = cd[3], c0 = cc[0], c1 = cc[1];
+    if (P > 4 || S > 2 * CM_WAVE) {                  // rare shapes: the general body, one row after the other on the whole wavefront
+      for (int hh = 0; hh < 2; ++hh) {
+        const int src = 32 * hh;
+        if (!__builtin_amdgcn_readlane((int)need, src)) continue;
+        const int row = __builtin_amdgcn_readlane(n, src);
+        mc_logit_body<false, true>(row, lane, cm_readlane_f64(mean0, src), cm_readlane_f64(mean1, src), cm_readlane_f64(sd0, src), cm_readlane_f64(sd1, src),
+                                   (const double2*)p.wtab + ((size_t)a.nx * N + row) * 2 * S, p.vals, p.V, S, sm + (size_t)wave * 2 * S, p.mcE, etab,
+                                   cm_readlane_f64(c0, src), cm_readlane_f64(c1, src), nullptr, p.mce_ld);
       }
-      const double m0 = qq[0] * sd0 + mean0, m1 = qq[1] * sd1 + mean1;
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (k < P) acc[k][q >> 1] += cm_logit_of_sigmoid(m0 * vk[k] - m1, etab);
+      continue;
     }
-  }
-  double tot = 0.0;
+    const double2* __restrict__ wu = (const double2*)p.wtab + ((size_t)a.nx * N + n) * 2 * S;
+    double2 t[4][2];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (k < P) {
-      double r01 = cm_seg_sum<16>(acc[k][0]), r23 = cm_seg_sum<16>(acc[k][1]);   // r0 | r1 and r2 | r3 in the two 16-lane rows of the half
-      r01 += __shfl_xor(r01, 16, CM_WAVE);                                          // r0 + r1 (the other row: r1 + r0, the same bits)
-      r23 += __shfl_xor(r23, 16, CM_WAVE);
-      const double sum = r01 + r23;
-      if (j == k) tot = sum;
+    for (int q = 0; q < 4; ++q) {
+      const int s_ = j + 32 * (q >> 1) + 64 * (q & 1);               // slots: j, j + 64 (virtual lane j), j + 32, j + 96 (virtual lane j + 32)
+#pragma unroll
+      for (int comp = 0; comp < 2; ++comp) t[q][comp] = (need && s_ < S) ? wu[2 * s_ + comp] : make_double2(0.0, 0.0);
     }
+    const bool tiny0 = c0 < 0x1p-106, tiny1 = c1 < 0x1p-106;
+    double acc[4][2] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int s_ = j + 32 * (q >> 1) + 64 * (q & 1);
+      if (need && s_ < S) {
+        // the draw of mc_logit_body<false> (caviar.py:212): the tabulated quantile whenever arg = c + u (1 - c) is u bit for bit
+        double qq[2];
+#pragma unroll
+        for (int comp = 0; comp < 2; ++comp) {
+          const double c = comp ? c1 : c0;
+          const bool tiny = comp ? tiny1 : tiny0;
+          const double2 tt = t[q][comp];
+          if (tiny) qq[comp] = (tt.x == -INFINITY && c != 0.0) ? cm_quantile_slow(c) : tt.x;
+          else { const double arg = c + tt.y * (1.0 - c); qq[comp] = (arg == tt.y) ? tt.x : cm_quantile_slow(arg); }
+        }
+        const double m0 = qq[0] * sd0 + mean0, m1 = qq[1] * sd1 + mean1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k < P) acc[k][q >> 1] += cm_logit_of_sigmoid(m0 * vk[k] - m1, etab);
+      }
+    }
+    double tot = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k < P) {
+        double r01 = cm_seg_sum<16>(acc[k][0]), r23 = cm_seg_sum<16>(acc[k][1]);   // r0 | r1 and r2 | r3 in the two 16-lane rows of the half
+        r01 += __shfl_xor(r01, 16, CM_WAVE);                                          // r0 + r1 (the other row: r1 + r0, the same bits)
+        r23 += __shfl_xor(r23, 16, CM_WAVE);
+        const double sum = r01 + r23;
+        if (j == k) tot = sum;
+      }
+    }
+    const double mean = tot / (double)S;                 // lane k of the half: the mean of power k -- one division serves all of them
+    if (need && j < P) p.mcE[(size_t)n * p.mce_ld + (j == 0 ? gi[0] : (j == 1 ? gi[1] : (j == 2 ? gi[2] : gi[3])))] = mean;
   }
-  const double mean = tot / (double)S;                 // lane k of the half: the mean of power k -- one division serves all of them
-  if (dead && j < P) p.mcE[(size_t)n * p.mce_ld + (j == 0 ? gi[0] : (j == 1 ? gi[1] : (j == 2 ? gi[2] : gi[3])))] = mean;
 }
 
 // LISTED (batches, steady state): the per-neuron role walks the list of rows with lam != 0 in a stride loop -- its own instantiation,
@@ -281,7 +334,12 @@ static int launch_iter2(cm_ctx* ctx, cm_set& s, const IterDyn& a0, size_t lds, i
     }
     if (between) CM_HIP(hipEventRecord(between, ctx->stream));
     CM_TRY(cm_raise_lds(ctx, CM_LDS_MC_DEAD_B, reinterpret_cast<const void*>(k_mc_dead<true>), 4 * lds_waves, 48 * 1024));   // (num_mc_samples > 768)
-    CM_LAUNCH_SET(k_mc_dead, s, (s.lead->N + 7) / 8, 256, 4 * lds_waves, ctx->stream, a0);   // two rows per wavefront
+    {
+      // screening on: 256 rows per workgroup (one per thread; the few rows the bound leaves are evaluated two per wavefront); off: 8 rows per
+      // workgroup, i.e. every wavefront has its two rows at once
+      const int rows_per_wg = a0.mc_screen ? 256 : 8;
+      CM_LAUNCH_SET(k_mc_dead, s, (s.lead->N + rows_per_wg - 1) / rows_per_wg, 256, 4 * lds_waves, ctx->stream, a0, rows_per_wg);
+    }
   } else {
     CM_LAUNCH_SET_T(k_iter_mid, (SEG, FULLMC), s, blocks, threads, lds, ctx->stream, a0);
     if (between) CM_HIP(hipEventRecord(between, ctx->stream));
@@ -314,6 +372,9 @@ int cm_launch_iter_mid(cm_ctx* ctx, cm_set& s, int it, int iters, int S, int rng
   // batches: listed rows + k_mc_dead once fewer than half of the rows were active when the iteration began (any choice is correct: the
   // plain form handles all-zero rows itself); the early iterations, with every row alive, run one wavefront per row
   a.skip_dead = (s.B > 1 && do_phi && it >= 0 && roles == 3 && 2 * s.na_max < N) ? 1 : 0;
+  static const bool no_screen = getenv("CAVIAR_HIP_NO_MC_SCREEN") != nullptr;     // diagnostic: every all-zero row through the exact Monte-Carlo logit
+  a.mc_screen = (!no_screen && nxt > o->delay_spont_est) ? 1 : 0;                   // (the sweep of iteration nxt applies the gate: cm_launch_sweep)
+  a.msrmp = o->msrmp; a.min_count = o->minimum_spike_count;
   a.dbg = (ctx->dbg_block0 && it >= 0 && it < 64) ? ctx->dbg_block0 + 8 * it : nullptr;
   const int threads = s.B == 1 ? CM_ITER_THREADS : CM_ITER_THREADS_BATCH;
   const int waves = threads / CM_WAVE;

@@ -92,16 +92,36 @@ __global__ __launch_bounds__(256) void k_invert_orders(const int* __restrict__ o
 // neuron n reads its row without first looking up the neuron's sweep position (one dependent memory round trip less in kernels that are
 // latency-bound).  orders_all == nullptr (cm_k_rng_streams): rows by sweep step.
 __global__ __launch_bounds__(64) void k_ndtri_table(const uint32_t* __restrict__ keys_all, const double* __restrict__ uexp_all, const int* __restrict__ orders_all,
-                                                     int it0, int N, int S, double* __restrict__ wtab, double* __restrict__ u_out) {
+                                                     int it0, int N, int S, double* __restrict__ wtab, double* __restrict__ u_out, double* __restrict__ wstat) {
   const int m = blockIdx.x, it = it0 + blockIdx.y;
   const size_t base = ((size_t)it * N + m) * 2 * S;
-  const size_t wbase = ((size_t)it * N + (orders_all ? orders_all[(size_t)it * N + m] : m)) * 2 * S;
+  const size_t wrow = (size_t)it * N + (orders_all ? orders_all[(size_t)it * N + m] : m);
+  const size_t wbase = wrow * 2 * S;
   uint32_t k0 = 0, k1 = 0;
   if (!uexp_all) { const uint32_t* keys = keys_all + (size_t)it * (N + 3) * 2; k0 = keys[2 * (3 + m)]; k1 = keys[2 * (3 + m) + 1]; }
+  // Row statistics for k_mc_dead's screening of all-zero rows: mean and maximum of the phi_0 quantiles (draws j = 2 s), mean and minimum of
+  // the phi_1 quantiles (j = 2 s + 1), smallest phi_0 uniform.  A row with a non-finite quantile (u == 0) is marked by max = +inf: never screened.
+  double s0 = 0.0, s1 = 0.0, mx0 = -INFINITY, mn1 = INFINITY, mnu0 = INFINITY;
+  bool fin = true;
   for (int j = threadIdx.x; j < 2 * S; j += CM_WAVE) {
     const double u = uexp_all ? uexp_all[base + j] : cm_uniform64(k0, k1, j, S);
-    if (wtab) { wtab[2 * (wbase + j)] = normcdfinv(u); wtab[2 * (wbase + j) + 1] = u; }   // (ndtri(u), u) pairs
+    if (wtab) {
+      const double q = normcdfinv(u);
+      wtab[2 * (wbase + j)] = q; wtab[2 * (wbase + j) + 1] = u;   // (ndtri(u), u) pairs
+      fin = fin && isfinite(q);
+      if (j & 1) { s1 += q; mn1 = fmin(mn1, q); } else { s0 += q; mx0 = fmax(mx0, q); mnu0 = fmin(mnu0, u); }
+    }
     if (u_out) u_out[(size_t)m * 2 * S + j] = u;
+  }
+  if (wtab && wstat) {
+    s0 = cm_wave_sum(s0); s1 = cm_wave_sum(s1);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mx0 = fmax(mx0, __shfl_xor(mx0, o, CM_WAVE)); mn1 = fmin(mn1, __shfl_xor(mn1, o, CM_WAVE)); mnu0 = fmin(mnu0, __shfl_xor(mnu0, o, CM_WAVE)); }
+    const bool all_fin = __all(fin);
+    if (threadIdx.x == 0) {
+      double* w = wstat + wrow * CM_WSTAT;
+      w[0] = s0 / (double)S; w[1] = all_fin ? mx0 : INFINITY; w[2] = s1 / (double)S; w[3] = mn1; w[4] = mnu0; w[5] = 0.0;
+    }
   }
 }
 
@@ -139,26 +159,10 @@ __device__ __forceinline__ bool quiescent_gate(const SweepArgs& a, int n, double
   const int P = a.V - 1;
   const double be = a.beta[n];
   const double arg = sig * (be * be);
-  double sr[8], total = 0.0;
+  double mce[8];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    sr[q] = 0.0;
-    if (q < P) {
-      const double est = cm_sigmoid(a.mcE[(size_t)n * a.mld + q + 1] - 0.5 * arg);
-      const int packed = a.qcnt[(size_t)n * 8 + q], cnt = packed & 0xFFFF;
-      const double num = (double)(packed >> 16) * est;
-      total += num;
-      sr[q] = num / ((double)cnt + 1e-4 * (double)(cnt == 0));                  // caviar.py:183
-    }
-  }
-  double S = 0.0, best = -1.0;
-  int c = 0;
-#pragma unroll
-  for (int j = 7; j >= 0; --j) {
-    if (j < P) { S += sr[j]; ++c; const double m = S / (double)c; best = m > best ? m : best; }
-  }
-  const double iso = P > 0 ? best : 0.0;
-  return iso >= thresh && total >= a.min_count;                                 // caviar.py:220
+  for (int q = 0; q < 8; ++q) mce[q] = q < P ? a.mcE[(size_t)n * a.mld + q + 1] : 0.0;
+  return cm_quiescent_gate_core(P, arg, thresh, a.min_count, a.qcnt + (size_t)n * 8, mce);
 }
 
 // pava.py:9-88 with gamma = 1, last element only; literal pool walk (strict '>' merge test, pava.py:42)
@@ -835,7 +839,7 @@ int cm_launch_ndtri_table(cm_ctx* ctx, cm_problem* p, int it0, int n_it, int S, 
   (void)ctx;
   if (n_it <= 0) return CM_OK;
   const double* uexp = (rng_mode == CM_RNG_EXPLICIT) ? p->uexp : nullptr;
-  hipLaunchKernelGGL(k_ndtri_table, dim3(p->N, n_it), dim3(64), 0, st, p->keys, uexp, (const int*)p->orders_all, it0, p->N, S, p->wtab, (double*)nullptr);
+  hipLaunchKernelGGL(k_ndtri_table, dim3(p->N, n_it), dim3(64), 0, st, p->keys, uexp, (const int*)p->orders_all, it0, p->N, S, p->wtab, (double*)nullptr, p->wstat);
   if (rng_mode == CM_RNG_EXPLICIT) {
     const long long total = (long long)n_it * p->N;
     hipLaunchKernelGGL(k_invert_orders, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p->orders_all + (size_t)it0 * p->N,
@@ -846,7 +850,7 @@ int cm_launch_ndtri_table(cm_ctx* ctx, cm_problem* p, int it0, int n_it, int S, 
 }
 
 int cm_k_rng_streams_impl(cm_ctx* ctx, cm_problem* p, int it, int S, double* d_u) {
-  hipLaunchKernelGGL(k_ndtri_table, dim3(p->N, 1), dim3(64), 0, ctx->stream, p->keys, (const double*)nullptr, (const int*)nullptr, it, p->N, S, (double*)nullptr, d_u);
+  hipLaunchKernelGGL(k_ndtri_table, dim3(p->N, 1), dim3(64), 0, ctx->stream, p->keys, (const double*)nullptr, (const int*)nullptr, it, p->N, S, (double*)nullptr, d_u, (double*)nullptr);
   CM_HIP(hipGetLastError());
   return CM_OK;
 }
