@@ -306,6 +306,7 @@ static void carve_a(cm_problem* p, cm_carver& c) {           // sizes known from
   c.take(&p->row_ptr, N + 1); c.take(&p->col_ptr, K + 1); c.take(&p->mask, K); c.take(&p->pslab, 8 * N + CM_S_COUNT); c.take(&p->phi, 2 * N);
   c.take(&p->phi_cov, 4 * N); c.take(&p->phi_dead, 8 * N); c.take(&p->R, K); c.take(&p->colany, K); c.take(&p->mcE, N * CM_MAX_VALS);
   c.take(&p->rs, 4 * N); c.take(&p->act_idx, N); c.take(&p->act_inv, N); c.take(&p->n_act, 4); c.take(&p->alive, N + 1);
+  c.take(&p->tstamp, 2 * K); c.take(&p->tlist_s, 2 * K); c.take(&p->tlist_r, 2 * K); c.take(&p->tcnt, 8);
   c.take(&p->A, ld * (ld + CM_LD_PAD)); c.take(&p->X, ld * (ld + CM_LD_PAD)); c.take(&p->Lf, ld * (ld + CM_LD_PAD)); c.take(&p->Dinv, ld * CM_TILE);
   c.take(&p->rhs, 2 * ld); c.take(&p->seq_n, N); c.take(&p->seq_off, N + 1); c.take(&p->seq_pos, N); c.take(&p->seq_meta, 8);
   c.take(&p->enc_table, CM_MAX_VALS); c.take(&p->enc_flags, 8); c.take(&p->enc_row_nnz, N); c.take(&p->enc_col_cnt, K); c.take(&p->enc_cursor, K);
@@ -477,7 +478,7 @@ void cm_fill_pdev(const cm_problem* p, const cm_problem* r, int* mailbox, cm_pde
   { int l = 1; while (l < p->V) l <<= 1; d->mce_ld = l; }
   d->lam = p->lam; d->mu = p->mu; d->beta = p->beta; d->phi = p->phi; d->phi_cov = p->phi_cov; d->scal = p->scal; d->R = p->R; d->z = p->z;
   d->mcE = p->mcE; d->rs = p->rs; d->phi_dead = p->phi_dead; d->phi_cov_dead = p->phi_dead ? p->phi_dead + 2 * (size_t)p->N : nullptr; d->phi_c_dead = p->phi_dead ? p->phi_dead + 6 * (size_t)p->N : nullptr; d->pslab = p->pslab; d->mu_prior = p->mu_prior; d->beta_prior = p->beta_prior; d->phi_prior = p->phi_prior;
-  d->phi_cov_prior = p->phi_cov_prior; d->act_idx = p->act_idx; d->act_inv = p->act_inv; d->n_act = p->n_act; d->alive = p->alive; d->seq_n = p->seq_n;
+  d->phi_cov_prior = p->phi_cov_prior; d->act_idx = p->act_idx; d->act_inv = p->act_inv; d->n_act = p->n_act; d->alive = p->alive; d->tstamp = p->tstamp; d->tlist_s = p->tlist_s; d->tlist_r = p->tlist_r; d->tcnt = p->tcnt; d->seq_n = p->seq_n;
   d->seq_off = p->seq_off; d->seq_pos = p->seq_pos; d->chunk_first = p->chunk_first; d->seq_meta = p->seq_meta; d->packed = p->packed;
   d->A = p->A; d->X = p->X; d->Lf = p->Lf; d->Dinv = p->Dinv; d->rhs = p->rhs; d->mailbox = mailbox;
   d->orders_all = r->orders_all; d->inv_all = r->inv_all; d->wtab = r->wtab; d->wstat = r->wstat; d->uexp = r->uexp; d->keys = r->keys;
@@ -779,6 +780,11 @@ static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_option
   const int B = (int)s.ps.size();
   const int N = p->N, S = o->num_mc_samples, iters = o->iters;
   for (cm_problem* q : s.ps) q->ran = false;
+  s.tlist_it = s.tlist_sweep_it = -1;
+  s.lists_ok = true;                                 // (the listed column sums, cm_pdev::tstamp, rely on mu = 0 outside the active set)
+  for (int c = 0; c < B && s.lists_ok; ++c)
+    for (int i = 0; i < s.ps[c]->N; ++i)
+      if (prs[c].mu[i] != 0.0) { s.lists_ok = false; break; }
   CM_HIP(hipEventRecord(ctx->ev[0], st));
 
   // RNG streams: sweep orders of all iterations live in orders_all (uploaded, or generated below in one batched launch).  They are
@@ -891,7 +897,7 @@ static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_option
     if (phases) CM_HIP(hipEventRecord(EV(it, 1), st));
     CM_TRY(cm_launch_sweep(ctx, s, it, o, timed ? EV(it, 3) : nullptr));  // :81  update_lam
     if (timed) CM_HIP(hipEventRecord(EV(it, 4), st));
-    CM_TRY(cm_launch_stats(ctx, s, o->spont_orthogonality, cm_sweep_quiescent(ctx, s, it, o)));   // row + column statistics of the new lam
+    CM_TRY(cm_launch_stats(ctx, s, o->spont_orthogonality, cm_sweep_quiescent(ctx, s, it, o), it));   // row + column statistics of the new lam
     if (rng_deferred) {
       // The work of this iteration is enqueued and the GPU is busy with it: extend the (sequential, host-side) threefry key
       // chain (~17 us per iteration at N = 1000) and turn it into sweep orders / ndtri tables on the side stream.  Three chunks,

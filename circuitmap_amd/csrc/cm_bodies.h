@@ -45,17 +45,15 @@ __device__ __forceinline__ void cm_col_dot16(int t, int K, const double* __restr
 // Two trial columns per 16-lane segment (batches: the launch is latency-bound at full occupancy -- half the wavefronts, each with the
 // three load levels of both of its columns in flight together).  Column k and column k + ceil(K / 2); every column is summed exactly
 // as cm_col_dot16 sums it (same entries per lane, same segment reduction, same 0.0 + x), so R is bit for bit the same.
-__device__ __forceinline__ void cm_col_dot16x2(int t, int K, const double* __restrict__ mu, const double* __restrict__ lam,
-                                               const int* __restrict__ col_ptr, const int* __restrict__ csc_row,
-                                               const int* __restrict__ csc_pos, double orth, double* __restrict__ R,
-                                               uint8_t* __restrict__ colany) {
-  const int Kh = (K + 1) >> 1;
-  const int k0 = t >> 4, j = t & 15, k1 = k0 + Kh;
-  const bool ok0 = k0 < Kh, ok1 = ok0 && k1 < K;
+// (columns k0 and k1 given explicitly; ok0 / ok1: the column exists -- uniform over the segment)
+__device__ __forceinline__ void cm_col_dot16x2_k(int k0, bool ok0, int k1, bool ok1, int j, int K, const double* __restrict__ mu, const double* __restrict__ lam,
+                                                 const int* __restrict__ col_ptr, const int* __restrict__ csc_row,
+                                                 const int* __restrict__ csc_pos, double orth, double* __restrict__ R,
+                                                 uint8_t* __restrict__ colany) {
   const int beg0 = ok0 ? col_ptr[k0] : 0, end0 = ok0 ? col_ptr[k0 + 1] : 0;
   const int beg1 = ok1 ? col_ptr[k1] : 0, end1 = ok1 ? col_ptr[k1 + 1] : 0;
   if (end0 - beg0 > 16 || end1 - beg1 > 16) {        // (uniform over the segment) long columns: one after the other, the plain way
-    cm_col_dot16(t, Kh, mu, lam, col_ptr, csc_row, csc_pos, orth, R, colany);
+    if (ok0) cm_col_dot16((k0 << 4) | j, K, mu, lam, col_ptr, csc_row, csc_pos, orth, R, colany);
     if (ok1) cm_col_dot16((k1 << 4) | j, K, mu, lam, col_ptr, csc_row, csc_pos, orth, R, colany);   // (DPP sources lie inside the segment)
     return;
   }
@@ -80,6 +78,41 @@ __device__ __forceinline__ void cm_col_dot16x2(int t, int K, const double* __res
     if (ok0) { R[k0] = s0; if (colany) colany[k0] = (uint8_t)((any & 1) != 0); }
     if (ok1) { R[k1] = s1; if (colany) colany[k1] = (uint8_t)((any & 2) != 0); }
   }
+}
+__device__ __forceinline__ void cm_col_dot16x2(int t, int K, const double* __restrict__ mu, const double* __restrict__ lam,
+                                               const int* __restrict__ col_ptr, const int* __restrict__ csc_row,
+                                               const int* __restrict__ csc_pos, double orth, double* __restrict__ R,
+                                               uint8_t* __restrict__ colany) {
+  const int Kh = (K + 1) >> 1;
+  const int k0 = t >> 4, k1 = k0 + Kh;
+  const bool ok0 = k0 < Kh, ok1 = ok0 && k1 < K;
+  cm_col_dot16x2_k(k0, ok0, k1, ok1, t & 15, K, mu, lam, col_ptr, csc_row, csc_pos, orth, R, colany);
+}
+
+// LISTED trials (cm_pdev::tstamp ...): the column sums of the trials on the list(s) -- every listed column exactly as cm_col_dot16 sums it -- in a
+// stride loop over 16-lane segments; `seg` = this segment's index among `nseg` (both uniform over the segment).  ls / ns: the list k_stats left,
+// lr / nr: the trials of the rows the pre-sweep revived (nr = 0: none).
+__device__ __forceinline__ void cm_col_dot16_listed(int seg, int nseg, int j, const int* __restrict__ ls, int ns, const int* __restrict__ lr, int nr,
+                                                    int K, const double* __restrict__ mu, const double* __restrict__ lam,
+                                                    const int* __restrict__ col_ptr, const int* __restrict__ csc_row, const int* __restrict__ csc_pos,
+                                                    double orth, double* __restrict__ R, uint8_t* __restrict__ colany) {
+  const int cnt = ns + nr, half = (cnt + 1) >> 1;   // two listed trials per segment (entries i and i + half), their load levels in flight together
+  for (int i = seg; i < half; i += nseg) {
+    const int i1 = i + half;
+    const int k0 = i < ns ? ls[i] : lr[i - ns];
+    const bool ok1 = i1 < cnt;
+    const int k1 = ok1 ? (i1 < ns ? ls[i1] : lr[i1 - ns]) : 0;
+    cm_col_dot16x2_k(k0, true, k1, ok1, j, K, mu, lam, col_ptr, csc_row, csc_pos, orth, R, colany);
+  }
+}
+// ... and zero for every trial that is not listed: one thread per trial.  stamp_lo .. stamp_hi: the stamps that mean "listed".
+__device__ __forceinline__ void cm_col_zero_unlisted(int k, int K, const int* __restrict__ stamp, int stamp_lo, int stamp_hi,
+                                                     double* __restrict__ R, uint8_t* __restrict__ colany) {
+  if (k >= K) return;
+  const int st = stamp[k];
+  if (st >= stamp_lo && st <= stamp_hi) return;
+  R[k] = 0.0;
+  if (colany) colany[k] = 0;
 }
 
 // The single-workgroup phases run on the first CM_POST_THREADS threads of their workgroup, whatever its launch size (the other

@@ -177,6 +177,7 @@ struct cm_problem {
   int32_t* act_inv = nullptr; // [N] neuron -> compact index or -1
   int32_t* n_act = nullptr;   // [4] device: N_a, flags
   int32_t* alive = nullptr;   // [1 + N] count + list of rows with lam != 0 (batches: work list of the per-neuron role of k_iter_mid)
+  int32_t *tstamp = nullptr, *tlist_s = nullptr, *tlist_r = nullptr, *tcnt = nullptr;   // listed trials of the column sums (cm_pdev)
   int32_t* order = nullptr;   // sweep order of the current iteration (points into orders_all)
   int32_t* orders_all = nullptr; // [iters*N] sweep orders of every iteration (device generated, or the explicit stream)
   int32_t* orders_tmp = nullptr; // [iters*N] ping-pong buffer of the shuffle rounds
@@ -235,6 +236,11 @@ struct cm_pdev {
   const double *pslab, *mu_prior, *beta_prior, *phi_prior, *phi_cov_prior;
   int *act_idx, *act_inv, *n_act, *seq_n, *seq_off, *seq_pos, *chunk_first, *seq_meta;
   int* alive;                    // [1 + N] batches: number and list of the rows with lam != 0 after the sweep (k_stats)
+  // Trials the column sums R = lam^T mu / colany have to visit (quiescent regime): only trials of rows with lam != 0 can contribute, and
+  // k_stats walks exactly those rows.  Double-buffered by iteration parity q = it & 1: tstamp[q K + k] = 2 it if k_stats(it - 1) listed
+  // trial k for iteration it (tlist_s[q K + ..], tcnt[q] entries), 2 it + 1 if the pre-sweep of iteration it added it for a row it
+  // revived (tlist_r[q K + ..], tcnt[2 + q] entries), anything else: not listed -- its sums are zero.
+  int *tstamp, *tlist_s, *tlist_r, *tcnt;
   void* packed;
   double *A, *X, *Lf, *Dinv, *rhs;
   int* mailbox;                  // this circuit's 64-bit word in host-mapped pinned memory (nullptr: no mailbox)
@@ -307,6 +313,9 @@ struct cm_set {
   long long nnz_max = 0, nnz_min = 0;
   long long fact_launches = 0, fact_tile_updates = 0, fact_panel_tiles = 0, fact_tri_tiles = 0, fact_products = 0, inv_products = 0;   // counters of the tiled solves (cm_timings)
   bool last_fact = false;                // the last cm_solve_launch ran a factorisation (and recorded its event pair)
+  bool lists_ok = false;                 // every prior mean of the set is zero: a row outside the active set has mu = 0, only rows with lam != 0 feed R (run_set)
+  int tlist_it = -1;                     // iteration for which k_stats listed the trials of the rows with lam != 0 (-1: no list)
+  int tlist_sweep_it = -1;               // iteration whose pre-sweep ran on that list (and appended the trials of revived rows)
   std::vector<int> na;                   // last active-set sizes read from the mailboxes
   int na_max = 0;
 };
@@ -483,7 +492,7 @@ int cm_launch_rng(cm_ctx* ctx, cm_problem* p, int it0, int n_it, hipStream_t st)
 int cm_launch_sweep(cm_ctx* ctx, cm_set& s, int it, const cm_options* o, hipEvent_t mid, int table_it = -1);   // table_it: iteration whose sweep order is used (default: it)
 int cm_launch_sum_y(cm_ctx* ctx, cm_set& s);
 int cm_sweep_variant(const cm_set& s, int rows_hint);
-int cm_launch_stats(cm_ctx* ctx, cm_set& s, double spont_orthogonality, int quiescent = 0);   // quiescent: cm_sweep_quiescent() of the sweep just launched
+int cm_launch_stats(cm_ctx* ctx, cm_set& s, double spont_orthogonality, int quiescent = 0, int it = -1);   // quiescent: cm_sweep_quiescent() of the sweep just launched
 int cm_sweep_quiescent(const cm_ctx* ctx, const cm_set& s, int it, const cm_options* o);
 int cm_launch_post_single(cm_ctx* ctx, cm_set& s, int it, const cm_options* o, int do_sigma);
 int cm_wait_active(cm_ctx* ctx, cm_set& s);

@@ -13,8 +13,9 @@
 //                     colany_k = any_n lam_nk >= spont_orthogonality
 // ------------------------------------------------------------------------------------------------
 // statistics of one row by one wavefront: rs[n] = {sum lam, sum lam^2, sum y lam, sum lam (1 - lam) or -1 for an all-zero row}
+// mark_it >= 0: a row with lam != 0 also puts its trials on the list of iteration mark_it (cm_pdev::tstamp: first writer of a stamp appends)
 template <bool BATCH>
-__device__ __forceinline__ void stats_row(const cm_pdev& p, const double* __restrict__ lam, int n, int lane) {
+__device__ __forceinline__ void stats_row(const cm_pdev& p, const double* __restrict__ lam, int n, int lane, int mark_it = -1) {
     const int* __restrict__ row_ptr = p.row_ptr;
   const double* __restrict__ ye = p.ye;               // y[col[e]], entry by entry: contiguous like lam
   double s1 = 0.0, s2 = 0.0, sy = 0.0, d = 0.0;
@@ -39,13 +40,23 @@ __device__ __forceinline__ void stats_row(const cm_pdev& p, const double* __rest
     // (a few dozen per circuit in the steady state), counter zeroed by k_init_state / k_presweep
     if (BATCH && any) { const int pos = atomicAdd(&p.alive[0], 1); if (pos < p.N) p.alive[1 + pos] = n; }
   }
+  if (mark_it >= 0 && any) {
+    const int q = mark_it & 1, K = p.K, stamp = 2 * mark_it;
+    for (int e = row_ptr[n] + lane; e < row_ptr[n + 1]; e += CM_WAVE) {
+      const int k = p.col[e];
+      if (atomicExch(&p.tstamp[q * K + k], stamp) != stamp) p.tlist_s[q * K + atomicAdd(&p.tcnt[q], 1)] = k;
+    }
+  }
 }
 
 // `quiescent` (set with the pre-sweep's, cm_launch_sweep): rows are screened one per THREAD -- a row that was all zero before the sweep, was
 // not on the chain (mu == 0) and was not revived by the pre-sweep is still all zero and keeps its statistics {0, 0, 0, -1}; only the
 // others (a few dozen per circuit in the steady state) are re-read, one wavefront each.
+// rows screened per workgroup in the quiescent regime: few enough that each of the four wavefronts re-reads (and lists the trials of) about one row --
+// with 256 rows per workgroup a wavefront walked three or four rows one after the other, five dependent round trips each
+#define CM_STATS_QROWS 64
 template <bool BATCH>
-__global__ __launch_bounds__(256) void k_stats(cm_parg<BATCH> pa, int nbR, double orth, int quiescent) {
+__global__ __launch_bounds__(256) void k_stats(cm_parg<BATCH> pa, int nbR, double orth, int quiescent, int nbL, int list_it, int mark_it) {
   const cm_pdev& p = pa.get();
   const double* __restrict__ lam = p.lam;
   if (quiescent && (int)blockIdx.x < nbR) {
@@ -53,15 +64,15 @@ __global__ __launch_bounds__(256) void k_stats(cm_parg<BATCH> pa, int nbR, doubl
     __shared__ int qn;
     if (threadIdx.x == 0) qn = 0;
     __syncthreads();
-    const int n = (int)blockIdx.x * 256 + (int)threadIdx.x;
-    if (n < p.N) {
+    const int n = (int)blockIdx.x * CM_STATS_QROWS + (int)threadIdx.x;
+    if ((int)threadIdx.x < CM_STATS_QROWS && n < p.N) {
       const bool revived = p.touch[n] != 0;
       if (revived) p.touch[n] = 0;
       if (revived || p.rs[(size_t)n * 4 + 3] >= 0.0 || p.seq_pos[n] >= 0) qlist[atomicAdd(&qn, 1)] = n;
     }
     __syncthreads();
     const int cnt = qn;
-    for (int i = threadIdx.x / CM_WAVE; i < cnt; i += 4) stats_row<BATCH>(p, lam, qlist[i], threadIdx.x % CM_WAVE);
+    for (int i = threadIdx.x / CM_WAVE; i < cnt; i += 4) stats_row<BATCH>(p, lam, qlist[i], threadIdx.x % CM_WAVE, mark_it);
     return;
   }
   if (BATCH && (int)blockIdx.x < nbR) {
@@ -119,6 +130,15 @@ __global__ __launch_bounds__(256) void k_stats(cm_parg<BATCH> pa, int nbR, doubl
     const int lane = threadIdx.x % CM_WAVE;
     if (n >= p.N) return;
     stats_row<BATCH>(p, lam, n, lane);
+  } else if (list_it >= 0) {
+    // listed trials (the pre-sweep of this iteration ran on the list too and added the trials of the rows it revived): blocks [nbR, nbR + nbL)
+    // walk the two lists, the blocks behind them zero every trial that is on neither
+    const int q = list_it & 1, K = p.K, b = (int)blockIdx.x - nbR;
+    if (b < nbL)
+      cm_col_dot16_listed(b * (int)(blockDim.x >> 4) + (int)(threadIdx.x >> 4), nbL * (int)(blockDim.x >> 4), threadIdx.x & 15, p.tlist_s + q * K, p.tcnt[q],
+                          p.tlist_r + q * K, p.tcnt[2 + q], K, p.mu, lam, p.col_ptr, p.csc_row, p.csc_pos, orth, p.R, p.colany);
+    else
+      cm_col_zero_unlisted((b - nbL) * (int)blockDim.x + (int)threadIdx.x, K, p.tstamp + q * K, 2 * list_it, 2 * list_it + 1, p.R, p.colany);
   } else {
     const int t = ((int)blockIdx.x - nbR) * blockDim.x + threadIdx.x;
     if (BATCH) cm_col_dot16x2(t, p.K, p.mu, lam, p.col_ptr, p.csc_row, p.csc_pos, orth, p.R, p.colany);
@@ -135,12 +155,27 @@ __global__ __launch_bounds__(CM_POST_THREADS) void k_post_single(cm_parg<false> 
 }
 
 // Row + column statistics of the current lam.
-int cm_launch_stats(cm_ctx* ctx, cm_set& s, double spont_orthogonality, int quiescent) {
+int cm_launch_stats(cm_ctx* ctx, cm_set& s, double spont_orthogonality, int quiescent, int it) {
   const cm_problem* p = s.lead;
-  const int nbR = quiescent ? (p->N + 255) / 256 : (s.B > 1 ? (p->N + 15) / 16 : (p->N + 3) / 4);      // one wave per row (batches: per four rows); screened: 256 rows per block
-  const int nbC = ((s.B > 1 ? (p->K + 1) / 2 : p->K) * 16 + 255) / 256;   // 16 lanes per trial column (batches: per two columns)
-  CM_LAUNCH_SET(k_stats, s, nbR + nbC, 256, 0, ctx->stream, nbR, spont_orthogonality, quiescent);
+  const int nbR = quiescent ? (p->N + CM_STATS_QROWS - 1) / CM_STATS_QROWS : (s.B > 1 ? (p->N + 15) / 16 : (p->N + 3) / 4);      // one wave per row (batches: per four rows); screened: CM_STATS_QROWS rows per block
+  int nbC = ((s.B > 1 ? (p->K + 1) / 2 : p->K) * 16 + 255) / 256;   // 16 lanes per trial column (batches: per two columns)
+  // Listed trials (cm_pdev::tstamp): in the quiescent regime the row role walks exactly the rows with lam != 0 and leaves the list of their trials
+  // for the next iteration (mark_it); the column role uses this iteration's list if the pre-sweep ran on it (and completed it with the trials of
+  // the rows it revived).  Grid for the listed walk: the trials the rows of the largest active set can touch, with slack for revived rows --
+  // a stride loop takes whatever exceeds it.
+  static const bool no_lists = getenv("CAVIAR_HIP_NO_TRIAL_LISTS") != nullptr;   // diagnostic: every column, every iteration
+  const int mark_it = (quiescent && it >= 0 && !no_lists && s.lists_ok) ? it + 1 : -1;
+  const int list_it = (quiescent && it >= 0 && s.tlist_it == it && s.tlist_sweep_it == it) ? it : -1;
+  int nbL = 0;
+  if (list_it >= 0) {
+    const long long per_row = (s.nnz_max + p->N - 1) / p->N;
+    const long long est = std::min<long long>(p->K, per_row * (long long)s.na_max * 3 / 2 + 64);
+    nbL = (int)((((est + 1) / 2) * 16 + 255) / 256);                 // two listed trials per 16-lane segment
+    nbC = nbL + (p->K + 255) / 256;
+  }
+  CM_LAUNCH_SET(k_stats, s, nbR + nbC, 256, 0, ctx->stream, nbR, spont_orthogonality, quiescent, nbL, list_it, mark_it);
   CM_HIP(hipGetLastError());
+  s.tlist_it = mark_it;
   return CM_OK;
 }
 

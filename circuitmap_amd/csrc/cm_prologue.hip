@@ -399,7 +399,8 @@ __global__ __launch_bounds__(256) void k_init_state(cm_parg<BATCH> pa, double th
   if (i < 2 * (long long)N) p.phi[i] = pslab[2 * (size_t)N + i];
   if (i < 4 * (long long)N) p.phi_cov[i] = pslab[4 * (size_t)N + i];
   if (i < 4) p.n_act[i] = 0;
-  if (i < 8) p.seq_meta[i] = 0;
+  if (i < 8) { p.seq_meta[i] = 0; p.tcnt[i] = 0; }
+  if (i < 2 * (long long)K) p.tstamp[i] = -1;                 // (stamps are iteration numbers: those of an earlier run must not be taken for this one's)
   if (i == 0) p.alive[0] = 0;
 }
 template <bool BATCH>
@@ -460,7 +461,7 @@ static int launch_mask_counts(cm_ctx* ctx, cm_set& s) {
 int cm_launch_init_state(cm_ctx* ctx, cm_set& s, double y_xcorr_thresh) {
   hipStream_t st = ctx->stream;
   const cm_problem* p = s.lead;
-  const long long n = std::max<long long>(std::max<long long>(4LL * p->N, p->K), std::max<long long>(s.nnz_max, 8));
+  const long long n = std::max<long long>(std::max<long long>(4LL * p->N, 2LL * p->K), std::max<long long>(s.nnz_max, 8));
   CM_LAUNCH_SET(k_init_state, s, (unsigned)((n + 255) / 256), 256, 0, st, y_xcorr_thresh);
   CM_LAUNCH_SET(k_sum_y_set, s, 1, 1024, 0, st);
   CM_HIP(hipGetLastError());

@@ -130,6 +130,7 @@ __global__ __launch_bounds__(64) void k_ndtri_table(const uint32_t* __restrict__
 // ------------------------------------------------------------------------------------------------
 struct SweepArgs {
   const int* qcnt; const double* rs; uint8_t* touch; int quiescent_ok;   // closed-form gate of all-zero rows (quiescent_gate)
+  int *lst_stamp, *lst_r, *lst_cnt; int lst_it;                          // listed trials (cm_pdev::tstamp), this iteration's parity; lst_it < 0: no list
   int mld;                                                                // row stride of mcE
   const int* row_ptr; const int* col; const uint8_t* grp; const int* rowcnt;
   const double* y; const uint8_t* mask; const double* ye; const uint8_t* me; const double* mu; const double* beta; const double* mcE; const double* scal;
@@ -144,6 +145,7 @@ __device__ __forceinline__ SweepArgs sweep_args(const cm_pdev& p, int gated, dou
   a.y = p.y; a.mask = p.mask; a.ye = p.ye; a.me = p.me; a.mu = p.mu; a.beta = p.beta; a.mcE = p.mcE; a.scal = p.scal;
   a.lam = p.lam; a.V = p.V; a.gated = gated; a.msrmp = msrmp; a.min_count = min_count;
   a.qcnt = p.qcnt; a.rs = p.rs; a.touch = p.touch; a.mld = p.mce_ld;
+  a.lst_stamp = nullptr; a.lst_r = nullptr; a.lst_cnt = nullptr; a.lst_it = -1;
   a.quiescent_ok = gated && p.V - 1 <= 8 && p.V >= 1 && p.max_row_len < 65536 && p.vals[0] == 0.0;   // (a stimulus matrix without zeros keeps value-0 entries in the rows: the plain path)
   return a;
 }
@@ -359,6 +361,13 @@ __device__ __forceinline__ void sweep_indep_row(const SweepArgs& a, int n, int l
     if (!quiescent_gate(a, n, sig, thresh)) return;  // stays zero: nothing to write
     decided = true;
     if (lane == 0) a.touch[n] = 1;
+    if (a.lst_it >= 0) {                             // the column statistics after the sweep must visit this row's trials: list those not listed yet
+      const int lo = 2 * a.lst_it;
+      for (int e = a.row_ptr[n] + lane; e < a.row_ptr[n + 1]; e += CM_WAVE) {
+        const int k = a.col[e], old = a.lst_stamp[k];
+        if (old < lo && atomicCAS(&a.lst_stamp[k], old, lo + 1) == old) a.lst_r[atomicAdd(a.lst_cnt, 1)] = k;
+      }
+    }
   }
   const int beg = a.row_ptr[n], len = a.row_ptr[n + 1] - beg;
   if (!LEAN && len > CM_WAVE) {
@@ -517,12 +526,13 @@ __device__ __forceinline__ void seq_scan_body(const int* __restrict__ order, con
 // rows: a handful) are walked by the workgroup's wavefronts.  1 workgroup per 1024 rows instead of 32 or 64.
 template <bool BATCH, bool LEAN>
 __global__ __launch_bounds__(1024) void k_presweep(cm_parg<BATCH> pa, int it, int gated, double msrmp, double min_count, int nbI, int nbC,
-                                                    int roles, int gran, int quiescent) {
+                                                    int roles, int gran, int quiescent, int nbL, int list_it) {
   __shared__ double scr_all[16][3 * CM_MAX_VALS];
   __shared__ int wsum[2][16];
   __shared__ int carry[2];
   const cm_pdev& p = pa.get();
-  const SweepArgs a = sweep_args(p, gated, msrmp, min_count);
+  SweepArgs a = sweep_args(p, gated, msrmp, min_count);
+  if (list_it >= 0) { const int q = list_it & 1; a.lst_stamp = p.tstamp + q * p.K; a.lst_r = p.tlist_r + q * p.K; a.lst_cnt = p.tcnt + 2 + q; a.lst_it = list_it; }
   const int N = p.N;
   const int b = blockIdx.x;
   if (b < nbI) {
@@ -553,11 +563,23 @@ __global__ __launch_bounds__(1024) void k_presweep(cm_parg<BATCH> pa, int it, in
     }
   } else if (b < nbI + nbC) {
     if (!(roles & 2)) return;
+    if (list_it >= 0) {
+      // listed trials: only the trials of rows with lam != 0 (k_stats of the last iteration listed them) can carry a row with mu != 0; the
+      // blocks behind the walk zero every other trial.  (A trial a revived row adds during this launch has mu = 0 on all its rows: zero too.)
+      const int q = list_it & 1, K = p.K, bb = b - nbI;
+      if (bb < nbL)
+        cm_col_dot16_listed(bb * 64 + (int)(threadIdx.x >> 4), nbL * 64, threadIdx.x & 15, p.tlist_s + q * K, p.tcnt[q], nullptr, 0, K, a.mu, a.lam,
+                            p.col_ptr, p.csc_row, p.csc_pos, 0.0, p.R, nullptr);
+      else
+        cm_col_zero_unlisted((bb - nbL) * 1024 + (int)threadIdx.x, K, p.tstamp + q * K, 2 * list_it, 2 * list_it, p.R, nullptr);
+      return;
+    }
     if (BATCH) cm_col_dot16x2((b - nbI) * 1024 + threadIdx.x, p.K, a.mu, a.lam, p.col_ptr, p.csc_row, p.csc_pos, 0.0, p.R, nullptr);
     else cm_col_dot16((b - nbI) * 1024 + threadIdx.x, p.K, a.mu, a.lam, p.col_ptr, p.csc_row, p.csc_pos, 0.0, p.R, nullptr);
   } else {
     if (!(roles & 4)) return;
     if (BATCH && threadIdx.x == 0) p.alive[0] = 0;     // list of rows with lam != 0 that k_stats rebuilds after the sweep
+    if (threadIdx.x == 0) { const int qn = (it + 1) & 1; p.tcnt[qn] = 0; p.tcnt[2 + qn] = 0; }   // the trial lists of the next iteration start empty
     seq_scan_body(p.orders_all + (size_t)it * N, a.mu, a.row_ptr, N, p.seq_n, p.seq_off, p.chunk_first, p.seq_meta, p.seq_pos, gran, wsum, carry);
   }
 }
@@ -884,10 +906,21 @@ int cm_launch_sweep(cm_ctx* ctx, cm_set& s, int it, const cm_options* o, hipEven
   // one row per THREAD in the first role once the gate is on and fewer than half of the rows are active (any choice is correct)
   const int quiescent = table_it < 0 ? cm_sweep_quiescent(ctx, s, it, o) : 0;
   const int nbIq = quiescent ? (N + 1023) / 1024 : nbI;
-  for (int pass = 0; pass < (split ? 3 : 1); ++pass) {
-    if (lean) CM_LAUNCH_SET_T(k_presweep, (true), s, nbIq + nbC + 1, 1024, 0, st, (table_it < 0 ? it : table_it), gated, msrmp, min_count, nbIq, nbC, split ? (1 << pass) : 7, gran, quiescent);
-    else CM_LAUNCH_SET_T(k_presweep, (false), s, nbIq + nbC + 1, 1024, 0, st, (table_it < 0 ? it : table_it), gated, msrmp, min_count, nbIq, nbC, split ? (1 << pass) : 7, gran, quiescent);
+  // listed trials (cm_pdev::tstamp): k_stats of the last iteration left the trials of the rows with lam != 0 -- the column sums walk those (at most
+  // the trials the rows of the active set can touch; a stride loop takes what exceeds the grid) and zero the rest
+  const int list_it = (quiescent && s.tlist_it == it && it >= 0) ? it : -1;
+  int nbL = 0, nbCk = nbC;
+  if (list_it >= 0) {
+    const long long per_row = (s.nnz_max + N - 1) / N;
+    const long long est = std::min<long long>(p->K, per_row * (long long)s.na_max * 5 / 4 + 64);
+    nbL = (int)(((est + 1) / 2 + 63) / 64);                         // two listed trials per 16-lane segment
+    nbCk = nbL + (p->K + 1023) / 1024;
   }
+  for (int pass = 0; pass < (split ? 3 : 1); ++pass) {
+    if (lean) CM_LAUNCH_SET_T(k_presweep, (true), s, nbIq + nbCk + 1, 1024, 0, st, (table_it < 0 ? it : table_it), gated, msrmp, min_count, nbIq, nbCk, split ? (1 << pass) : 7, gran, quiescent, nbL, list_it);
+    else CM_LAUNCH_SET_T(k_presweep, (false), s, nbIq + nbCk + 1, 1024, 0, st, (table_it < 0 ? it : table_it), gated, msrmp, min_count, nbIq, nbCk, split ? (1 << pass) : 7, gran, quiescent, nbL, list_it);
+  }
+  s.tlist_sweep_it = list_it;
   static const bool bad_ticket = getenv("CAVIAR_HIP_TEST_BAD_TICKET") != nullptr;   // test hook: exercises the bounded wait + error report of the ticketed chain
   const int pack_rows = s.B > 1 ? std::min(N, std::max(64, 2 * s.na_max)) : N;      // (one circuit: the N / 4 workgroups are not what its 5 us are made of)
   CM_LAUNCH_SET(k_seq_pack, s, (pack_rows + 3) / 4, 256, 0, st, gated, msrmp, min_count, par ? (bad_ticket ? 2 : 1) : 0);
