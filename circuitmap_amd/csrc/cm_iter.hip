@@ -23,7 +23,7 @@
 
 struct IterDyn {     // what changes from iteration to iteration (common to all circuits of a batch)
   int it, max_iters; double penalty, scale_factor, tol; int do_sigma, seq, do_solve, stage_ok, do_phi, do_mc, S, roles, nx, explicit_rng, skip_dead;
-  int mc_screen; double msrmp, min_count;   // k_mc_dead: the next sweep is gated -> all-zero rows whose gate cannot pass need no Monte-Carlo logit
+  int mc_screen, dead_sep; double msrmp, min_count;   // k_mc_dead: the next sweep is gated -> all-zero rows whose gate cannot pass need no Monte-Carlo logit
   long long* dbg;      // diagnostic (CAVIAR_HIP_TRACE_BLOCK0): device clock at the phase boundaries of block 0, 8 words per launch
 };
 
@@ -251,6 +251,7 @@ __global__ __launch_bounds__(CM_ITER_THREADS) void k_iter_mid(cm_parg<BATCH> pa,
   double dc0 = 0.0, dc1 = 0.0;
   if (a.do_phi && p.rs[(size_t)n * 4 + 3] < 0.0) {
     // the row is identically zero (k_stats of this iteration): its update_phi is the per-run constant of this neuron
+    if (BATCH && a.dead_sep) return;                   // ... and k_mc_dead, launched behind this kernel, takes it (screening, one row per thread)
     dead_row = true;
     dead_phi_copy(p, n, lane, pc, &dc0, &dc1);
   } else if (a.do_phi) {
@@ -343,6 +344,10 @@ static int launch_iter2(cm_ctx* ctx, cm_set& s, const IterDyn& a0, size_t lds, i
   } else {
     CM_LAUNCH_SET_T(k_iter_mid, (SEG, FULLMC), s, blocks, threads, lds, ctx->stream, a0);
     if (between) CM_HIP(hipEventRecord(between, ctx->stream));
+    if (a0.dead_sep && !FULLMC && s.B > 1) {
+      CM_TRY(cm_raise_lds(ctx, CM_LDS_MC_DEAD_B, reinterpret_cast<const void*>(k_mc_dead<true>), 4 * lds_waves, 48 * 1024));
+      CM_LAUNCH_SET(k_mc_dead, s, (s.lead->N + 255) / 256, 256, 4 * lds_waves, ctx->stream, a0, 256);
+    }
   }
   CM_HIP(hipGetLastError());
   return CM_OK;
@@ -375,6 +380,9 @@ int cm_launch_iter_mid(cm_ctx* ctx, cm_set& s, int it, int iters, int S, int rng
   static const bool no_screen = getenv("CAVIAR_HIP_NO_MC_SCREEN") != nullptr;     // diagnostic: every all-zero row through the exact Monte-Carlo logit
   a.mc_screen = (!no_screen && nxt > o->delay_spont_est) ? 1 : 0;                   // (the sweep of iteration nxt applies the gate: cm_launch_sweep)
   a.msrmp = o->msrmp; a.min_count = o->minimum_spike_count;
+  // batches, the gated iterations before the listed regime: every row still has its wavefront (the rows with lam != 0 are too many for a list),
+  // but the all-zero ones -- most rows from the first gated sweep on -- go to k_mc_dead, where nearly all of them are screened
+  a.dead_sep = (s.B > 1 && do_phi && it >= 0 && roles == 3 && a.mc_screen && !a.skip_dead && nxt < iters) ? 1 : 0;
   a.dbg = (ctx->dbg_block0 && it >= 0 && it < 64) ? ctx->dbg_block0 + 8 * it : nullptr;
   const int threads = s.B == 1 ? CM_ITER_THREADS : CM_ITER_THREADS_BATCH;
   const int waves = threads / CM_WAVE;
