@@ -164,7 +164,11 @@ int cm_launch_stats(cm_ctx* ctx, cm_set& s, double spont_orthogonality, int quie
   // the rows it revived).  Grid for the listed walk: the trials the rows of the largest active set can touch, with slack for revived rows --
   // a stride loop takes whatever exceeds it.
   static const bool no_lists = getenv("CAVIAR_HIP_NO_TRIAL_LISTS") != nullptr;   // diagnostic: every column, every iteration
-  const int mark_it = (quiescent && it >= 0 && !no_lists && s.lists_ok) ? it + 1 : -1;
+  long long na_sum = 0;
+  for (int v : s.na) na_sum += v;
+  const long long rows_mean = s.na.empty() ? p->N : (na_sum + (long long)s.na.size() - 1) / (long long)s.na.size();
+  const bool few = ((s.nnz_max + p->N - 1) / p->N) * rows_mean * 2 <= p->K || getenv("CAVIAR_HIP_TEST_TRIAL_LISTS") != nullptr;     // the rows with lam != 0 touch at most half of the trials
+  const int mark_it = (quiescent && it >= 0 && !no_lists && s.lists_ok && few) ? it + 1 : -1;
   const int list_it = (quiescent && it >= 0 && s.tlist_it == it && s.tlist_sweep_it == it) ? it : -1;
   int nbL = 0;
   if (list_it >= 0) {

@@ -702,6 +702,42 @@ def test_create_batch_and_fetch_batch(ctx):
     ctx.release_cache()                                                  # the pool hands everything back
 
 
+def test_listed_column_sums_never_matter(ctx, monkeypatch):
+    """The column sums R = lam^T mu / colany over the LISTED trials (k_stats lists the trials of the rows with lam != 0, the pre-sweep adds those of
+    revived rows, everything else is zeroed) give bitwise the results of the walk over all columns: forced on for a small shape
+    (CAVIAR_HIP_TEST_TRIAL_LISTS; by default the lists are used from K = 1536 on), off (CAVIAR_HIP_NO_TRIAL_LISTS is read once per process, so the
+    reference here is the single fit of every circuit, which at this shape runs without lists), with a non-zero prior mean (lists must stay off:
+    every row then has mu != 0) and against the oracle."""
+    from circuitmap_amd.optimise.caviar import run_batch
+    from oracle import caviar_oracle as co
+    N, K, B = 200, 400, 8
+    pri = default_priors(N)
+    opts = dict(iters=20, seed=1)
+    probs, host = _device_circuits(ctx, N, K, B, 5200, host_copy_of=(0,))
+    singles = []
+    for q in probs:
+        q.run(*prior_args(pri), **opts)
+        singles.append(q.fetch())
+    monkeypatch.setenv("CAVIAR_HIP_TEST_TRIAL_LISTS", "1")
+    run_batch(probs, pri, **opts)
+    for c, q in enumerate(probs):
+        _assert_same_fit(q.fetch(), singles[c], "listed trials, circuit %d" % c)
+    probs[0].run(*prior_args(pri), **opts)                                # one circuit with lists
+    _assert_same_fit(probs[0].fetch(), singles[0], "listed trials, single fit")
+    ref = co.caviar(host[0][0], host[0][1], *prior_args(pri), literal=False, **opts)
+    for i, nm in enumerate(OUT_NAMES):
+        assert rel_err(singles[0][i], ref[i]) < 1e-6, nm
+    pri2 = dict(pri, mu=0.5 * np.ones(N))                                 # prior mean != 0: all rows carry mu != 0, the lists must not be used
+    run_batch(probs[:2], pri2, **opts)
+    with_env = [q.fetch() for q in probs[:2]]
+    monkeypatch.delenv("CAVIAR_HIP_TEST_TRIAL_LISTS")
+    run_batch(probs[:2], pri2, **opts)
+    for c in range(2):
+        _assert_same_fit(probs[c].fetch(), with_env[c], "prior mean != 0, circuit %d" % c)
+    for q in probs:
+        q.close()
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_run_batch_xcd_placement_never_matters(ctx, monkeypatch, mode):
     """CAVIAR_HIP_XCD_MODE = 0 (plain grid), 1 (interleaved), 2 (circuit-major) give bitwise the results of the default mode 3:
