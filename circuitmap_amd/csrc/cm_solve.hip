@@ -56,10 +56,10 @@
 __host__ __device__ static inline size_t build_prec_lds(int ld) { return (size_t)ld * sizeof(double) + CM_BP_ITEMS * (sizeof(double) + sizeof(int)); }
 
 template <bool BATCH>
-__global__ __launch_bounds__(64) void k_build_precision(cm_parg<BATCH> pa, int na_arg, int skip_own) {
+__global__ __launch_bounds__(64) void k_build_precision(cm_parg<BATCH> pa, int na_arg, int skip_own, int row0, int acc_len) {
   CM_SOLVE_PROLOGUE(2)
   const int n_act = na;
-  if ((int)blockIdx.x >= nrow) return;
+  if (row0 + (int)blockIdx.x >= nrow) return;
   const double* __restrict__ lam = p.lam;
   const int* __restrict__ row_ptr = p.row_ptr;
   const int* __restrict__ col = p.col;
@@ -74,12 +74,12 @@ __global__ __launch_bounds__(64) void k_build_precision(cm_parg<BATCH> pa, int n
   const double* __restrict__ beta_prior = p.beta_prior;
   double* __restrict__ A = p.A;
   double* __restrict__ rhs = p.rhs;
-  extern __shared__ double acc[];                  // [ld] accumulator row, then the staged items
-  double* il = acc + ld;                           // [CM_BP_ITEMS] lam of the column mate
+  extern __shared__ double acc[];                  // [acc_len] accumulator row (the launch covers rows whose diagonal tile ends at or before acc_len), then the staged items
+  double* il = acc + acc_len;                      // [CM_BP_ITEMS] lam of the column mate
   int* ib = reinterpret_cast<int*>(il + CM_BP_ITEMS);   // [CM_BP_ITEMS] its active index (-1: not in the active set)
   __shared__ int s_off[CM_WAVE], s_cs[CM_WAVE];
   __shared__ double s_le[CM_WAVE];
-  const int a = blockIdx.x;
+  const int a = row0 + (int)blockIdx.x;
   const int lane = threadIdx.x;
   double* Arow = A + (size_t)a * ld;
   // Only the tiles on and below the diagonal are ever read (the factorisation works on the lower triangle, the inverse uses the
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(64) void k_build_precision(cm_parg<BATCH> pa, int n
         const int c0 = s_cs[j0], c1 = c0 + __builtin_amdgcn_readlane(cl, j0);
         for (int ce = c0 + lane; ce < c1; ce += CM_WAVE) {
           const int b = act_inv[csc_row[ce]];
-          if (b >= 0) acc[b] = fma(lj, lam[csc_pos[ce]], acc[b]);
+          if (b >= 0 && b < b_end) acc[b] = fma(lj, lam[csc_pos[ce]], acc[b]);   // (columns beyond the diagonal tile are never stored: not accumulated either)
         }
         __builtin_amdgcn_wave_barrier();
         ++j0;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(64) void k_build_precision(cm_parg<BATCH> pa, int n
         const double lj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(le), j), __builtin_amdgcn_readlane(__double2loint(le), j));
         for (int q = lane; q < c; q += CM_WAVE) {
           const int b = ib[o + q];
-          if (b >= 0) acc[b] = fma(lj, il[o + q], acc[b]);
+          if (b >= 0 && b < b_end) acc[b] = fma(lj, il[o + q], acc[b]);
         }
         __builtin_amdgcn_wave_barrier();
       }
@@ -1126,7 +1126,16 @@ static int cm_solve_group_launch(cm_ctx* ctx, const cm_solve_sub& g, int nblk, i
     if (g.single) hipLaunchKernelGGL((KERN<false, TARG>), dim3(gridx), dim3(block), lds, st, cm_parg<false>{g.h0}, ##__VA_ARGS__);          \
     else hipLaunchKernelGGL((KERN<true, TARG>), dim3(gridx, gy), dim3(block), lds, st, cm_parg<true>{g.d_arr}, ##__VA_ARGS__);              \
   } while (0)
-  if (parts & 1) CM_LAUNCH_G(k_build_precision, ld, 64, build_prec_lds(ld + CM_LD_PAD), na1, skip_le);
+  if (parts & 1) {
+    // Row a accumulates columns up to the end of its diagonal tile only, and the kernel's wavefronts per CU are set by the LDS row they hold: a
+    // batch launches the rows in four bands, each with the accumulator its last row needs (5 / 7 / 9 / 11 KB instead of 11 for all at n = 1000:
+    // 20 instead of 14 wavefronts per CU on average -- the kernel is a chain of dependent gathers, its time is its wavefronts over its occupancy)
+    const int bands = (!g.single && ld >= 16 * TS) ? 4 : 1;
+    for (int q = 0; q < bands; ++q) {
+      const int r0 = ((ld / TS) * q / bands) * TS, r1 = ((ld / TS) * (q + 1) / bands) * TS;
+      if (r1 > r0) CM_LAUNCH_G(k_build_precision, r1 - r0, 64, build_prec_lds(r1 + CM_LD_PAD), na1, skip_le, r0, r1 + CM_LD_PAD);
+    }
+  }
   if (parts & 2) {
     if (fact_begin) CM_HIP(hipEventRecord(fact_begin, st));
     if (large_g && cm_use_grouped(ctx, g.single)) {    // grouped family: four panels per pass over the trailing matrix, 64 x 64 super-tiles
