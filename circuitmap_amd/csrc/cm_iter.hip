@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void k_mc_dead(cm_parg<BATCH> pa, IterDyn a, i
 // because the loop costs the role ~100 registers (232 against 126: two wavefronts per SIMD instead of three), which the early
 // iterations, where every row is alive and the role is one wavefront per row, must not pay.
 template <bool BATCH, int SEG, bool FULLMC, bool LISTED = false>
-__global__ __launch_bounds__(CM_ITER_THREADS) void k_iter_mid(cm_parg<BATCH> pa, IterDyn a) {
+__global__ __launch_bounds__(CM_ITER_THREADS, (BATCH && !FULLMC) ? 4 : 1) void k_iter_mid(cm_parg<BATCH> pa, IterDyn a) {
   extern __shared__ double sm[];
   const cm_pdev& p = pa.get();
   if (blockIdx.x <= 1) {
