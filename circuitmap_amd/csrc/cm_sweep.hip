@@ -525,7 +525,7 @@ __device__ __forceinline__ void seq_scan_body(const int* __restrict__ order, con
 // wavefront, a row pointer or an entry of theirs being touched -- and only the rows left over (rows with lam != 0 but mu == 0, revived
 // rows: a handful) are walked by the workgroup's wavefronts.  1 workgroup per 1024 rows instead of 32 or 64.
 template <bool BATCH, bool LEAN>
-__global__ __launch_bounds__(1024) void k_presweep(cm_parg<BATCH> pa, int it, int gated, double msrmp, double min_count, int nbI, int nbC,
+__global__ __launch_bounds__(1024, (BATCH && LEAN) ? 8 : 4) void k_presweep(cm_parg<BATCH> pa, int it, int gated, double msrmp, double min_count, int nbI, int nbC,
                                                     int roles, int gran, int quiescent, int nbL, int list_it) {
   __shared__ double scr_all[16][3 * CM_MAX_VALS];
   __shared__ int wsum[2][16];
