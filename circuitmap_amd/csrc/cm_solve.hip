@@ -38,7 +38,9 @@
 #define TP (CM_TILE + 2)   // padded LDS row (doubles): even, so that a thread's pair of neighbours moves with one 16-byte LDS store.  The matrix-core operand reads
                           // are tile[row = lane & 15][k = lane >> 4] (ds_read_b64, banked over the 32 lanes of a half-wave on 64 dword banks): a pitch of
                           // 68 dwords puts the 32 (row, k) pairs on 32 distinct bank pairs, where 32 + 1 made (row, 1) collide with (row + 1, 0)
-#define TPN (CM_TILE + 16) // pitch of a tile read as B[k = lane >> 4][col = lane & 15] (blk_mfma_nn): 96 dwords = 32 mod 64 keeps k = 0 / 1 on disjoint banks
+#define TPN (CM_TILE + 2)  // pitch of a tile read as B[k = lane >> 4][col = lane & 15] (blk_mfma_nn).  The conflict-free pitch for that read is 48 (96 dwords = 32 mod 64
+                           // keeps k = 0 / 1 on disjoint banks); it was measured no faster than this one (the 2-way conflict is hidden) and its 12 KB cost the
+                           // inverse kernels a workgroup per CU: 1.212 ms at 48, 1.195 ms at 34 for 128 x n = 1000
 
 // ------------------------------------------------------------------------------------------------
 // precision matrix over the active set; one wave per (padded) row, accumulator row in LDS.
