@@ -947,7 +947,7 @@ static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_option
     // reconnect_spont_cells on the device, one workgroup per circuit, straight on mu | beta | z | lam in HBM (cm_fnscan.hip): no host
     // round trip, no synchronisation; the final update_phi follows on the stream
     CM_TRY(cm_launch_fn_scan(ctx, s, o->msrmp, o->minimum_spike_count));
-    CM_TRY(cm_launch_update_phi(ctx, s, st, iters > 0 ? 1 : 0));     // (iters == 0: the per-run constants were not produced)
+    CM_TRY(cm_launch_update_phi(ctx, s, st, iters > 0 ? 1 : 0, 1));  // (iters == 0: the per-run constants were not produced)
   } else if (o->fn_scan) {
     // Host path (verbose runs: the reference's progress messages; circuits too large for the scan kernel's LDS).
     // mu | beta | z | lam are one device slab per circuit.  The scan reads mu and z and only ever WRITES lam (entries set to 1), so
@@ -979,7 +979,7 @@ static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_option
       start += ones[c].size();
     }
     CM_LAUNCH_SET(k_fn_scatter, s, (unsigned)((per + 255) / 256), 256, 0, st, (const double*)dbase, per, (const int32_t*)(dbase + (size_t)B * per));
-    CM_TRY(cm_launch_update_phi(ctx, s, st, iters > 0 ? 1 : 0));     // (iters == 0: the per-run constants were not produced)
+    CM_TRY(cm_launch_update_phi(ctx, s, st, iters > 0 ? 1 : 0, 1));  // (iters == 0: the per-run constants were not produced)
   }
   CM_HIP(hipEventRecord(ctx->ev[3], st));
   lap("fn_scan");

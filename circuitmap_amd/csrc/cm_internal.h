@@ -496,7 +496,7 @@ int cm_launch_stats(cm_ctx* ctx, cm_set& s, double spont_orthogonality, int quie
 int cm_sweep_quiescent(const cm_ctx* ctx, const cm_set& s, int it, const cm_options* o);
 int cm_launch_post_single(cm_ctx* ctx, cm_set& s, int it, const cm_options* o, int do_sigma);
 int cm_wait_active(cm_ctx* ctx, cm_set& s);
-int cm_launch_update_phi(cm_ctx* ctx, cm_set& s, hipStream_t st, int use_dead = 0);
+int cm_launch_update_phi(cm_ctx* ctx, cm_set& s, hipStream_t st, int use_dead = 0, int screen = 0);   // screen: rs holds the statistics of the last sweep (final update of a run)
 int cm_launch_phi_dead(cm_ctx* ctx, cm_set& s, hipStream_t st);
 bool cm_fn_scan_fits(const cm_set& s);
 int cm_launch_fn_scan(cm_ctx* ctx, cm_set& s, double minimax_spk_prob, double minimum_spike_count);   // reconnect_spont_cells on the device (cm_fnscan.hip)

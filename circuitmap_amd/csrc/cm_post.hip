@@ -234,16 +234,39 @@ int cm_wait_active(cm_ctx* ctx, cm_set& s) {
 
 // update_phi stand-alone (final update after the false-negative scan, and the per-phase test hook): one wave per neuron
 // use_dead: rows found to be identically zero take the per-run constants (valid once k_phi_dead has run for the current priors)
+// screen (batches, final update of a run: rs still holds the statistics of the last sweep): 64 rows per workgroup, one per THREAD first -- a row
+// that was all zero after the last sweep and has mu == 0 was not reconnected by the false-negative scan (a reconnected cell gets mu = mean of
+// its events > 0) and takes its constants without a wavefront; only the others (a few dozen per circuit) run the Newton iteration.  One
+// wavefront per row for all N rows, 95 % of which only found out that they were all zero, was 0.44 ms per step.
+#define CM_PHI_QROWS 64
 template <bool BATCH, int SEG>
-__global__ __launch_bounds__(256) void k_update_phi(cm_parg<BATCH> pa, int use_dead) {
+__global__ __launch_bounds__(256) void k_update_phi(cm_parg<BATCH> pa, int use_dead, int screen) {
   __shared__ double etab[64], ltab[128];
+  __shared__ int qlist[CM_PHI_QROWS], qn;
   cm_exptab_init(etab);
   cm_logtab_init(ltab);
+  if (threadIdx.x == 0) qn = 0;
   __syncthreads();                                   // (before any wavefront leaves)
   const cm_pdev& p = pa.get();
+  double out[4];
+  if (BATCH && screen) {
+    const int n = (int)blockIdx.x * CM_PHI_QROWS + (int)threadIdx.x;
+    if ((int)threadIdx.x < CM_PHI_QROWS && n < p.N) {
+      if (p.rs[(size_t)n * 4 + 3] < 0.0 && p.mu[n] == 0.0) {
+        p.phi[2 * n] = p.phi_dead[2 * n]; p.phi[2 * n + 1] = p.phi_dead[2 * n + 1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p.phi_cov[4 * n + i] = p.phi_cov_dead[4 * n + i];
+      } else qlist[atomicAdd(&qn, 1)] = n;
+    }
+    __syncthreads();
+    const int cnt = qn;
+    for (int i = threadIdx.x / CM_WAVE; i < cnt; i += 4)
+      phi_body<SEG>(qlist[i], threadIdx.x % CM_WAVE, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, out,
+                    etab, ltab, p.phi_dead, p.phi_cov_dead);
+    return;
+  }
   const int n = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE;
   if (n >= p.N) return;
-  double out[4];
   phi_body<SEG>(n, threadIdx.x % CM_WAVE, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, out,
                 etab, ltab, use_dead ? p.phi_dead : nullptr, use_dead ? p.phi_cov_dead : nullptr);
 }
@@ -286,20 +309,22 @@ int cm_launch_phi_dead(cm_ctx* ctx, cm_set& s, hipStream_t st) {
 }
 
 template <int SEG>
-static void launch_phi(cm_set& s, hipStream_t st, int use_dead) {
-  CM_LAUNCH_SET_T(k_update_phi, (SEG), s, (unsigned)((s.lead->N + 3) / 4), 256, 0, st, use_dead);
+static void launch_phi(cm_set& s, hipStream_t st, int use_dead, int screen) {
+  const int N = s.lead->N;
+  CM_LAUNCH_SET_T(k_update_phi, (SEG), s, (unsigned)(screen ? (N + CM_PHI_QROWS - 1) / CM_PHI_QROWS : (N + 3) / 4), 256, 0, st, use_dead, screen);
 }
 
-int cm_launch_update_phi(cm_ctx* ctx, cm_set& s, hipStream_t st, int use_dead) {
+int cm_launch_update_phi(cm_ctx* ctx, cm_set& s, hipStream_t st, int use_dead, int screen) {
   (void)ctx;
+  screen = (screen && use_dead && s.B > 1) ? 1 : 0;
   const int V = s.lead->V;                                  // the group shares the lane-segment class of V
-  if (V <= 1) launch_phi<1>(s, st, use_dead);
-  else if (V <= 2) launch_phi<2>(s, st, use_dead);
-  else if (V <= 4) launch_phi<4>(s, st, use_dead);
-  else if (V <= 8) launch_phi<8>(s, st, use_dead);
-  else if (V <= 16) launch_phi<16>(s, st, use_dead);
-  else if (V <= 32) launch_phi<32>(s, st, use_dead);
-  else launch_phi<64>(s, st, use_dead);
+  if (V <= 1) launch_phi<1>(s, st, use_dead, screen);
+  else if (V <= 2) launch_phi<2>(s, st, use_dead, screen);
+  else if (V <= 4) launch_phi<4>(s, st, use_dead, screen);
+  else if (V <= 8) launch_phi<8>(s, st, use_dead, screen);
+  else if (V <= 16) launch_phi<16>(s, st, use_dead, screen);
+  else if (V <= 32) launch_phi<32>(s, st, use_dead, screen);
+  else launch_phi<64>(s, st, use_dead, screen);
   CM_HIP(hipGetLastError());
   return CM_OK;
 }
