@@ -304,7 +304,7 @@ static void carve_a(cm_problem* p, cm_carver& c) {           // sizes known from
   const size_t N = p->N, K = p->K, ld = p->ld;
   c.take(&p->y, K); c.take(&p->ss, K); c.take(&p->sum_y, 2); c.take(&p->vals, CM_MAX_VALS); c.take(&p->rowcnt, N * CM_MAX_VALS); c.take(&p->mcnt, N * CM_MAX_VALS); c.take(&p->qcnt, N * 8); c.take(&p->touch, N);
   c.take(&p->row_ptr, N + 1); c.take(&p->col_ptr, K + 1); c.take(&p->mask, K); c.take(&p->pslab, 8 * N + CM_S_COUNT); c.take(&p->phi, 2 * N);
-  c.take(&p->phi_cov, 4 * N); c.take(&p->phi_dead, 8 * N); c.take(&p->R, K); c.take(&p->colany, K); c.take(&p->mcE, N * CM_MAX_VALS);
+  c.take(&p->phi_cov, 4 * N); c.take(&p->phi_dead, 8 * N); c.take(&p->phi_rep, N); c.take(&p->R, K); c.take(&p->colany, K); c.take(&p->mcE, N * CM_MAX_VALS);
   c.take(&p->rs, 4 * N); c.take(&p->act_idx, N); c.take(&p->act_inv, N); c.take(&p->n_act, 4); c.take(&p->alive, N + 1);
   c.take(&p->tstamp, 2 * K); c.take(&p->tlist_s, 2 * K); c.take(&p->tlist_r, 2 * K); c.take(&p->tcnt, 8);
   c.take(&p->A, ld * (ld + CM_LD_PAD)); c.take(&p->X, ld * (ld + CM_LD_PAD)); c.take(&p->Lf, ld * (ld + CM_LD_PAD)); c.take(&p->Dinv, ld * CM_TILE);
@@ -477,7 +477,7 @@ void cm_fill_pdev(const cm_problem* p, const cm_problem* r, int* mailbox, cm_pde
   d->rowcnt = p->rowcnt; d->col_ptr = p->col_ptr; d->csc_row = p->csc_row; d->csc_pos = p->csc_pos; d->csc_grp = p->csc_grp; d->mask = p->mask; d->colany = p->colany; d->ye = p->ye; d->me = p->me; d->mcnt = p->mcnt; d->touch = p->touch; d->qcnt = p->qcnt;
   { int l = 1; while (l < p->V) l <<= 1; d->mce_ld = l; }
   d->lam = p->lam; d->mu = p->mu; d->beta = p->beta; d->phi = p->phi; d->phi_cov = p->phi_cov; d->scal = p->scal; d->R = p->R; d->z = p->z;
-  d->mcE = p->mcE; d->rs = p->rs; d->phi_dead = p->phi_dead; d->phi_cov_dead = p->phi_dead ? p->phi_dead + 2 * (size_t)p->N : nullptr; d->phi_c_dead = p->phi_dead ? p->phi_dead + 6 * (size_t)p->N : nullptr; d->pslab = p->pslab; d->mu_prior = p->mu_prior; d->beta_prior = p->beta_prior; d->phi_prior = p->phi_prior;
+  d->mcE = p->mcE; d->rs = p->rs; d->phi_rep = p->phi_rep; d->phi_dead = p->phi_dead; d->phi_cov_dead = p->phi_dead ? p->phi_dead + 2 * (size_t)p->N : nullptr; d->phi_c_dead = p->phi_dead ? p->phi_dead + 6 * (size_t)p->N : nullptr; d->pslab = p->pslab; d->mu_prior = p->mu_prior; d->beta_prior = p->beta_prior; d->phi_prior = p->phi_prior;
   d->phi_cov_prior = p->phi_cov_prior; d->act_idx = p->act_idx; d->act_inv = p->act_inv; d->n_act = p->n_act; d->alive = p->alive; d->tstamp = p->tstamp; d->tlist_s = p->tlist_s; d->tlist_r = p->tlist_r; d->tcnt = p->tcnt; d->seq_n = p->seq_n;
   d->seq_off = p->seq_off; d->seq_pos = p->seq_pos; d->chunk_first = p->chunk_first; d->seq_meta = p->seq_meta; d->packed = p->packed;
   d->A = p->A; d->X = p->X; d->Lf = p->Lf; d->Dinv = p->Dinv; d->rhs = p->rhs; d->mailbox = mailbox;

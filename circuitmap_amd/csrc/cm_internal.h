@@ -164,6 +164,7 @@ struct cm_problem {
   double* beta_prior = nullptr; // [N]
   double* phi = nullptr;      // [N*2]
   double* phi_cov = nullptr;  // [N*4]
+  int32_t* phi_rep = nullptr;  // [N] representatives of k_phi_dead (cm_pdev)
   double* phi_dead = nullptr; // [N*8] update_phi result of neuron n if its lam row is identically zero: phi [N*2] | phi_cov [N*4] | ndtr(-mean/sdev) [N*2]
   double* phi_prior = nullptr;
   double* phi_cov_prior = nullptr;
@@ -233,6 +234,7 @@ struct cm_pdev {
   const int* qcnt;                          // [N*8] power q of row n: unmasked trials << 16 | trials (quiescent_gate; valid for <= 8 powers, rows < 65536 trials)
   double *lam, *mu, *beta, *phi, *phi_cov, *scal, *R, *z, *mcE, *rs;
   double *phi_dead, *phi_cov_dead, *phi_c_dead;   // update_phi of an all-zero row, per neuron, and ndtr(-mean / sdev) of it: constants of a run (k_phi_dead)
+  int* phi_rep;                  // [N] first neuron with the same trial counts and phi priors (itself: a representative whose constants are computed; the others copy)
   const double *pslab, *mu_prior, *beta_prior, *phi_prior, *phi_cov_prior;
   int *act_idx, *act_inv, *n_act, *seq_n, *seq_off, *seq_pos, *chunk_first, *seq_meta;
   int* alive;                    // [1 + N] batches: number and list of the rows with lam != 0 after the sweep (k_stats)
@@ -443,7 +445,7 @@ inline void cm_threefry2x32(uint32_t k0, uint32_t k1, uint32_t& x0, uint32_t& x1
 enum cm_lds_slot { CM_LDS_ITER = 0 /* 7 x 2 x 2 template variants */, CM_LDS_SOLVE_SMALL = 28, CM_LDS_SWEEP_PAR, CM_LDS_SWEEP_PAR2, CM_LDS_SWEEP_SEQ,
                    CM_LDS_NWD, CM_LDS_SIM_SORT, CM_LDS_BUILD_PREC, CM_LDS_SWEEP_PAR_B, CM_LDS_SWEEP_PAR2_B, CM_LDS_SWEEP_SEQ_B,
                    CM_LDS_SOLVE_SMALL_B, CM_LDS_BUILD_PREC_B, CM_LDS_ITER_LISTED /* 7 SEG variants */, CM_LDS_MC_DEAD = 47, CM_LDS_MC_DEAD_B, CM_LDS_ITER_OVERFLOW /* 7 SEG variants */, CM_LDS_CHOL_DIAG = 56, CM_LDS_CHOL_GPANEL, CM_LDS_CHOL_WIDE,
-                   CM_LDS_CHOL_DIAG_B, CM_LDS_CHOL_GPANEL_B, CM_LDS_CHOL_WIDE_B, CM_LDS_FN_SCAN, CM_LDS_FN_SCAN_B, CM_LDS_FN_SCAN_G, CM_LDS_FN_SCAN_GB, CM_LDS_SLOTS = 66 };
+                   CM_LDS_CHOL_DIAG_B, CM_LDS_CHOL_GPANEL_B, CM_LDS_CHOL_WIDE_B, CM_LDS_FN_SCAN, CM_LDS_FN_SCAN_B, CM_LDS_FN_SCAN_G, CM_LDS_FN_SCAN_GB, CM_LDS_PHI_REP, CM_LDS_PHI_REP_B, CM_LDS_SLOTS = 68 };
 static_assert(CM_LDS_SLOTS <= 72, "cm_ctx::lds_attr");
 // Table update AND runtime call under ONE lock: `set(fn, bytes, user)` is invoked while the table's mutex is held, and the table takes
 // the new value only after the setter succeeded -- two host threads (contexts on one GPU) can therefore never apply their values in

@@ -271,7 +271,42 @@ __global__ __launch_bounds__(256) void k_update_phi(cm_parg<BATCH> pa, int use_d
                 etab, ltab, use_dead ? p.phi_dead : nullptr, use_dead ? p.phi_cov_dead : nullptr);
 }
 
-// the per-run constants: update_phi of neuron n for an all-zero lam row -> phi_dead / phi_cov_dead
+// the per-run constants: update_phi of neuron n for an all-zero lam row -> phi_dead / phi_cov_dead.
+// That result is a function of the neuron's trial counts per stimulus value and of its phi priors alone, and neurons share those: at the benchmark
+// shape a circuit's 1000 neurons have ~200 distinct (counts, priors) tuples.  So the Newton iteration (as expensive as that of a live row: the
+// launch took ~1 ms of every 256-circuit step on the side stream) runs for one REPRESENTATIVE per tuple -- the first neuron that carries it, found
+// by an exact comparison behind a hash -- and the other neurons copy its six numbers: the same function of the same arguments, bit for bit.
+#define CM_REP_MAXN 8192           // hashes of all neurons in LDS; larger circuits: every neuron its own representative
+__device__ __forceinline__ unsigned rep_hash(const cm_pdev& p, int n) {
+  unsigned long long h = 0x9E3779B97F4A7C15ull;
+  for (int g = 0; g < p.V; ++g) h = (h ^ (unsigned long long)(unsigned)p.rowcnt[(size_t)n * CM_MAX_VALS + g]) * 0x100000001B3ull;
+  for (int i = 0; i < 2; ++i) h = (h ^ (unsigned long long)__double_as_longlong(p.phi_prior[2 * (size_t)n + i])) * 0x100000001B3ull;
+  for (int i = 0; i < 4; ++i) h = (h ^ (unsigned long long)__double_as_longlong(p.phi_cov_prior[4 * (size_t)n + i])) * 0x100000001B3ull;
+  return (unsigned)(h ^ (h >> 32));
+}
+__device__ __forceinline__ bool rep_same(const cm_pdev& p, int a, int b) {
+  for (int g = 0; g < p.V; ++g) if (p.rowcnt[(size_t)a * CM_MAX_VALS + g] != p.rowcnt[(size_t)b * CM_MAX_VALS + g]) return false;
+  for (int i = 0; i < 2; ++i) if (__double_as_longlong(p.phi_prior[2 * (size_t)a + i]) != __double_as_longlong(p.phi_prior[2 * (size_t)b + i])) return false;
+  for (int i = 0; i < 4; ++i) if (__double_as_longlong(p.phi_cov_prior[4 * (size_t)a + i]) != __double_as_longlong(p.phi_cov_prior[4 * (size_t)b + i])) return false;
+  return true;
+}
+template <bool BATCH>
+__global__ __launch_bounds__(256) void k_phi_rep(cm_parg<BATCH> pa) {
+  const cm_pdev& p = pa.get();
+  const int N = p.N;
+  const int n = (int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x;
+  if (N > CM_REP_MAXN) { if (n < N) p.phi_rep[n] = n; return; }
+  extern __shared__ unsigned rep_h[];              // [N]
+  const int hi = min(N, ((int)blockIdx.x + 1) * (int)blockDim.x);     // this workgroup's neurons look at 0 .. hi - 1
+  for (int i = threadIdx.x; i < hi; i += blockDim.x) rep_h[i] = rep_hash(p, i);
+  __syncthreads();
+  if (n >= N) return;
+  const unsigned mine = rep_h[n];
+  int rep = n;
+  for (int m = 0; m < n; ++m)
+    if (rep_h[m] == mine && rep_same(p, m, n)) { rep = m; break; }
+  p.phi_rep[n] = rep;
+}
 template <bool BATCH, int SEG>
 __global__ __launch_bounds__(256) void k_phi_dead(cm_parg<BATCH> pa) {
   __shared__ double etab[64], ltab[128];
@@ -281,6 +316,7 @@ __global__ __launch_bounds__(256) void k_phi_dead(cm_parg<BATCH> pa) {
   const cm_pdev& p = pa.get();
   const int n = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE;
   if (n >= p.N) return;
+  if (p.phi_rep[n] != n) return;                     // (k_phi_copy fills it in from its representative)
   double out[4];
   phi_body<SEG, true>(n, threadIdx.x % CM_WAVE, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi_dead,
                       p.phi_cov_dead, out, etab, ltab);
@@ -290,13 +326,30 @@ __global__ __launch_bounds__(256) void k_phi_dead(cm_parg<BATCH> pa) {
     p.phi_c_dead[2 * n + 1] = normcdf(-out[1] / out[3]);
   }
 }
+template <bool BATCH>
+__global__ __launch_bounds__(256) void k_phi_copy(cm_parg<BATCH> pa) {
+  const cm_pdev& p = pa.get();
+  const int n = (int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x;
+  if (n >= p.N) return;
+  const int r = p.phi_rep[n];
+  if (r == n) return;
+  p.phi_dead[2 * n] = p.phi_dead[2 * r]; p.phi_dead[2 * n + 1] = p.phi_dead[2 * r + 1];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) p.phi_cov_dead[4 * n + i] = p.phi_cov_dead[4 * r + i];
+  p.phi_c_dead[2 * n] = p.phi_c_dead[2 * r]; p.phi_c_dead[2 * n + 1] = p.phi_c_dead[2 * r + 1];
+}
 template <int SEG>
 static void launch_phi_dead(cm_set& s, hipStream_t st) {
   CM_LAUNCH_SET_T(k_phi_dead, (SEG), s, (unsigned)((s.lead->N + 3) / 4), 256, 0, st);
 }
 int cm_launch_phi_dead(cm_ctx* ctx, cm_set& s, hipStream_t st) {
-  (void)ctx;
-  const int V = s.lead->V;
+  const int V = s.lead->V, N = s.lead->N;
+  {
+    const size_t lds = N <= CM_REP_MAXN ? (size_t)N * sizeof(unsigned) : 0;
+    if (s.B == 1) CM_TRY(cm_raise_lds(ctx, CM_LDS_PHI_REP, reinterpret_cast<const void*>(k_phi_rep<false>), lds, 48 * 1024));
+    else CM_TRY(cm_raise_lds(ctx, CM_LDS_PHI_REP_B, reinterpret_cast<const void*>(k_phi_rep<true>), lds, 48 * 1024));
+    CM_LAUNCH_SET(k_phi_rep, s, (unsigned)((N + 255) / 256), 256, lds, st);
+  }
   if (V <= 1) launch_phi_dead<1>(s, st);
   else if (V <= 2) launch_phi_dead<2>(s, st);
   else if (V <= 4) launch_phi_dead<4>(s, st);
@@ -304,6 +357,7 @@ int cm_launch_phi_dead(cm_ctx* ctx, cm_set& s, hipStream_t st) {
   else if (V <= 16) launch_phi_dead<16>(s, st);
   else if (V <= 32) launch_phi_dead<32>(s, st);
   else launch_phi_dead<64>(s, st);
+  CM_LAUNCH_SET(k_phi_copy, s, (unsigned)((N + 255) / 256), 256, 0, st);
   CM_HIP(hipGetLastError());
   return CM_OK;
 }
