@@ -536,34 +536,51 @@ int cm_set_single(cm_ctx* ctx, cm_problem* p, cm_set* s) {
   return set_build(ctx, s);
 }
 
-__global__ __launch_bounds__(256) void k_priors_scatter(cm_parg<true> pa, const double* __restrict__ stage, size_t per) {
+__global__ __launch_bounds__(256) void k_priors_scatter(cm_parg<true> pa, const double* __restrict__ stage, size_t per, const int* __restrict__ slot) {
   const cm_pdev& p = pa.get();
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < per) const_cast<double*>(p.pslab)[i] = stage[(size_t)blockIdx.y * per + i];
+  if (i < per) const_cast<double*>(p.pslab)[i] = stage[(size_t)slot[blockIdx.y] * per + i];
 }
 
 // priors -> device, one pinned transfer per circuit (mu_prior | beta_prior | phi_prior | phi_cov_prior | scalars); the state is
-// then initialised from them on the device (k_init_state, caviar.py:44-49)
+// then initialised from them on the device (k_init_state, caviar.py:44-49).  Circuits that are handed the SAME prior arrays (one priors
+// dict for a whole batch: the usual case) share one staged copy -- staging 64 KB per circuit was a 16 MB host copy and a 16 MB read over
+// PCIe in front of every 256-circuit run.
 static int upload_priors(cm_ctx* ctx, cm_set& s, const cm_priors* prs) {
   hipStream_t st = ctx->stream;
   const size_t N = s.lead->N, n = 8 * N + CM_S_COUNT;
   CM_HIP(hipStreamSynchronize(st));                 // the staging buffer may still feed an earlier transfer of this context
   size_t slab_tot = 0;
   for (const cm_problem* q : s.ps) slab_tot += 2 * N + (size_t)q->K + (size_t)q->nnz;
-  CM_TRY(stage_reserve(ctx, std::max(n * s.B, slab_tot) * sizeof(double)));
+  std::vector<int> slot(s.B), first;                // first[k]: the circuit whose priors slot k holds
   for (int c = 0; c < s.B; ++c) {
-    const cm_priors* pr = &prs[c];
-    double* h = (double*)ctx->h_stage + n * c;
+    const cm_priors& a = prs[c];
+    int k = 0;
+    for (; k < (int)first.size(); ++k) {
+      const cm_priors& b = prs[first[k]];
+      if (a.mu == b.mu && a.beta == b.beta && a.phi == b.phi && a.phi_cov == b.phi_cov && a.shape == b.shape && a.rate == b.rate) break;
+    }
+    if (k == (int)first.size()) first.push_back(c);
+    slot[c] = k;
+  }
+  const size_t n_slots = s.B == 1 ? 1 : first.size();
+  CM_TRY(stage_reserve(ctx, std::max(n * n_slots + (size_t)s.B, slab_tot) * sizeof(double)));
+  for (size_t k = 0; k < n_slots; ++k) {
+    const cm_priors* pr = &prs[first[k]];
+    double* h = (double*)ctx->h_stage + n * k;
     memcpy(h, pr->mu, N * 8); memcpy(h + N, pr->beta, N * 8); memcpy(h + 2 * N, pr->phi, 2 * N * 8); memcpy(h + 4 * N, pr->phi_cov, 4 * N * 8);
     double* sc = h + 8 * N;
     for (int i = 0; i < CM_S_COUNT; ++i) sc[i] = 0.0;
     sc[CM_S_SHAPE] = pr->shape; sc[CM_S_RATE] = pr->rate; sc[CM_S_SHAPE_PRIOR] = pr->shape; sc[CM_S_RATE_PRIOR] = pr->rate;
-    if (s.B == 1) CM_HIP(hipMemcpyAsync(s.ps[c]->pslab, h, n * sizeof(double), hipMemcpyHostToDevice, st));
+    if (s.B == 1) CM_HIP(hipMemcpyAsync(s.ps[0]->pslab, h, n * sizeof(double), hipMemcpyHostToDevice, st));
   }
   if (s.B > 1) {                                     // one kernel reads the pinned staging buffer for all circuits (instead of B copies)
+    int* hslot = (int*)((double*)ctx->h_stage + n * n_slots);
+    memcpy(hslot, slot.data(), (size_t)s.B * sizeof(int));
     double* dbase = nullptr;
     CM_HIP(hipHostGetDevicePointer((void**)&dbase, ctx->h_stage, 0));
-    hipLaunchKernelGGL(k_priors_scatter, dim3((unsigned)((n + 255) / 256), s.B), dim3(256), 0, st, cm_parg<true>{s.d_arr}, (const double*)dbase, n);
+    hipLaunchKernelGGL(k_priors_scatter, dim3((unsigned)((n + 255) / 256), s.B), dim3(256), 0, st, cm_parg<true>{s.d_arr}, (const double*)dbase, n,
+                       (const int*)(dbase + n * n_slots));
     CM_HIP(hipGetLastError());
   }
   return CM_OK;
@@ -784,9 +801,11 @@ static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_option
   // (the listed column sums, cm_pdev::tstamp, rely on mu = 0 outside the active set; they pay when there are many trial columns to skip: at
   // K = 1000 the marking and the extra roles cost more than the shorter walk saves -- 502 k against 528 k it/s at N = 300 -- at K = 2000 they gain 3.5 %)
   s.lists_ok = p->K >= 1536 || getenv("CAVIAR_HIP_TEST_TRIAL_LISTS") != nullptr;      // (test hook: the listed walk on small shapes)
-  for (int c = 0; c < B && s.lists_ok; ++c)
+  for (int c = 0; c < B && s.lists_ok; ++c) {
+    if (c > 0 && prs[c].mu == prs[c - 1].mu) continue;          // (the same array as the last circuit's: checked)
     for (int i = 0; i < s.ps[c]->N; ++i)
       if (prs[c].mu[i] != 0.0) { s.lists_ok = false; break; }
+  }
   CM_HIP(hipEventRecord(ctx->ev[0], st));
 
   // RNG streams: sweep orders of all iterations live in orders_all (uploaded, or generated below in one batched launch).  They are
