@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """CAVIaR iterations/s on MI355X (BASELINE.json metric), one process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg5|nwd] [--circuits-per-gpu B] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg5|demo|nwd] [--circuits-per-gpu B] [--no-cpu-baseline]
 
 `--workload nwd` benchmarks the upstream NWD demixer forward pass instead (its own metric, traces/s; see bench_nwd).
 
@@ -41,7 +41,14 @@ WORKLOADS = {
     "cfg2": dict(N=300, K=1000, T=900, H=10),
     "cfg3": dict(N=1000, K=2000, T=900, H=10),       # the configuration BASELINE.json's metric is quoted on
     "cfg5": dict(N=5000, K=10000, T=900, H=10),
+    # the one workload the reference publishes a CAVIaR rate for: examples/demo_compressive_connectivity_mapping.ipynb:172-175 (N = 200 neurons,
+    # 2 min at 30 Hz = K ~ 3600 trials, H = 10 targets, connection_prob 0.1), msrmp 0.4 (:512), 50 iterations in 25 s = 1.97 it/s (:538) on an
+    # unnamed Colab GPU -- ~180 trials per cell, i.e. every chain row spans three 64-entry record segments
+    "demo": dict(N=200, K=3600, T=900, H=10, sim=dict(connection_prob=0.1), fit=dict(msrmp=0.4)),
 }
+PUBLISHED = {"demo": dict(value=1.97, unit="iterations/s", source="reference examples/demo_compressive_connectivity_mapping.ipynb:538 (50 it in 25 s)",
+                          hardware="Google Colab, accelerator GPU (model unnamed), JAX <= 0.3.15",
+                          note="one circuit; context, not a same-node comparison (different, unnamed hardware; the notebook's data were unseeded)")}
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
@@ -75,7 +82,7 @@ def default_priors(N):
                 phi_cov=np.array([np.array([[1e-1, 0], [0, 1e0]]) for _ in range(N)]))
 
 
-def cpu_baseline(sim, pri, wl):
+def cpu_baseline(sim, pri, wl, fit=None):
     """The literal float64 oracle (operation-for-operation restatement of the reference, O(N^2 K) sweep) timed on
     this host for ONE iteration (iteration 0: full active set, the most expensive one), plus the running-residual
     formulation for a few iterations as a stronger baseline.  Bounded to roughly 30-40 s of CPU work."""
@@ -89,13 +96,13 @@ def cpu_baseline(sim, pri, wl):
     out = {}
     if wl["N"] <= 1000:
         t = time.time()
-        co.caviar(*args, iters=1, seed=0, literal=True, fn_scan=False)
+        co.caviar(*args, iters=1, seed=0, literal=True, fn_scan=False, **(fit or {}))
         dt = time.time() - t
         out.update(value=1.0 / dt, unit="iterations/s", cores=int(nthreads), kind="port",
                    sample="literal O(N^2 K) oracle, 1 iteration (it=0) of 50, %.1f s; cores = BLAS threads, sweep loop is single-threaded NumPy" % dt)
     n_fast = 6 if wl["N"] <= 1000 else 1
     t = time.time()
-    co.caviar(*args, iters=n_fast, seed=0, literal=False, fn_scan=False)
+    co.caviar(*args, iters=n_fast, seed=0, literal=False, fn_scan=False, **(fit or {}))
     dtf = time.time() - t
     out["fast_formulation"] = dict(value=n_fast / dtf, unit="iterations/s",
                                    sample="running-residual oracle, first %d iterations, %.1f s" % (n_fast, dtf))
@@ -269,11 +276,11 @@ def measure_batch(ctx, local_rank, wl, pri, iters, B, seed0, steps, warmup, sync
     N, K, T, H = wl["N"], wl["K"], wl["T"], wl["H"]
     dsims, probs = [], []
     for c in range(B):
-        d = simulate_device(N=N, T=T, H=H, trials=K, seed=seed0 + c, device_id=local_rank, keep_on_device=True, ctx=ctx)
+        d = simulate_device(N=N, T=T, H=H, trials=K, seed=seed0 + c, device_id=local_rank, keep_on_device=True, ctx=ctx, **wl.get("sim", {}))
         dsims.append(d)
         probs.append(Problem(ctx, None, None, device_ptrs=(N, K, T, d["psc_ptr"], d["stim_ptr"])))
         ctx.free(d["psc_ptr"]); ctx.free(d["stim_ptr"])             # the problem keeps its own encoding
-    opts = dict(iters=iters, seed=0)
+    opts = dict(iters=iters, seed=0, **wl.get("fit", {}))
     for _ in range(warmup):
         run_batch(probs, pri, **opts)
     sync()
@@ -297,8 +304,8 @@ def end_to_end(_lib, ctx, local_rank, wl, pri, a, B):
     from circuitmap_amd.optimise.caviar import Problem, run_batch, fetch_batch, make_options, _priors_struct
     from circuitmap_amd.simulation import simulate_device
     N, K, T, H = wl["N"], wl["K"], wl["T"], wl["H"]
-    opts = dict(iters=a.iters, seed=0)
-    devs = [simulate_device(N=N, T=T, H=H, trials=K, seed=a.circuit_seed + j, device_id=local_rank, keep_on_device=True, ctx=ctx) for j in range(B)]
+    opts = dict(iters=a.iters, seed=0, **wl.get("fit", {}))
+    devs = [simulate_device(N=N, T=T, H=H, trials=K, seed=a.circuit_seed + j, device_id=local_rank, keep_on_device=True, ctx=ctx, **wl.get("sim", {})) for j in range(B)]
     res = {}
 
     def dev_pass():
@@ -454,13 +461,13 @@ def main():
             ctx = ctxs[j % G]                              # circuit j of a set lives on context j mod G
             seed = a.circuit_seed + c * B + j
             if a.host_sim:
-                sim = simulate(N=N, T=T, H=H, trials=K, seed=seed, lite=(N > 2000))
+                sim = simulate(N=N, T=T, H=H, trials=K, seed=seed, lite=(N > 2000), **wl.get("sim", {}))
                 if not sims:
                     sims.append(sim)
                 probs.append(Problem(ctx, sim["psc"], sim["stim_matrix"]))        # H2D + one-off prologue: outside the timed region
             else:
                 from circuitmap_amd.simulation import simulate_device
-                d = simulate_device(N=N, T=T, H=H, trials=K, seed=seed, device_id=local_rank, keep_on_device=True, ctx=ctx)
+                d = simulate_device(N=N, T=T, H=H, trials=K, seed=seed, device_id=local_rank, keep_on_device=True, ctx=ctx, **wl.get("sim", {}))
                 gen_ms = d["device_ms"]
                 probs.append(Problem(ctx, None, None, device_ptrs=(N, K, T, d["psc_ptr"], d["stim_ptr"])))   # one-off prologue: outside the timed region
                 if c == 0 and j == 0 and world == 1 and not a.no_cpu_baseline:
@@ -474,7 +481,7 @@ def main():
         pool = ThreadPoolExecutor(max_workers=G)
     nnz, nvals = sets[0][0].nnz
     run_args = (pri["mu"], pri["beta"], pri["shape"], pri["rate"], pri["phi"], pri["phi_cov"])
-    opts = dict(iters=a.iters, seed=0)
+    opts = dict(iters=a.iters, seed=0, **wl.get("fit", {}))
     # Per-kernel HIP events cost a launch boundary each (~8 % of a fit with four per iteration), so the library records them only on
     # request.  The timed region asks for them on every 4th step: the kernel durations in `roofline` are
     # measured live inside the timed region, on a sample of its steps; `value` pays for that sample (about 2 %).
@@ -667,6 +674,10 @@ def main():
                                        "k_iter_mid_avg_launch_ms": btms[-1]["mid_ms"] / its, "k_sweep_par_avg_launch_ms": btms[-1]["sweep_seq_ms"] / its,
                                        "fact_ms_per_step": btms[-1]["fact_ms"],
                                        "note": "every circuit bit-identical to its single fit (tests/test_gpu_parity.py::test_fit_batch_baseline_config3)"}
+        if a.workload in PUBLISHED:
+            out["published_reference"] = PUBLISHED[a.workload]
+            if B == 1:
+                out["published_reference"] = dict(PUBLISHED[a.workload], x_published=value / PUBLISHED[a.workload]["value"])
         batch_res0 = None
         if B > 1:
             # self-check of the launch configuration that was just timed: circuit 0's results as the lock-step batch left them ...
@@ -688,6 +699,8 @@ def main():
                                      "fact_ms_per_fit": float(np.mean([t["fact_ms"] for t in sk])),
                                      "batch_x_single": value / (8 * its / sdt),
                                      "note": "one circuit per step on the same GPU: a latency chain occupying a few percent of the chip"}
+            if a.workload in PUBLISHED:
+                out["single_circuit"]["x_published"] = out["single_circuit"]["value"] / PUBLISHED[a.workload]["value"]
         if batch_res0 is not None:
             # ... against the same problem object fitted alone (cm_caviar_run): bit for bit, all eight outputs (mu, beta, lam, shape,
             # rate, phi, phi_cov, z).  A mismatch makes the run fail (exit code 1 after the line is printed).
@@ -738,7 +751,7 @@ def main():
             if not all(same):
                 out["batch_equals_single"] = False
         if world == 1 and not a.no_cpu_baseline and sims:
-            out["cpu_baseline"] = cpu_baseline(sims[0], pri, wl)
+            out["cpu_baseline"] = cpu_baseline(sims[0], pri, wl, wl.get("fit"))
         emit(json.dumps(out))
         if out.get("batch_equals_single") is False:
             print("bench.py: circuit 0 of the batch differs from its single fit", file=sys.stderr)

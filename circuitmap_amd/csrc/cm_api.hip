@@ -778,8 +778,7 @@ extern "C" int cm_caviar_run_batch(cm_ctx* ctx, int32_t n, cm_problem* const* pr
 static int seg_class(int V) { int c = 1; while (c < V) c <<= 1; return c; }
 bool cm_same_launch_config(const cm_problem* a, const cm_problem* b) {
   if (a->N != b->N || a->K != b->K || seg_class(a->V) != seg_class(b->V)) return false;
-  auto par_ok = [](const cm_problem* q) { return q->max_row_len <= CM_WAVE && q->max_col_len <= 255 && q->nnz < (1 << 24); };
-  return par_ok(a) == par_ok(b);
+  return cm_par_class(a->K, a->max_row_len, a->max_col_len, a->nnz) == cm_par_class(b->K, b->max_row_len, b->max_col_len, b->nnz);
 }
 
 static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_options* o, cm_timings* tm) {
@@ -821,13 +820,16 @@ static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_option
     CM_TRY(pmalloc(ctx, &p->inv_all, (size_t)iters * N));
     p->orders_cap = iters;
   }
-  if (p->wtab_cap < (size_t)iters * N * S * 4) {           // (ndtri(u), u) for each of the iters x N x S x 2 uniforms
+  // (ndtri(u), u) for each of the iters x N x S x 2 uniforms, and the row statistics (iters x N rows).  The two buffers have their own
+  // capacities: a re-run with more iterations and fewer samples -- (50, 100) then (100, 50) -- keeps the product but needs twice the rows.
+  if (p->wtab_cap < (size_t)iters * N * S * 4 || p->wstat_rows < (size_t)iters * N) {
     cm_pool_free(ctx, p->wtab);
     cm_pool_free(ctx, p->wstat);
-    p->wtab = p->wstat = nullptr; p->wtab_cap = 0;
+    p->wtab = p->wstat = nullptr; p->wtab_cap = 0; p->wstat_rows = 0;
     CM_TRY(pmalloc(ctx, &p->wtab, (size_t)iters * N * S * 4));
     CM_TRY(pmalloc(ctx, &p->wstat, (size_t)iters * N * CM_WSTAT));
     p->wtab_cap = (size_t)iters * N * S * 4;
+    p->wstat_rows = (size_t)iters * N;
   }
   if (o->rng_mode == CM_RNG_EXPLICIT) {
     cm_pool_free(ctx, p->uexp); p->uexp = nullptr;

@@ -186,6 +186,7 @@ struct cm_problem {
   double* wtab = nullptr;        // [iters*N*2S*2] (ndtri(u), u) for every uniform of the run (data independent)
   size_t wtab_cap = 0;
   double* wstat = nullptr;        // statistics of the table rows (allocated with wtab)
+  size_t wstat_rows = 0;          // rows (iterations x N) wstat is sized for
   int32_t orders_cap = 0;     // iterations the two buffers are sized for
   int32_t* seq_n = nullptr;   // [N]   neurons with mu != 0 in sweep order
   int32_t* seq_off = nullptr; // [N+1] record offset of each such row in `packed`
@@ -301,6 +302,18 @@ __host__ __device__ static inline size_t small_lds_bytes(int n, int tot_cap) {
 __host__ __device__ static inline int cm_solve_kind(int na, int small_cap, bool skip_solved) {
   if (na <= small_cap) return skip_solved ? 0 : 1;
   return 2;
+}
+
+// Chain rows (cm_sweep.hip) of up to this many trials travel as packed records: half a record buffer of `cap` records, so that a chunk of the
+// chain still holds at least as many records again.  Which kernel can walk the chain: 1 / 2 = the multi-wave ticketed kernel with 1024-record
+// buffers + 32-bit tickets (K up to ~5600 trials, rows up to 511 trials) / 512-record buffers + 8-bit tickets (K up to ~10900, rows up to 255);
+// 0 = the single-consumer kernel (anything else: longer rows, more than 255 neurons per trial, K beyond the LDS budget).
+static inline int cm_pack_limit(int cap) { return cap / 2 - 1; }
+static inline int cm_par_class(int K, int max_row_len, int max_col_len, long long nnz) {
+  if (max_col_len > 255 || nnz >= (1 << 24)) return 0;
+  if ((size_t)K * 12 <= 68 * 1024 && max_row_len <= cm_pack_limit(1024)) return 1;
+  if ((size_t)K * 9 + 16 <= 96 * 1024 && max_row_len <= cm_pack_limit(512)) return 2;
+  return 0;
 }
 
 // The circuits one launch serves: a single problem, or a lock-step group with identical launch configuration.

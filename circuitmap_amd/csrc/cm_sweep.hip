@@ -462,7 +462,7 @@ struct __align__(16) SeqRec {
 __device__ __forceinline__ void seq_scan_body(const int* __restrict__ order, const double* __restrict__ mu,
                                               const int* __restrict__ row_ptr, int N, int* __restrict__ seq_n,
                                               int* __restrict__ seq_off, int* __restrict__ chunk_first, int* __restrict__ meta,
-                                              int* __restrict__ seq_pos, int gran, int (*wsum)[16], int* carry) {
+                                              int* __restrict__ seq_pos, int gran, int pack_max, int (*wsum)[16], int* carry) {
   if (threadIdx.x < 2) carry[threadIdx.x] = 0;
   __syncthreads();
   const int lane = threadIdx.x % CM_WAVE, w = threadIdx.x / CM_WAVE;
@@ -473,7 +473,7 @@ __device__ __forceinline__ void seq_scan_body(const int* __restrict__ order, con
       n = order[m];
       f = mu[n] != 0.0;
       const int len = row_ptr[n + 1] - row_ptr[n];
-      recs = f ? 1 + (len <= CM_WAVE ? len : 0) : 0;
+      recs = f ? 1 + (len <= pack_max ? len : 0) : 0;     // (a row beyond pack_max keeps its header only: the single-consumer kernel walks it from the CSR arrays)
     }
     int sf = f, sr = recs;                     // inclusive wave scans
     for (int o = 1; o < CM_WAVE; o <<= 1) {
@@ -526,7 +526,7 @@ __device__ __forceinline__ void seq_scan_body(const int* __restrict__ order, con
 // rows: a handful) are walked by the workgroup's wavefronts.  1 workgroup per 1024 rows instead of 32 or 64.
 template <bool BATCH, bool LEAN>
 __global__ __launch_bounds__(1024, (BATCH && LEAN) ? 8 : 4) void k_presweep(cm_parg<BATCH> pa, int it, int gated, double msrmp, double min_count, int nbI, int nbC,
-                                                    int roles, int gran, int quiescent, int nbL, int list_it) {
+                                                    int roles, int gran, int quiescent, int nbL, int list_it, int pack_max) {
   __shared__ double scr_all[16][3 * CM_MAX_VALS];
   __shared__ int wsum[2][16];
   __shared__ int carry[2];
@@ -580,14 +580,14 @@ __global__ __launch_bounds__(1024, (BATCH && LEAN) ? 8 : 4) void k_presweep(cm_p
     if (!(roles & 4)) return;
     if (BATCH && threadIdx.x == 0) p.alive[0] = 0;     // list of rows with lam != 0 that k_stats rebuilds after the sweep
     if (threadIdx.x == 0) { const int qn = (it + 1) & 1; p.tcnt[qn] = 0; p.tcnt[2 + qn] = 0; }   // the trial lists of the next iteration start empty
-    seq_scan_body(p.orders_all + (size_t)it * N, a.mu, a.row_ptr, N, p.seq_n, p.seq_off, p.chunk_first, p.seq_meta, p.seq_pos, gran, wsum, carry);
+    seq_scan_body(p.orders_all + (size_t)it * N, a.mu, a.row_ptr, N, p.seq_n, p.seq_off, p.chunk_first, p.seq_meta, p.seq_pos, gran, pack_max, wsum, carry);
   }
 }
 
 // `turns` != 0: also store in bits 24..31 of the slot word how many EARLIER chain rows touch the entry's trial (its ticket
 // in the multi-wave chain kernel); requires nnz < 2^24 and at most 255 targeted neurons per trial.
 template <bool BATCH>
-__global__ __launch_bounds__(256) void k_seq_pack(cm_parg<BATCH> pa, int gated, double msrmp, double min_count, int turns) {
+__global__ __launch_bounds__(256) void k_seq_pack(cm_parg<BATCH> pa, int gated, double msrmp, double min_count, int turns, int pack_max) {
   const cm_pdev& p = pa.get();
   const SweepArgs a = sweep_args(p, gated, msrmp, min_count);
   const int* __restrict__ seq_n = p.seq_n;
@@ -611,26 +611,97 @@ __global__ __launch_bounds__(256) void k_seq_pack(cm_parg<BATCH> pa, int gated, 
       h.a = (uint32_t)n; h.b = len; h.x = mu; h.y = sig * (mu * mu + be * be); h.z = 0.0;   // caviar.py:206
       packed[off] = h;
     }
-    if (len <= CM_WAVE && lane < len) {
-      const int e = beg + lane;
+    if (len > pack_max) continue;                     // (header only: see seq_scan_body)
+    for (int l = lane; l < len; l += CM_WAVE) {       // a row of more than 64 trials: ceil(len / 64) segments of records, in trial order
+      const int e = beg + l;
       const int k = a.col[e], g = a.grp[e];
       SeqRec r;
       r.a = (uint32_t)k | ((uint32_t)g << 24) | ((uint32_t)(a.me[e] != 0) << 31);
       int turn = 0;
       if (turns)     // (gathering four neurons at a time was measured slower than this plain loop: 28.3 vs 26.8 us at 128 circuits, 6.6 vs 5.4 us for one)
         for (int ce = col_ptr[k]; ce < col_ptr[k + 1]; ++ce) { const int q = seq_pos[csc_row[ce]]; turn += (q >= 0 && q < j); }
-      if (turns == 2 && j == 1 && lane == 0) turn = (turn + 1) & 0xFF;   // fault injection (CAVIAR_HIP_TEST_BAD_TICKET): a turn that never comes
+      if (turns == 2 && j == 1 && l == 0) turn = (turn + 1) & 0xFF;   // fault injection (CAVIAR_HIP_TEST_BAD_TICKET): a turn that never comes
       r.b = e | (turn << 24);
       r.x = a.lam[e];
       r.y = a.mcE[(size_t)n * a.mld + g];
       r.z = -2.0 * sig * a.ye[e] * mu;                                                      // caviar.py:205, first term (ye[e] = y[k])
-      packed[off + 1 + lane] = r;
+      packed[off + 1 + l] = r;
     }
   }
 }
 
+// A chain row of MORE than 64 trials from its packed records (LDS; `rec` = the row's first entry record, `len` entries in trial order), as
+// ceil(len / 64) segments of one entry per lane.  Shared by the multi-wave and the single-consumer chain kernels: the same operations in the
+// same order, so the two give bitwise the same row.  The structure is sweep_step_long's (the CSR walk): pass 1 evaluates every entry's
+// estimate -- kept in the record's `y` field, which is dead once the estimate exists; a chunk's records belong to the wavefront that walks
+// them -- and the gate's sums, per lane over the segments in trial order, then across the lanes; literal pool walk; pass 2 writes lam and R.
+// The caller has made sure every trial of the row shows its turn (multi-wave kernel) and publishes the tickets afterwards.
+template <typename RT>
+__device__ __forceinline__ void sweep_row_packed_long(const SweepArgs& a, SeqRec* rec, int len, double mu, double t3, RT* Rl, double sig, double thresh,
+                                                      int P, int lane, double* scr) {
+  double total = 0.0;
+  double psum[8];
+  int pcnt[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { psum[j] = 0.0; pcnt[j] = 0; }
+  for (int i0 = 0; i0 < len; i0 += CM_WAVE) {
+    const int i = i0 + lane;
+    double est = 0.0;
+    int g = -1;
+    if (i < len) {
+      const SeqRec r = rec[i];
+      g = (int)((r.a >> 24) & 0x7Fu);
+      if ((r.a >> 31) != 0u) {
+        const double rk = Rl[r.a & 0xFFFFFFu];
+        const double loo = sig * (rk - mu * r.x);
+        const double arg = r.z + 2.0 * mu * loo + t3;                                // caviar.py:205-206
+        est = cm_sigmoid(r.y - 0.5 * arg);                                           // caviar.py:216
+      }
+      rec[i].y = est;
+    }
+    total += est;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const bool in = g == j + 1; psum[j] += in ? est : 0.0; pcnt[j] += __popcll(__ballot(in)); }
+  }
+  double pava = 1.0;
+  if (a.gated) {
+    double* srate = scr;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < P) { const double s = cm_wave_sum(psum[j]); srate[j] = s / ((double)pcnt[j] + 1e-4 * (double)(pcnt[j] == 0)); }   // caviar.py:183
+    for (int p0 = 8; p0 < P; p0 += 8) {                 // more than eight powers: further passes over the stored estimates
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { psum[j] = 0.0; pcnt[j] = 0; }
+      __builtin_amdgcn_wave_barrier();
+      for (int i0 = 0; i0 < len; i0 += CM_WAVE) {
+        const int i = i0 + lane;
+        double est = 0.0;
+        int g = -1;
+        if (i < len) { const SeqRec r = rec[i]; g = (int)((r.a >> 24) & 0x7Fu); est = r.y; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const bool in = g == p0 + j + 1; psum[j] += in ? est : 0.0; pcnt[j] += __popcll(__ballot(in)); }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (p0 + j < P) { const double s = cm_wave_sum(psum[j]); srate[p0 + j] = s / ((double)pcnt[j] + 1e-4 * (double)(pcnt[j] == 0)); }
+    }
+    total = cm_wave_sum(total);
+    __builtin_amdgcn_wave_barrier();
+    const double iso = P > 0 ? cm_pava_last_dev(srate, P, scr + CM_MAX_VALS, scr + 2 * CM_MAX_VALS) : 0.0;
+    pava = (iso >= thresh && total >= a.min_count) ? 1.0 : 0.0;                       // caviar.py:220-221
+  }
+  __builtin_amdgcn_wave_barrier();                      // (the estimates written above are read back by the lanes that wrote them)
+  for (int i = lane; i < len; i += CM_WAVE) {
+    const SeqRec r = rec[i];
+    const int k = (int)(r.a & 0xFFFFFFu);
+    const double nl = r.y * pava;                                                     // caviar.py:224
+    a.lam[r.b & 0xFFFFFF] = nl;
+    Rl[k] = Rl[k] + mu * (nl - r.x);
+  }
+}
+
 template <bool BATCH, bool R_IN_LDS>
-__global__ __launch_bounds__(1024) void k_sweep_seq(cm_parg<BATCH> pa, int gated, double msrmp, double min_count, int packed_cap, int nchunks_cap) {
+__global__ __launch_bounds__(1024) void k_sweep_seq(cm_parg<BATCH> pa, int gated, double msrmp, double min_count, int packed_cap, int nchunks_cap, int pack_max) {
   const cm_pdev& p = pa.get();
   const SweepArgs a = sweep_args(p, gated, msrmp, min_count);
   const SeqRec* __restrict__ packed = (const SeqRec*)p.packed;
@@ -679,12 +750,15 @@ __global__ __launch_bounds__(1024) void k_sweep_seq(cm_parg<BATCH> pa, int gated
       SeqRec r = buf[cur][min(1 + lane, CM_SEQ_CAP - 1)];
       for (int j = 0; j < rows; ++j) {
         const int len = h.b;
-        const bool lng = len > CM_WAVE;
-        const int npos = pos + 1 + (lng ? 0 : len);
+        const bool lng = len > CM_WAVE, lng_packed = lng && len <= pack_max;
+        const int npos = pos + 1 + ((lng && !lng_packed) ? 0 : len);
         // software pipeline: the next row's header and records are requested before this row is computed
         const SeqRec hn = buf[cur][min(npos, CM_SEQ_CAP - 1)];
         const SeqRec rn = buf[cur][min(npos + 1 + lane, CM_SEQ_CAP - 1)];
-        if (lng) {
+        if (lng_packed) {
+          if (R_IN_LDS) sweep_row_packed_long(a, &buf[cur][pos + 1], len, h.x, h.y, Rl, sig, thresh, P, lane, scr);
+          else sweep_row_packed_long(a, &buf[cur][pos + 1], len, h.x, h.y, Rg, sig, thresh, P, lane, scr);
+        } else if (lng) {
           if (R_IN_LDS) sweep_step_long<true>(a, (int)h.a, Rl, sig, thresh, lane, scr);
           else sweep_step_long<true>(a, (int)h.a, Rg, sig, thresh, lane, scr);
         } else {
@@ -797,6 +871,25 @@ __global__ __launch_bounds__(1024) void k_sweep_par(cm_parg<BATCH> pa, int gated
           hn = buf[cur][pn]; rn = buf[cur][min(pn + 1 + lane, CAP - 1)];
         }
         const int len = h.b;
+        if (len > CM_WAVE) {
+          // a row of more than 64 trials: its records as segments of 64 -- wait for the tickets of all of them, walk the row
+          // (sweep_row_packed_long: the function the single-consumer kernel runs on the same records), publish all of them
+          SeqRec* rec = &buf[cur][roff[cur][j] + 1];
+          unsigned spins = 0;
+          while (true) {
+            bool ok = true;
+            for (int i = lane; i < len; i += CM_WAVE) { const SeqRec q = rec[i]; ok = ok && ((int)cnt[q.a & 0xFFFFFFu] == (int)((unsigned)q.b >> 24)); }
+            if (__all(ok)) break;
+            if (++spins > (1u << 18)) { if (lane == 0) *err_flag = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          sweep_row_packed_long(a, rec, len, h.x, h.y, Rl, sig, thresh, P, lane, scr[wave]);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          for (int i = lane; i < len; i += CM_WAVE) { const SeqRec q = rec[i]; cnt[q.a & 0xFFFFFFu] = (TK)(((unsigned)q.b >> 24) + 1u); }
+          h = hn; r = rn;
+          continue;
+        }
         const bool valid = lane < len;
         const double mu = h.x, t3 = h.y;
         const int k = valid ? (int)(r.a & 0xFFFFFFu) : 0, g = (int)((r.a >> 24) & 0x7Fu);
@@ -897,7 +990,11 @@ int cm_launch_sweep(cm_ctx* ctx, cm_set& s, int it, const cm_options* o, hipEven
   // every R_k sees its updates in sweep order: the variants give bit-identical results.
   const int par = cm_sweep_variant(s, s.B > 1 ? 1 : ctx->mb_n);
   const int cap = (par == 2) ? 512 : CM_SEQ_CAP;
-  const int gran = cap - CM_WAVE - 1;                              // chunking granule: a chunk spans < gran + 65 <= cap records
+  // Chain rows of up to pack_max trials travel as packed records (rows of more than 64 as several 64-entry segments); a longer row keeps its
+  // header only and is walked from the CSR arrays by the single-consumer kernel (the multi-wave kernel requires every row packed:
+  // cm_sweep_variant).  Chunking granule: a chunk spans < gran + 1 + pack_max <= cap records.
+  const int pack_max = std::max(CM_WAVE, std::min(s.max_row_len_max, cm_pack_limit(cap)));
+  const int gran = cap - pack_max - 1;
   const size_t lds_par = (par == 2) ? (size_t)p->K * 9 + 16 : (size_t)p->K * 12;
   static const bool split = getenv("CAVIAR_HIP_SPLIT_PRESWEEP") != nullptr;     // diagnostic: one launch per role (profiling only)
   int v_max = 0;
@@ -917,13 +1014,13 @@ int cm_launch_sweep(cm_ctx* ctx, cm_set& s, int it, const cm_options* o, hipEven
     nbCk = nbL + (p->K + 1023) / 1024;
   }
   for (int pass = 0; pass < (split ? 3 : 1); ++pass) {
-    if (lean) CM_LAUNCH_SET_T(k_presweep, (true), s, nbIq + nbCk + 1, 1024, 0, st, (table_it < 0 ? it : table_it), gated, msrmp, min_count, nbIq, nbCk, split ? (1 << pass) : 7, gran, quiescent, nbL, list_it);
-    else CM_LAUNCH_SET_T(k_presweep, (false), s, nbIq + nbCk + 1, 1024, 0, st, (table_it < 0 ? it : table_it), gated, msrmp, min_count, nbIq, nbCk, split ? (1 << pass) : 7, gran, quiescent, nbL, list_it);
+    if (lean) CM_LAUNCH_SET_T(k_presweep, (true), s, nbIq + nbCk + 1, 1024, 0, st, (table_it < 0 ? it : table_it), gated, msrmp, min_count, nbIq, nbCk, split ? (1 << pass) : 7, gran, quiescent, nbL, list_it, pack_max);
+    else CM_LAUNCH_SET_T(k_presweep, (false), s, nbIq + nbCk + 1, 1024, 0, st, (table_it < 0 ? it : table_it), gated, msrmp, min_count, nbIq, nbCk, split ? (1 << pass) : 7, gran, quiescent, nbL, list_it, pack_max);
   }
   s.tlist_sweep_it = list_it;
   static const bool bad_ticket = getenv("CAVIAR_HIP_TEST_BAD_TICKET") != nullptr;   // test hook: exercises the bounded wait + error report of the ticketed chain
   const int pack_rows = s.B > 1 ? std::min(N, std::max(64, 2 * s.na_max)) : N;      // (one circuit: the N / 4 workgroups are not what its 5 us are made of)
-  CM_LAUNCH_SET(k_seq_pack, s, (pack_rows + 3) / 4, 256, 0, st, gated, msrmp, min_count, par ? (bad_ticket ? 2 : 1) : 0);
+  CM_LAUNCH_SET(k_seq_pack, s, (pack_rows + 3) / 4, 256, 0, st, gated, msrmp, min_count, par ? (bad_ticket ? 2 : 1) : 0, pack_max);
   if (mid) CM_HIP(hipEventRecord(mid, st));
   const size_t lds = (size_t)p->K * sizeof(double);
   const long long nrec = (long long)p->N + s.nnz_min;          // smallest allocation of `packed` (records) and of the chunk table in the set
@@ -940,9 +1037,9 @@ int cm_launch_sweep(cm_ctx* ctx, cm_set& s, int it, const cm_options* o, hipEven
   } else if (lds <= 88 * 1024) {     // 64 KiB of record buffers + R must fit the CU's 160 KiB
     if (s.B == 1) CM_TRY(cm_raise_lds(ctx, CM_LDS_SWEEP_SEQ, reinterpret_cast<const void*>(k_sweep_seq<false, true>), lds, 0));
     else CM_TRY(cm_raise_lds(ctx, CM_LDS_SWEEP_SEQ_B, reinterpret_cast<const void*>(k_sweep_seq<true, true>), lds, 0));
-    CM_LAUNCH_SET_T(k_sweep_seq, (true), s, 1, 1024, lds, st, gated, msrmp, min_count, packed_cap, nchunks_cap);
+    CM_LAUNCH_SET_T(k_sweep_seq, (true), s, 1, 1024, lds, st, gated, msrmp, min_count, packed_cap, nchunks_cap, pack_max);
   } else {
-    CM_LAUNCH_SET_T(k_sweep_seq, (false), s, 1, 1024, 0, st, gated, msrmp, min_count, packed_cap, nchunks_cap);
+    CM_LAUNCH_SET_T(k_sweep_seq, (false), s, 1, 1024, 0, st, gated, msrmp, min_count, packed_cap, nchunks_cap, pack_max);
   }
   CM_HIP(hipGetLastError());
   return CM_OK;
@@ -954,9 +1051,6 @@ int cm_sweep_variant(const cm_set& s, int rows_hint) {
   static const bool no_par = getenv("CAVIAR_HIP_NO_PAR_SWEEP") != nullptr;
   const cm_problem* p = s.lead;
   int par = 0;
-  if (!no_par && rows_hint > CM_PAR_MIN_ROWS && s.max_row_len_max <= CM_WAVE && s.max_col_len_max <= 255 && s.nnz_max < (1 << 24)) {
-    if ((size_t)p->K * 12 <= 68 * 1024) par = 1;
-    else if ((size_t)p->K * 9 + 16 <= 96 * 1024) par = 2;
-  }
+  if (!no_par && rows_hint > CM_PAR_MIN_ROWS) par = cm_par_class(p->K, s.max_row_len_max, s.max_col_len_max, s.nnz_max);
   return par;
 }

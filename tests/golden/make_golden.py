@@ -103,6 +103,26 @@ def case_cfg2(ref):
          **{"opt_" + k: np.asarray(v) for k, v in opts.items()}, **{"out_" + k: v for k, v in res.items()})
 
 
+def case_cfg3(ref, iters=8):
+    """BASELINE configs[2] — the headline shape N=1000, K=2000, T=900 — default options: the first 8 iterations (three ungated
+    full-size solves, the gating transition, the collapsing active set) + false-negative scan + final update_phi, with every
+    per-iteration history.  lam (final and history) is stored on the support of the stimulus matrix only, as for cfg2; the
+    stimulus matrix as its CSR triples' dense float32 form (compresses to a few hundred KB)."""
+    N, K = 1000, 2000
+    sim = simulate(N=N, trials=K, seed=2000)
+    psc, stim = f32_exact(sim["psc"]), sim["stim_matrix"]
+    pri = default_priors(N)
+    opts = dict(iters=iters, seed=0, save_histories=True)
+    res = run_caviar(ref, psc, stim, pri, **opts)
+    sup = stim > 0
+    assert not np.any(res["lam"][~sup]) and not np.any(res["hist_lam"][:, ~sup])
+    res["lam"] = res["lam"][sup]
+    res["hist_lam"] = res["hist_lam"][:, sup]
+    res["hist_shape"], res["hist_rate"] = res["hist_shape"][:, 0].copy(), res["hist_rate"][:, 0].copy()
+    save("caviar_cfg3", psc=psc.astype(np.float32), stim=stim.astype(np.float32), weights=sim["weights"],
+         **{"opt_" + k: np.asarray(v) for k, v in opts.items()}, **{"out_" + k: v for k, v in res.items()})
+
+
 def tiny_problem(seed, N=8, K=48, T=60, H=2, powers=(30.0, 50.0, 70.0)):
     rng = np.random.default_rng(seed)
     stim = np.zeros((N, K))
@@ -218,11 +238,17 @@ def case_units(ref):
 
 def main():
     ref, pava = load_reference()
+    if len(sys.argv) > 1:                       # e.g. `make_golden.py cfg3`: one case only (cfg3 takes ~10 CPU-minutes)
+        for name in sys.argv[1:]:
+            fn = globals()["case_" + name]
+            fn(pava if name == "pava" else ref)
+        return
     case_pava(pava)
     case_units(ref)
     case_tiny(ref)
     case_cfg1(ref)
     case_cfg2(ref)
+    case_cfg3(ref)
 
 
 if __name__ == "__main__":

@@ -138,8 +138,12 @@ def test_caviar_vs_oracle_bench_sizes(N, K, iters):
     opts = dict(iters=iters, seed=0)
     res = caviar(sim["psc"], sim["stim_matrix"], *prior_args(pri), **opts)
     ref = co.caviar(sim["psc"], sim["stim_matrix"], *prior_args(pri), literal=False, **opts)
+    # 50 iterations: the trajectory has long left the ill-conditioned early solves; the committed report (profiles/r0*_parity_report.txt)
+    # measures 3e-8 worst case over all outputs -- held to 1e-7, so a regression of half an order of magnitude shows.  3 iterations end
+    # inside the amplified phase (see TOL_HIST).
+    tol = 1e-7 if iters == 50 else 1e-6
     for i, nm in enumerate(OUT_NAMES):
-        assert rel_err(res[i], ref[i]) < 1e-6, nm
+        assert rel_err(res[i], ref[i]) < tol, (nm, rel_err(res[i], ref[i]))
     if iters == 50:
         # the connected set the two sides report is the same set (gate decisions are discontinuous: a flipped gate would show here)
         assert np.array_equal(np.asarray(res[0]) != 0, np.asarray(ref[0]) != 0)
@@ -581,11 +585,14 @@ def test_phase_hooks_vs_golden(ctx):
     assert np.any(g["ul_lam_gated"].sum(axis=1) == 0) and np.any(g["ul_lam_gated"] != g["ul_lam_ungated"])   # the gate did close rows
 
 
-def test_caviar_vs_golden_cfg2():
-    """BASELINE configs[1] shape (N=300, K=1000, T=900) against the vectors recorded from the reference's own source: first 12
-    iterations + false-negative scan, all per-iteration histories (lam stored on the support of the stimulus matrix)."""
+@pytest.mark.parametrize("name", ["caviar_cfg2", "caviar_cfg3"])
+def test_caviar_vs_golden_bench_shapes(name):
+    """BASELINE configs[1] (N=300, K=1000, T=900; first 12 iterations) and configs[2] -- the HEADLINE shape N=1000, K=2000, T=900; first 8
+    iterations: three ungated full-size tiled solves, the gating transition, the collapsing active set -- against the vectors recorded from the
+    reference's own source text (tests/golden/make_golden.py: case_cfg2, case_cfg3; caviar.py:79-98): iterations + false-negative scan + final
+    update_phi, all per-iteration histories (lam stored on the support of the stimulus matrix)."""
     from circuitmap_amd.optimise import caviar
-    g, psc, stim, pri, opts = load_case("caviar_cfg2")
+    g, psc, stim, pri, opts = load_case(name)
     res = caviar(psc, stim, *prior_args(pri), **opts)
     sup = stim > 0
     for i, nm in enumerate(OUT_NAMES):
@@ -619,11 +626,14 @@ def _device_circuits(cx, N, K, B, seed0, T=900, host_copy_of=()):
     return probs, host
 
 
-@pytest.mark.parametrize("N,K,B,iters", [(200, 400, 16, 14), (200, 400, 33, 14), (200, 400, 128, 14), (1000, 2000, 16, 50), (1000, 2000, 256, 50)])
+@pytest.mark.parametrize("N,K,B,iters", [(200, 400, 16, 14), (200, 400, 33, 14), (200, 400, 128, 14), (1000, 2000, 16, 50), (1000, 2000, 256, 50),
+                                         (200, 3600, 16, 14)])
 def test_run_batch_many_per_xcd(ctx, N, K, B, iters):
     """cm_caviar_run_batch with 2 and 16 circuits per XCD (cm_xcd_remap mode 3 with per > 1, which needs gridDim.y % 8 == 0): every
     circuit bit-identical to its own cm_caviar_run; circuit 0 within 1e-6 of the running-residual oracle (the small shape; the
-    N = 1000 oracle trajectory is test_caviar_vs_oracle_bench_sizes).  N = 200 / K = 400 starts with a 7-tile-row tiled solve;
+    N = 1000 oracle trajectory is test_caviar_vs_oracle_bench_sizes).  N = 200 / K = 400 starts with a 7-tile-row tiled solve; N = 200 / K = 3600
+    is the reference's published workload (examples/demo_compressive_connectivity_mapping.ipynb:172-175: ~180 trials per cell, every chain row is
+    three 64-entry record segments in the multi-wave chain kernel);
     (1000, 2000, 256) is bench.py's default step: timed as one lock-step batch, and as the two interleaved half-batches that are the
     library's default scheduling (cm_options.interleave) -- both forms are checked."""
     from circuitmap_amd.optimise.caviar import run_batch
@@ -869,3 +879,114 @@ def test_fit_lockstep_accepts_scattered_device_circuits():
         for i, nm in enumerate(OUT_NAMES):
             if nm != "lam":
                 np.testing.assert_array_equal(np.asarray(res[i], dtype=float), np.asarray(g[nm], dtype=float), err_msg=nm)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Two builds / two environments of the library, compared through child processes (tests/child_fit.py)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _worst_rel(a, b, per_iteration):
+    """largest relative deviation; histories are scaled iteration by iteration"""
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    if not per_iteration:
+        return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)) if a.size else 0.0
+    return max(float(np.max(np.abs(x - y)) / max(np.max(np.abs(y)), 1e-300)) for x, y in zip(a, b))
+
+
+def test_mc_logit_residue_threshold(tmp_path):
+    """The default build takes log(f / (1 - f)), f = sigmoid(x), as x itself for -700 < x < 8 (csrc/cm_bodies.h: CM_LOGIT_RESIDUE_FROM; the
+    rounding residue it drops is <= 3.3e-13 there, reference caviar.py:233-236).  The variant build -DCM_LOGIT_RESIDUE_FROM=-1e300
+    (circuitmap_amd/libcaviar_hip_litlogit.so, built by __graft_entry__.build(); it also switches k_mc_dead's screening off, whose bound
+    assumes the threshold) evaluates the residue for every argument.  Four circuits of BASELINE configs[1]'s shape, all 50 iterations with
+    histories, in a child process per build: trajectories agree to 1e-8 (mu, beta, z, rate per iteration, final lam; phi per iteration 1e-7) and NOT ONE gate
+    decision differs (a neuron whose lam row is zero in one build and not in the other, at any iteration)."""
+    import os
+    from child_fit import fit_specs, run_child
+    variant = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "circuitmap_amd", "libcaviar_hip_litlogit.so")
+    assert os.path.exists(variant), "variant build missing: run __graft_entry__.build()"
+    specs = [dict(N=300, K=1000, B=4, seed0=2000, batch=True, opts=dict(iters=50, seed=0, save_histories=True))]
+    ours = fit_specs(specs)
+    theirs = run_child(specs, {"CAVIAR_HIP_LIB": variant}, tmp_path)
+    assert sorted(ours) == sorted(theirs)
+    worst = {}
+    for c in range(4):
+        for nm in ("mu", "beta", "phi", "z", "rate"):
+            key = "0_%d_hist_%s" % (c, nm)
+            worst[nm] = max(worst.get(nm, 0.0), _worst_rel(ours[key], theirs[key], True))
+        worst["lam"] = max(worst.get("lam", 0.0), _worst_rel(ours["0_%d_lam" % c], theirs["0_%d_lam" % c], False))
+        assert np.array_equal(ours["0_%d_hist_alive" % c], theirs["0_%d_hist_alive" % c]), "gate flip in circuit %d" % c
+        assert np.array_equal(ours["0_%d_mu" % c] != 0, theirs["0_%d_mu" % c] != 0)
+    # measured (round 4, MI355X): mu 4.9e-10, beta 1.1e-9, lam 6.3e-11, phi 2.4e-8 (a row's Newton iteration amplifies the change of its lam row)
+    assert all(worst[nm] <= 1e-8 for nm in ("mu", "beta", "z", "rate", "lam")) and worst["phi"] <= 1e-7, worst
+    assert any(v > 0 for v in worst.values()), "the two builds cannot be bitwise equal: was the variant really loaded?"
+
+
+def test_mc_dead_screening_adversarial(tmp_path):
+    """k_mc_dead (csrc/cm_iter.hip) replaces the Monte-Carlo logit of an all-zero row by -inf when an UPPER BOUND of its mean logits already
+    fails the gate of the next sweep (reference caviar.py:209-221: the logit only feeds that gate).  Adversarial inputs for the bound: per-neuron
+    beta priors spread over 0.2 .. 10 (sigma beta^4 / 2 from negligible to decisive, so all-zero rows land on BOTH sides of the gate and some are
+    revived), msrmp swept over 0.05 .. 0.7 so the bounds straddle the threshold, num_mc_samples 3 and 7 (the sample mean of the quantiles far
+    from 0), delay_spont_est 0 and 5 (screening starts with the first gated sweep), and a phi prior (mean, var) = (0.5, 0.5) whose truncation
+    point ndtr(-mean / sdev) is far from negligible (the bound must then refuse to decide).  Every circuit of every configuration, all outputs
+    and all histories, bit-identical to the same batch with CAVIAR_HIP_NO_MC_SCREEN=1 (child process: the flag is read once)."""
+    from child_fit import fit_specs, run_child
+    specs = []
+    for S in (3, 7):
+        for delay in (0, 5):
+            for phi, cov in ((None, None), ([0.5, 0.5], [0.5, 0.5])):
+                for msrmp in (0.05, 0.2, 0.4, 0.7):
+                    specs.append(dict(N=120, K=400, B=8, seed0=6000 + len(specs), batch=True, beta_seed=17 + len(specs), phi=phi, phi_cov_diag=cov,
+                                      opts=dict(iters=9, seed=len(specs), num_mc_samples=S, delay_spont_est=delay, msrmp=msrmp, minimum_spike_count=2,
+                                                save_histories=True)))
+    ours = fit_specs(specs)
+    theirs = run_child(specs, {"CAVIAR_HIP_NO_MC_SCREEN": "1"}, tmp_path)
+    assert sorted(ours) == sorted(theirs)
+    for k in ours:
+        np.testing.assert_array_equal(ours[k], theirs[k], err_msg=k)
+    # the inputs did exercise both outcomes: all-zero rows that stay zero, and all-zero rows the next gated sweep revives
+    revived = stayed = 0
+    for si, spec in enumerate(specs):
+        for c in range(spec["B"]):
+            alive = ours["%d_%d_hist_alive" % (si, c)]
+            first = spec["opts"]["delay_spont_est"] + 1                      # first gated sweep
+            for it in range(max(first, 1), alive.shape[0]):
+                revived += int(np.sum(~alive[it - 1] & alive[it]))
+                stayed += int(np.sum(~alive[it - 1] & ~alive[it]))
+    assert revived > 0 and stayed > 0, (revived, stayed)
+
+
+def test_rerun_more_iterations_fewer_samples(ctx):
+    """The random tables of a problem are sized by (iters, N, S): a second run of the SAME problem objects with more iterations and fewer
+    Monte-Carlo samples -- (50, 100) then (100, 50): the product iters x S does not grow -- must re-size the per-row table statistics
+    (cm_pdev::wstat, iters x N rows; ADVICE r3: it was tied to the capacity of the sample table and overran into neighbouring pool slabs).
+    Every circuit equals a fresh problem's (100, 50) run bit for bit."""
+    from circuitmap_amd.optimise.caviar import run_batch
+    pri = default_priors(120)
+    probs, _ = _device_circuits(ctx, 120, 400, 4, 7100)
+    run_batch(probs, pri, iters=50, num_mc_samples=100, seed=1)
+    run_batch(probs, pri, iters=100, num_mc_samples=50, seed=1)
+    again = [q.fetch() for q in probs]
+    fresh, _ = _device_circuits(ctx, 120, 400, 4, 7100)
+    run_batch(fresh, pri, iters=100, num_mc_samples=50, seed=1)
+    for c, (q, a) in enumerate(zip(fresh, again)):
+        _assert_same_fit(q.fetch(), a, "re-run circuit %d" % c)
+    for q in probs + fresh:
+        q.close()
+
+
+def test_long_rows_par_chain_equals_single_consumer(tmp_path):
+    """Rows of more than 64 targeted trials travel through the multi-wave ticketed chain (k_sweep_par) as ceil(len / 64) record segments.  The
+    reference's published workload -- N = 200, K = 3600, H = 10: ~180 trials per cell (examples/demo_compressive_connectivity_mapping.ipynb:
+    172-175) -- as single fits and as a lock-step batch, and a 9-power design whose long rows take the literal pool walk: every output and every
+    per-iteration history bit-identical to the same fits walked by the single-consumer kernel (CAVIAR_HIP_NO_PAR_SWEEP=1, child process), which
+    runs the same per-row function on the same records one row at a time: the tickets only change WHEN a row runs, never what it computes."""
+    from child_fit import fit_specs, run_child
+    opts = dict(iters=12, seed=0, save_histories=True)
+    specs = [dict(N=200, K=3600, B=2, seed0=8100, batch=False, opts=opts, sim=dict(connection_prob=0.1)),
+             dict(N=200, K=3600, B=8, seed0=8200, batch=True, opts=opts, sim=dict(connection_prob=0.1)),
+             dict(N=60, K=1500, B=3, seed0=8300, batch=True, H=8, opts=dict(opts, msrmp=0.2), sim=dict(powers=[30.0 + 5 * i for i in range(9)], connection_prob=0.2))]
+    ours = fit_specs(specs)
+    theirs = run_child(specs, {"CAVIAR_HIP_NO_PAR_SWEEP": "1"}, tmp_path)
+    assert sorted(ours) == sorted(theirs)
+    for k in ours:
+        np.testing.assert_array_equal(ours[k], theirs[k], err_msg=k)
+    assert np.count_nonzero(ours["0_0_mu"]) > 0 and np.count_nonzero(ours["2_0_mu"]) > 0        # real fits: connections were found

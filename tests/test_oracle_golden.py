@@ -38,10 +38,12 @@ def test_fast_oracle_matches(name):
         assert rel_err(res[9 + i], g["out_hist_" + nm]) < 1e-6, "hist " + nm
 
 
-def test_oracle_vs_golden_cfg2():
-    """BASELINE configs[1] shape (N=300, K=1000, T=900; 12 iterations + fn_scan, histories) recorded from the reference's own source:
-    the literal oracle reproduces it bit for bit, the running-residual oracle to parity tolerance."""
-    g, psc, stim, pri, opts = load_case("caviar_cfg2")
+@pytest.mark.parametrize("name", ["caviar_cfg2", "caviar_cfg3"])
+def test_oracle_vs_golden_bench_shapes(name):
+    """BASELINE configs[1] (N=300, K=1000, T=900; 12 iterations) and configs[2] -- the HEADLINE shape N=1000, K=2000, T=900; 8 iterations --
+    + fn_scan + final update_phi with every per-iteration history, recorded from the reference's own source (make_golden.py case_cfg2 /
+    case_cfg3): the literal oracle reproduces them bit for bit, the running-residual oracle to parity tolerance."""
+    g, psc, stim, pri, opts = load_case(name)
     sup = stim > 0
     for literal in (True, False):
         res = co.caviar(psc, stim, *prior_args(pri), literal=literal, **opts)
@@ -55,7 +57,10 @@ def test_oracle_vs_golden_cfg2():
             if literal:
                 assert np.array_equal(got, g["out_" + nm], equal_nan=True) and np.array_equal(hist, g["out_hist_" + nm], equal_nan=True), nm
             else:
-                assert rel_err(got, g["out_" + nm]) < 1e-8 and rel_err(hist, g["out_hist_" + nm]) < 1e-6, nm
+                # (cfg3 stops after 8 iterations, inside the phase in which the early ill-conditioned solves amplify rounding differences:
+                # the fast formulation's final phi_cov is 1.3e-8 from the literal one there; cfg2's 12 iterations are past it)
+                tol = 1e-8 if name == "caviar_cfg2" else 1e-7
+                assert rel_err(got, g["out_" + nm]) < tol and rel_err(hist, g["out_hist_" + nm]) < 1e-6, nm
 
 
 def test_explicit_streams_reproduce_seeded_run():
