@@ -57,23 +57,51 @@
                                   // directly); small on purpose: the kernel is latency-bound and LDS is what limits its wavefronts per CU
 __host__ __device__ static inline size_t build_prec_lds(int ld) { return (size_t)ld * sizeof(double) + CM_BP_ITEMS * (sizeof(double) + sizeof(int)); }
 
+// Per-solve staging for the build (k_bp_prepare, one thread per entry / active row), laid out in the circuit's `packed` buffer -- the record
+// stream of the Gauss-Seidel chain, dead between two sweeps: [N] BpRow | [nnz] BpEnt (CSR order) | [nnz] BpMate (CSC order).  With them a row's
+// wavefront reaches its operands in THREE dependent round trips (row record -> its trials' records -> their mates' records) instead of six
+// (act_idx -> row_ptr -> lam / col -> col_ptr -> csc_row / csc_pos -> act_inv / lam): the kernel is a chain of dependent gathers, its time
+// is its wavefronts times the length of that chain over its occupancy.
+struct __align__(16) BpRow { int e_beg, e_end, n, pad; };
+struct __align__(16) BpEnt { double le; int cs, cl; };          // lam of the entry; CSC range of its trial (cl = 0 when lam == 0: contributes nothing)
+struct __align__(16) BpMate { double l; int b, pad; };          // lam of the column mate, its active index (-1: not in the active set)
+__device__ __forceinline__ BpRow* bp_rows(const cm_pdev& p) { return reinterpret_cast<BpRow*>(p.packed); }
+__device__ __forceinline__ BpEnt* bp_ents(const cm_pdev& p) { return reinterpret_cast<BpEnt*>(reinterpret_cast<char*>(p.packed) + (size_t)p.N * 16); }
+__device__ __forceinline__ BpMate* bp_mates(const cm_pdev& p) { return reinterpret_cast<BpMate*>(reinterpret_cast<char*>(p.packed) + (size_t)p.N * 16 + (size_t)p.nnz * 16); }
+
+template <bool BATCH>
+__global__ __launch_bounds__(256) void k_bp_prepare(cm_parg<BATCH> pa, int na_arg, int skip_own) {
+  CM_SOLVE_PROLOGUE(2)
+  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < na) {
+    const int n = p.act_idx[j];
+    BpRow r; r.e_beg = p.row_ptr[n]; r.e_end = p.row_ptr[n + 1]; r.n = n; r.pad = 0;
+    bp_rows(p)[j] = r;
+  }
+  if (j < p.nnz) {
+    const double le = p.lam[j];
+    const int k = p.col[j];
+    BpEnt e; e.le = le; e.cs = 0; e.cl = 0;
+    if (le != 0.0) { e.cs = p.col_ptr[k]; e.cl = p.col_ptr[k + 1] - e.cs; }
+    bp_ents(p)[j] = e;
+    BpMate m; m.b = p.act_inv[p.csc_row[j]]; m.l = p.lam[p.csc_pos[j]]; m.pad = 0;
+    bp_mates(p)[j] = m;
+  }
+}
+
 template <bool BATCH>
 __global__ __launch_bounds__(64) void k_build_precision(cm_parg<BATCH> pa, int na_arg, int skip_own, int row0, int acc_len) {
-  CM_SOLVE_PROLOGUE(2)
+  int bx = (int)blockIdx.x, circ = 0;
+  if (BATCH) cm_xcd_remap(bx, circ, 2);              // a circuit's rows on one XCD, circuit after circuit: its staged records (0.7 MB) stay in that L2
+  CM_SOLVE_PROLOGUE_AT(2, pa.get(circ))
   const int n_act = na;
-  if (row0 + (int)blockIdx.x >= nrow) return;
-  const double* __restrict__ lam = p.lam;
-  const int* __restrict__ row_ptr = p.row_ptr;
-  const int* __restrict__ col = p.col;
-  const int* __restrict__ col_ptr = p.col_ptr;
-  const int* __restrict__ csc_row = p.csc_row;
-  const int* __restrict__ csc_pos = p.csc_pos;
-  const int* __restrict__ act_idx = p.act_idx;
-  const int* __restrict__ act_inv = p.act_inv;
+  if (row0 + bx >= nrow) return;
   const double* __restrict__ rs = p.rs;
   const double* __restrict__ scal = p.scal;
   const double* __restrict__ mu_prior = p.mu_prior;
   const double* __restrict__ beta_prior = p.beta_prior;
+  const BpEnt* __restrict__ ents = bp_ents(p);
+  const BpMate* __restrict__ mates = bp_mates(p);
   double* __restrict__ A = p.A;
   double* __restrict__ rhs = p.rhs;
   extern __shared__ double acc[];                  // [acc_len] accumulator row (the launch covers rows whose diagonal tile ends at or before acc_len), then the staged items
@@ -81,7 +109,7 @@ __global__ __launch_bounds__(64) void k_build_precision(cm_parg<BATCH> pa, int n
   int* ib = reinterpret_cast<int*>(il + CM_BP_ITEMS);   // [CM_BP_ITEMS] its active index (-1: not in the active set)
   __shared__ int s_off[CM_WAVE], s_cs[CM_WAVE];
   __shared__ double s_le[CM_WAVE];
-  const int a = row0 + (int)blockIdx.x;
+  const int a = row0 + bx;
   const int lane = threadIdx.x;
   double* Arow = A + (size_t)a * ld;
   // Only the tiles on and below the diagonal are ever read (the factorisation works on the lower triangle, the inverse uses the
@@ -92,17 +120,18 @@ __global__ __launch_bounds__(64) void k_build_precision(cm_parg<BATCH> pa, int n
     if (lane == 0) rhs[a] = 0.0;
     return;
   }
+  const BpRow row = bp_rows(p)[a];
   for (int b = lane; b < b_end; b += CM_WAVE) acc[b] = 0.0;
-  const int n = act_idx[a];
+  const int n = row.n;
   const double sig = scal[CM_S_SHAPE] / scal[CM_S_RATE];
-  const int e_beg = row_ptr[n], e_end = row_ptr[n + 1];
+  const int e_beg = row.e_beg, e_end = row.e_end;
   for (int e0 = e_beg; e0 < e_end; e0 += CM_WAVE) {          // 64 trials of the row at a time, one per lane
     const int e = e0 + lane;
     const bool have = e < e_end;
-    const double le = have ? lam[e] : 0.0;
-    const int k = have ? col[e] : 0;
-    int cs = 0, cl = 0;
-    if (have && le != 0.0) { cs = col_ptr[k]; cl = col_ptr[k + 1] - cs; }
+    BpEnt en; en.le = 0.0; en.cs = 0; en.cl = 0;
+    if (have) en = ents[e];
+    const double le = en.le;
+    const int cs = en.cs, cl = en.cl;
     int incl = cl;                                            // inclusive wave scan of the column lengths
 #pragma unroll
     for (int d = 1; d < CM_WAVE; d <<= 1) { const int v = __shfl_up(incl, d, CM_WAVE); if (lane >= d) incl += v; }
@@ -120,8 +149,8 @@ __global__ __launch_bounds__(64) void k_build_precision(cm_parg<BATCH> pa, int n
         const double lj = s_le[j0];
         const int c0 = s_cs[j0], c1 = c0 + __builtin_amdgcn_readlane(cl, j0);
         for (int ce = c0 + lane; ce < c1; ce += CM_WAVE) {
-          const int b = act_inv[csc_row[ce]];
-          if (b >= 0 && b < b_end) acc[b] = fma(lj, lam[csc_pos[ce]], acc[b]);   // (columns beyond the diagonal tile are never stored: not accumulated either)
+          const BpMate m = mates[ce];
+          if (m.b >= 0 && m.b < b_end) acc[m.b] = fma(lj, m.l, acc[m.b]);   // (columns beyond the diagonal tile are never stored: not accumulated either)
         }
         __builtin_amdgcn_wave_barrier();
         ++j0;
@@ -130,7 +159,7 @@ __global__ __launch_bounds__(64) void k_build_precision(cm_parg<BATCH> pa, int n
       const int j1 = j0 + n_take, cnt = __builtin_amdgcn_readlane(incl, j1 - 1) - base;
       // gather: item g of the list belongs to the trial j with s_off[j] <= g < s_off[j + 1]
       for (int it0 = 0; it0 < cnt; it0 += 4 * CM_WAVE) {
-        int ce[4], pos[4], row[4];
+        int ce[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int it = it0 + q * CM_WAVE + lane;
@@ -142,16 +171,13 @@ __global__ __launch_bounds__(64) void k_build_precision(cm_parg<BATCH> pa, int n
             ce[q] = s_cs[lo] + (g - s_off[lo]);
           }
         }
+        BpMate mq[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { row[q] = ce[q] >= 0 ? csc_row[ce[q]] : 0; pos[q] = ce[q] >= 0 ? csc_pos[ce[q]] : 0; }
-        int bq[4];
-        double lq[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { bq[q] = ce[q] >= 0 ? act_inv[row[q]] : -1; lq[q] = ce[q] >= 0 ? lam[pos[q]] : 0.0; }
+        for (int q = 0; q < 4; ++q) { mq[q].b = -1; mq[q].l = 0.0; if (ce[q] >= 0) mq[q] = mates[ce[q]]; }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int it = it0 + q * CM_WAVE + lane;
-          if (it < cnt) { ib[it] = bq[q]; il[it] = lq[q]; }
+          if (it < cnt) { ib[it] = mq[q].b; il[it] = mq[q].l; }
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -1013,69 +1039,106 @@ __global__ __launch_bounds__(256) void k_inv_X21(cm_parg<BATCH> pa, int na_arg, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// w = X rhs (rows), then mu_c = sum_r X[r][c] w_r, beta_c = sum_r X[r][c]^2 (columns, two stages, fixed order)
+// mu = X^T (X rhs), beta = colsum(X^2)  (X = L^-1: Sigma = X^T X, caviar.py:170-172) in ONE pass over X.
+//
+// One 1024-thread workgroup per HALF tile row h (16 rows of X, columns through the diagonal tile): thread t holds column t of the 16 rows in
+// registers (a slab of 1024 columns; matrices beyond 1024 rows walk their slabs twice).  Phase A: w_r = sum_c X[r][c] rhs[c].  The 16 row
+// sums of a wavefront come out of ONE transposing butterfly instead of 16 reductions: at every step a lane hands the half of its values
+// that its partner keeps to that partner and adds what it receives (DPP: mirror within 16, mirror within 8, xor 1, xor 2: 8 + 4 + 2 + 1
+// exchanges), after which lane l of every 16-lane row holds the sum of row mb_row(l) over its 16 lanes; two cross-row adds finish the 64
+// lanes, the 16 wave partials are added in wave order.  Phase B, from the same registers: the half tile row's contribution to
+// mu_c = sum_r X[r][c] w_r and beta_c = sum_r X[r][c]^2, rows ascending, written to the factor's storage (dead by now) as partial sums per
+// half tile row; k_colsum_final adds them in order.  Every summation order is fixed: results are reproducible and identical for a circuit
+// alone and in a batch.  (Before: k_tri_matvec + k_colsum_partial streamed X twice -- 0.98 GB per 256 x n = 1000 solve.)
 // ------------------------------------------------------------------------------------------------
+#define CM_MB_THREADS 1024
+#define CM_MB_ROWS 16
+template <int CTRL, int HALF>
+__device__ __forceinline__ void mb_step(double (&v)[CM_MB_ROWS], bool upper) {
+#pragma unroll
+  for (int q = 0; q < HALF; ++q) {
+    const double keep = upper ? v[HALF + q] : v[q], send = upper ? v[q] : v[HALF + q];
+    v[q] = keep + cm_dpp_f64<CTRL>(send);
+  }
+}
+// row (0..15) whose sum lane l of a 16-lane row holds after the four steps: bit 3 and bit 2 from the lane's, bit 1 from lane bit 0, bit 0 from lane bit 1
+__device__ __forceinline__ int mb_row(int l) { return (l & 12) | ((l & 1) << 1) | ((l >> 1) & 1); }
+
 template <bool BATCH>
-__global__ __launch_bounds__(256) void k_tri_matvec(cm_parg<BATCH> pa, int na_arg, int skip_own) {
+__global__ __launch_bounds__(CM_MB_THREADS, BATCH ? 8 : 4) void k_mu_beta_rows(cm_parg<BATCH> pa, int na_arg, int skip_own) {
   CM_SOLVE_PROLOGUE(2)
+  const int h = 2 * nblk - 1 - (int)blockIdx.x;  // (the long rows first)
+  if (h < 0) return;
   const double* __restrict__ X = p.X;
   const double* __restrict__ rhs = p.rhs;
-  double* __restrict__ w = p.rhs + p.ld_alloc;
-  const int n = na;
-  const int r = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE;
-  const int lane = threadIdx.x % CM_WAVE;
-  if (r >= n) return;
-  double s = 0.0;
-  for (int c = lane; c <= r; c += CM_WAVE) s = fma(X[(size_t)r * ld + c], rhs[c], s);
-  s = cm_wave_sum(s);
-  if (lane == 0) w[r] = s;
-}
-
-#define CM_COLCHUNK 64
-// grid.x = nbx * nchunks (largest matrix of the set): block -> (column block, row chunk)
-template <bool BATCH>
-__global__ __launch_bounds__(64) void k_colsum_partial(cm_parg<BATCH> pa, int na_arg, int skip_own, int nbx) {
-  CM_SOLVE_PROLOGUE(2)
-  const double* __restrict__ X = p.X;
-  const double* __restrict__ w = p.rhs + p.ld_alloc;
-  double* __restrict__ part = p.A;               // the factor is no longer needed: its storage takes the partial column sums
-  const int n = na;
-  const int c = ((int)blockIdx.x % nbx) * 64 + threadIdx.x;
-  const int chunk = (int)blockIdx.x / nbx;
-  const int rbeg = chunk * CM_COLCHUNK, rend = min(n, rbeg + CM_COLCHUNK);
-  if (rbeg >= n || ((int)blockIdx.x % nbx) * 64 >= nrow) return;
-  double sm = 0.0, sb = 0.0;
-  if (c < n) {
-    // 8 independent loads in flight, then the 8 accumulations in row order (the summation order is part of the result)
-    for (int r0 = max(rbeg, c); r0 < rend; r0 += 8) {
-      double x[8], ww[8];
+  double* __restrict__ part = p.A;               // the factor is no longer needed: its storage takes the partial column sums [2 nblk][2][ld]
+  __shared__ double wpart[CM_MB_THREADS / CM_WAVE][CM_MB_ROWS];
+  __shared__ double wsh[CM_MB_ROWS];
+  const int tid = threadIdx.x, wave = tid / CM_WAVE, lane = tid % CM_WAVE;
+  const int r0 = h * CM_MB_ROWS, ncol = (h / 2 + 1) * TS;
+  if (r0 >= na) return;                          // (rows of the identity padding: nothing to add)
+  const int nslab = (ncol + CM_MB_THREADS - 1) / CM_MB_THREADS;
+  double x[CM_MB_ROWS];
+  auto load_slab = [&](int sl) {
+    const int c = sl * CM_MB_THREADS + tid;
+    const double* src = X + (size_t)r0 * ld + c;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int r = r0 + i < rend ? r0 + i : rend - 1;
-        x[i] = X[(size_t)r * ld + c];
-        ww[i] = w[r];
-      }
+    for (int rr = 0; rr < CM_MB_ROWS; ++rr) x[rr] = (c <= r0 + rr && r0 + rr < na) ? src[(size_t)rr * ld] : 0.0;   // lower triangle, rows of the active set
+  };
+  // ---- phase A: w_r = sum_c X[r][c] rhs[c]
+  for (int sl = 0; sl < nslab; ++sl) {
+    const int c = sl * CM_MB_THREADS + tid;
+    double tot = 0.0;
+    if (sl * CM_MB_THREADS + wave * CM_WAVE < ncol) {            // (wave-uniform: a wavefront whose columns lie beyond the diagonal tile adds nothing)
+      load_slab(sl);
+      const double rc = c < ncol ? rhs[c] : 0.0;
+      double v[CM_MB_ROWS];
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (r0 + i < rend) { sm = fma(x[i], ww[i], sm); sb = fma(x[i], x[i], sb); }
+      for (int rr = 0; rr < CM_MB_ROWS; ++rr) v[rr] = x[rr] * rc;
+      mb_step<CM_DPP_MIRROR, 8>(v, (lane & 8) != 0);
+      mb_step<CM_DPP_HALF_MIRROR, 4>(v, (lane & 4) != 0);
+      mb_step<CM_DPP_XOR1, 2>(v, (lane & 1) != 0);
+      mb_step<CM_DPP_XOR2, 1>(v, (lane & 2) != 0);
+      tot = v[0];
+      tot += __shfl_xor(tot, 16, CM_WAVE);
+      tot += __shfl_xor(tot, 32, CM_WAVE);
     }
+    if (lane < CM_MB_ROWS) wpart[wave][mb_row(lane)] = (sl == 0) ? tot : wpart[wave][mb_row(lane)] + tot;
   }
-  if (c < nrow) {
-    part[((size_t)chunk * 2 + 0) * ld + c] = sm;
-    part[((size_t)chunk * 2 + 1) * ld + c] = sb;
+  __syncthreads();
+  if (tid < CM_MB_ROWS) {
+    double w = 0.0;
+#pragma unroll
+    for (int wv = 0; wv < CM_MB_THREADS / CM_WAVE; ++wv) w += wpart[wv][tid];
+    wsh[tid] = w;
+  }
+  __syncthreads();
+  // ---- phase B: this half tile row's share of the column sums (one slab: straight from the registers of phase A)
+  for (int sl = 0; sl < nslab; ++sl) {
+    if (sl * CM_MB_THREADS + wave * CM_WAVE >= ncol) continue;
+    if (nslab > 1) load_slab(sl);
+    const int c = sl * CM_MB_THREADS + tid;
+    double sm = 0.0, sb = 0.0;
+#pragma unroll
+    for (int rr = 0; rr < CM_MB_ROWS; ++rr) { sm = fma(x[rr], wsh[rr], sm); sb = fma(x[rr], x[rr], sb); }
+    if (c < ncol) {
+      part[((size_t)h * 2 + 0) * ld + c] = sm;
+      part[((size_t)h * 2 + 1) * ld + c] = sb;
+    }
   }
 }
 template <bool BATCH>
 __global__ __launch_bounds__(256) void k_colsum_final(cm_parg<BATCH> pa, int na_arg, int skip_own) {
   CM_SOLVE_PROLOGUE(2)
   const double* __restrict__ part = p.A;
-  const int n = na, nchunks = (na + CM_COLCHUNK - 1) / CM_COLCHUNK;
+  const int n = na;
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n) return;
+  const int hend = (n + CM_MB_ROWS - 1) / CM_MB_ROWS;     // half tile rows that hold rows of the active set
   double sm = 0.0, sb = 0.0;
-  for (int ch = 0; ch < nchunks; ++ch) {
-    sm += part[((size_t)ch * 2 + 0) * ld + c];
-    sb += part[((size_t)ch * 2 + 1) * ld + c];
+  for (int h = (c / TS) * 2; h < hend; ++h) {      // half tile rows that hold column c, in order
+    sm += part[((size_t)h * 2 + 0) * ld + c];
+    sb += part[((size_t)h * 2 + 1) * ld + c];
   }
   const int nn = p.act_idx[c];
   p.mu[nn] = sm;
@@ -1111,7 +1174,7 @@ int cm_solve_mu(cm_ctx* ctx, cm_set& s, int* n_active_out) {
 static inline bool cm_use_grouped(const cm_ctx* ctx, bool single) { return ctx->chol_family == 2 || (ctx->chol_family == 1 && !single); }
 
 // One group of circuits through the tiled solve; `parts`: 1 = precision matrices, 2 = Cholesky, 4 = inverse of the factor, 8 = mu / beta.
-struct cm_solve_sub { int B; bool single; cm_pdev h0; const cm_pdev* d_arr; };
+struct cm_solve_sub { int B; bool single; cm_pdev h0; const cm_pdev* d_arr; long long nnz_max = 0; };
 static int cm_solve_group_launch(cm_ctx* ctx, const cm_solve_sub& g, int nblk, int na_g, int na1, int skip_le, int xflags, int large_min, int parts,
                                  hipEvent_t fact_begin, hipEvent_t fact_end) {
   hipStream_t st = ctx->stream;
@@ -1132,6 +1195,7 @@ static int cm_solve_group_launch(cm_ctx* ctx, const cm_solve_sub& g, int nblk, i
     // Row a accumulates columns up to the end of its diagonal tile only, and the kernel's wavefronts per CU are set by the LDS row they hold: a
     // batch launches the rows in four bands, each with the accumulator its last row needs (5 / 7 / 9 / 11 KB instead of 11 for all at n = 1000:
     // 20 instead of 14 wavefronts per CU on average -- the kernel is a chain of dependent gathers, its time is its wavefronts over its occupancy)
+    CM_LAUNCH_G(k_bp_prepare, (unsigned)((std::max<long long>(g.nnz_max, na_g) + 255) / 256), 256, 0, na1, skip_le);
     const int bands = (!g.single && ld >= 16 * TS) ? 4 : 1;
     for (int q = 0; q < bands; ++q) {
       const int r0 = ((ld / TS) * q / bands) * TS, r1 = ((ld / TS) * (q + 1) / bands) * TS;
@@ -1184,9 +1248,7 @@ static int cm_solve_group_launch(cm_ctx* ctx, const cm_solve_sub& g, int nblk, i
     }
   }
   if (parts & 8) {
-    CM_LAUNCH_G(k_tri_matvec, (na_g + 3) / 4, 256, 0, na1, skip_le);
-    const int nchunks = (na_g + CM_COLCHUNK - 1) / CM_COLCHUNK, nbx = (ld + 63) / 64;
-    CM_LAUNCH_G(k_colsum_partial, nbx * nchunks, 64, 0, na1, skip_le, nbx);
+    CM_LAUNCH_G(k_mu_beta_rows, 2 * nblk, CM_MB_THREADS, 0, na1, skip_le);
     CM_LAUNCH_G(k_colsum_final, (na_g + 255) / 256, 256, 0, na1, skip_le);
   }
 #undef CM_LAUNCH_G
@@ -1346,6 +1408,7 @@ int cm_solve_launch(cm_ctx* ctx, cm_set& s, int skip_mode, hipEvent_t fact_begin
     g.single = s.B == 1;
     if (s.B == 1) g.h0 = s.h0;
     g.d_arr = s.d_arr ? s.d_arr + c0 : nullptr;
+    g.nnz_max = s.nnz_max;
     int nblk = 0, na_g = 0;
     for (int c = c0; c < c0 + g.B; ++c) {
       if (cm_solve_kind(s.na[c], s.ps[c]->small_cap, skip_mode >= 0) != 2) continue;
