@@ -1513,6 +1513,24 @@ extern "C" int cm_k_event_pair_overhead(cm_ctx* ctx, int32_t reps, int32_t block
   return CM_OK;
 }
 
+int cm_k_ndtri_impl(cm_ctx* ctx, int n, const double* d_p, double* d_out);
+extern "C" int cm_k_ndtri(cm_ctx* ctx, int32_t n, const double* p, double* out) {
+  if (!ctx || !p || !out || n < 1) { cm_set_error("cm_k_ndtri: bad argument"); return CM_ERR_INVALID; }
+  CM_HIP(hipSetDevice(ctx->device));
+  double *d_p = nullptr, *d_o = nullptr;
+  int rc = CM_OK;
+  if ((rc = dmalloc(&d_p, (size_t)n)) || (rc = dmalloc(&d_o, (size_t)n))) {
+  } else if (hipMemcpyAsync(d_p, p, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { cm_set_error("cm_k_ndtri: upload failed"); rc = CM_ERR_HIP; }
+  if (!rc) rc = cm_k_ndtri_impl(ctx, n, d_p, d_o);
+  if (!rc && (hipMemcpyAsync(out, d_o, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)) {
+    cm_set_error("cm_k_ndtri: download failed: %s", hipGetErrorString(hipGetLastError())); rc = CM_ERR_HIP;
+  }
+  hipStreamSynchronize(ctx->stream);
+  if (d_p) hipFree(d_p);
+  if (d_o) hipFree(d_o);
+  return rc;
+}
+
 extern "C" int cm_k_rng_streams(cm_ctx* ctx, uint64_t seed, int32_t it, int32_t N, int32_t S, int32_t* order, double* u) {
   if (!ctx || !order || !u || N < 2 || S < 1 || it < 0) { cm_set_error("cm_k_rng_streams: bad argument"); return CM_ERR_INVALID; }
   CM_HIP(hipSetDevice(ctx->device));

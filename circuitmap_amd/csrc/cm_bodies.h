@@ -616,6 +616,172 @@ __device__ __forceinline__ void phi_body(int n, int lane, const double* __restri
 }
 
 
+// TWO rows per wavefront, one per 32-lane half: lanes 0-31 carry row `n` of the lower half, lanes 32-63 that of the upper half (n < 0: the
+// half has no row).  The Newton iteration is a chain of ~260-instruction steps whose time is its instruction stream: a ~20-entry row with
+// four stimulus values left most of a 64-lane wavefront's evaluation points unused (16 of them, of which the first candidate is accepted in
+// nearly every step); with a row per half the same stream serves two rows, each with E = 32 / SEG evaluation points (SEG = 4: the objective
+// at phi and seven step candidates per round).  Each half runs exactly the single-row iteration -- the same sufficient statistics, the same
+// sums within a segment, the first accepted candidate in the reference's order (caviar.py:259-268) -- so a row's result does not depend on
+// its partner, on which half it sits in or on the kernel that evaluates it; a half that is finished (fixed point, or no row) idles through
+// its partner's remaining steps.  SEG <= 16 (two evaluation points per half at least); larger SEG: phi_pair below falls back to phi_body.
+template <int SEG, bool DEAD = false>
+__device__ __forceinline__ void phi_body2(int n, int lane, const double* __restrict__ lam, const int* __restrict__ row_ptr,
+                                          const uint8_t* __restrict__ grp, const int* __restrict__ rowcnt,
+                                          const double* __restrict__ vals, int V,
+                                          const double* __restrict__ phi_prior, const double* __restrict__ phi_cov_prior,
+                                          double* __restrict__ phi, double* __restrict__ phi_cov, double out[4],
+                                          const double* etab, const double* ltab,
+                                          const double* __restrict__ dead_phi = nullptr, const double* __restrict__ dead_cov = nullptr) {
+  static_assert(SEG <= 16, "two evaluation points per half");
+  constexpr int E = 32 / SEG;
+  const int hl = lane & 31, hb = lane & 32;
+  const int g = hl % SEG, ev = hl / SEG;
+  const bool row = n >= 0;
+  const int nn = row ? n : 0;
+  // sufficient statistics of value g: segment `ev` of the half scans entries ev, ev + E, ...; partial sums are then combined across the
+  // half's segments (lanes at stride SEG)
+  const bool on = row && g < V;
+  const double val = on ? vals[g] : 0.0;
+  const double cnt = on ? (double)rowcnt[(size_t)nn * CM_MAX_VALS + g] : 0.0;
+  double n1 = 0.0, nmid = 0.0, smid = 0.0;
+  if (!DEAD && on && val > 0.0) {              // untargeted values carry lam == 0 on every trial
+    for (int e = row_ptr[nn] + ev; e < row_ptr[nn + 1]; e += E) {
+      if (grp[e] != g) continue;
+      const double l = lam[e];
+      if (l == 1.0) n1 += 1.0;
+      else if (l > 0.0 && l < 1.0) { nmid += 1.0; smid += l; }
+    }
+  }
+#pragma unroll
+  for (int o = SEG; o < 32; o <<= 1) {
+    n1 += __shfl_xor(n1, o, CM_WAVE); nmid += __shfl_xor(nmid, o, CM_WAVE); smid += __shfl_xor(smid, o, CM_WAVE);
+  }
+  const double n0 = cnt - n1 - nmid;
+  const double sy = n1 + smid;
+  bool done = !row;
+  out[0] = out[1] = out[2] = out[3] = 0.0;
+  if (!DEAD && dead_phi != nullptr) {
+    const unsigned zero_h = (unsigned)(__ballot(n1 == 0.0 && nmid == 0.0) >> hb);
+    if (row && zero_h == 0xFFFFFFFFu) {
+      // the row turned out to be identically zero: its result is the per-run constant of this neuron (k_phi_dead ran this very
+      // function on those statistics)
+      const double p0c = dead_phi[2 * nn], p1c = dead_phi[2 * nn + 1];
+      double cv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cv[i] = dead_cov[4 * nn + i];
+      if (hl == 0) {
+        phi[2 * nn] = p0c; phi[2 * nn + 1] = p1c;
+        phi_cov[4 * nn] = cv[0]; phi_cov[4 * nn + 1] = cv[1]; phi_cov[4 * nn + 2] = cv[2]; phi_cov[4 * nn + 3] = cv[3];
+      }
+      out[0] = p0c; out[1] = p1c; out[2] = cv[0]; out[3] = cv[3];
+      done = true;
+    }
+  }
+  if (__all(done)) return;
+  const bool live = !done;                        // this half runs the Newton iteration (and writes its result)
+  const double pr0 = phi_prior[2 * nn], pr1 = phi_prior[2 * nn + 1];
+  double prec[4];
+  inv2x2(phi_cov_prior[4 * nn], phi_cov_prior[4 * nn + 1], phi_cov_prior[4 * nn + 2], phi_cov_prior[4 * nn + 3], prec);   // caviar.py:306
+  const double t = 1e1, alpha = 0.25;
+  double p0 = pr0, p1 = pr1;                     // caviar.py:305: restart from the prior every call (quirk 3)
+  double cov[4] = {0, 0, 0, 0};
+  double fcur = 0.0;                              // sigmoid(p0 * val - p1) of this lane's value at the current phi
+  bool have_f = false;
+  for (int stepi = 0; stepi < 10; ++stepi) {     // caviar.py:308
+    if (__all(done)) break;
+    double j1 = 0.0, j2 = 0.0, h11 = 0.0, h12 = 0.0, h22 = 0.0;
+    if (on) {
+      // the accepted candidate of the previous step evaluated exactly this sigmoid (same expression, same operands)
+      const double f = have_f ? fcur : cm_sigmoid_tab(p0 * val - p1, etab);
+      const double r = sy - cnt * f;
+      j1 = -val * r; j2 = r;
+      const double ff = cnt * f * (1.0 - f);
+      h11 = val * val * ff; h12 = -val * ff; h22 = ff;
+    }
+    j1 = cm_seg_sum<SEG>(j1); j2 = cm_seg_sum<SEG>(j2);
+    h11 = cm_seg_sum<SEG>(h11); h12 = cm_seg_sum<SEG>(h12); h22 = cm_seg_sum<SEG>(h22);
+    const double d0 = p0 - pr0, d1 = p1 - pr1;
+    const double J0 = j1 + (prec[0] * d0 + prec[1] * d1) - 1.0 / (t * p0);      // caviar.py:278-280
+    const double J1 = j2 + (prec[2] * d0 + prec[3] * d1) - 1.0 / (t * p1);
+    double covn[4];
+    inv2x2(h11 + prec[0] + 1.0 / (t * p0 * p0), h12 + prec[1], h12 + prec[2], h22 + prec[3] + 1.0 / (t * p1 * p1), covn);   // :283-289
+    const double v0 = -(covn[0] * J0 + covn[1] * J1), v1 = -(covn[2] * J0 + covn[3] * J1);
+    const double Jv = J0 * v0 + J1 * v1;
+    // candidates b = 0..40 (step 2^-b); b <= 39 needs its Armijo test to pass, b = 40 is taken unconditionally
+    int accepted = -1;
+    double f0 = 0.0;
+    int base = 0;                                 // first candidate of this round (the two halves walk their rounds in step)
+    bool first = true;
+    while (base < 40) {
+      const bool need = !done && accepted < 0;
+      if (!__any(need)) break;
+      const int b = first ? base + ev - 1 : base + ev;       // first round: segment 0 evaluates phi itself
+      const bool is_f0 = first && ev == 0;
+      const double st = is_f0 ? 0.0 : ldexp(1.0, -b);
+      const double q0 = is_f0 ? p0 : p0 + st * v0, q1 = is_f0 ? p1 : p1 + st * v1;
+      double sg;
+      const double fv = phi_nll<SEG>(q0, q1, val, n0, n1, smid, nmid, on, g, pr0, pr1, prec, t, &sg, etab, ltab);
+      if (first) f0 = __shfl(fv, hb, CM_WAVE);               // (segment 0 of the half: the objective at phi)
+      const double rhs = f0 + alpha * st * Jv;
+      const bool ok = need && !is_f0 && b <= 39 && !(isnan(fv) || fv > rhs);
+      const unsigned mh = (unsigned)(__ballot(ok) >> hb);    // this half's accepting lanes
+      const int seg = mh ? (__ffs((int)mh) - 1) / SEG : 0;   // first accepting segment of this round
+      const double fsel = __shfl(sg, hb + seg * SEG + g, CM_WAVE);   // its sigmoid for this lane's value
+      if (need && mh) { accepted = (first ? base - 1 : base) + seg; fcur = fsel; }
+      base += first ? E - 1 : E;
+      first = false;
+    }
+    if (!done) {
+      have_f = accepted >= 0;                      // b = 40 is taken without an evaluation: recompute next step
+      if (accepted < 0) accepted = 40;
+      const double step = ldexp(1.0, -accepted);
+      const double q0 = p0 + step * v0, q1 = p1 + step * v1;                        // caviar.py:301
+      // A step that leaves phi bit-for-bit unchanged is a fixed point of the loop body: every later step would recompute the same
+      // J, H, covariance and (rejected) candidates and leave phi unchanged again, so the remaining steps are skipped -- exactly
+      // the reference's result.  Converged neurons are the expensive ones otherwise: their Armijo test fails for all 40 candidates.
+      const bool fixed = (q0 == p0) && (q1 == p1);
+      p0 = q0; p1 = q1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cov[i] = covn[i];
+      if (fixed) done = true;
+    }
+  }
+  if (live) {
+    if (hl == 0) {
+      phi[2 * nn] = p0; phi[2 * nn + 1] = p1;
+      phi_cov[4 * nn] = cov[0]; phi_cov[4 * nn + 1] = cov[1]; phi_cov[4 * nn + 2] = cov[2]; phi_cov[4 * nn + 3] = cov[3];
+    }
+    out[0] = p0; out[1] = p1; out[2] = cov[0]; out[3] = cov[3];     // mean and variance diagonal, for the MC logit that follows
+  }
+}
+
+// update_phi of the rows of a wavefront's two halves (n < 0: none): the pair iteration for SEG <= 16, one row after the other through the
+// single-row body beyond (more than 16 stimulus values).  EVERY kernel evaluates update_phi through this function, so a row's result is the
+// same bits wherever it is computed.  out[]: (phi_0, phi_1, cov_00, cov_11) of the lane's half.
+template <int SEG, bool DEAD = false>
+__device__ __forceinline__ void phi_pair(int n, int lane, const double* __restrict__ lam, const int* __restrict__ row_ptr,
+                                         const uint8_t* __restrict__ grp, const int* __restrict__ rowcnt,
+                                         const double* __restrict__ vals, int V,
+                                         const double* __restrict__ phi_prior, const double* __restrict__ phi_cov_prior,
+                                         double* __restrict__ phi, double* __restrict__ phi_cov, double out[4],
+                                         const double* etab, const double* ltab,
+                                         const double* __restrict__ dead_phi = nullptr, const double* __restrict__ dead_cov = nullptr) {
+  if constexpr (SEG <= 16) {
+    phi_body2<SEG, DEAD>(n, lane, lam, row_ptr, grp, rowcnt, vals, V, phi_prior, phi_cov_prior, phi, phi_cov, out, etab, ltab, dead_phi, dead_cov);
+  } else {
+    out[0] = out[1] = out[2] = out[3] = 0.0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int rown = __builtin_amdgcn_readlane(n, 32 * h);
+      if (rown < 0) continue;
+      double o[4];
+      phi_body<SEG, DEAD>(rown, lane, lam, row_ptr, grp, rowcnt, vals, V, phi_prior, phi_cov_prior, phi, phi_cov, o, etab, ltab, dead_phi, dead_cov);
+      if ((lane >> 5) == h) { out[0] = o[0]; out[1] = o[1]; out[2] = o[2]; out[3] = o[3]; }
+    }
+  }
+}
+
+
 // ------------------------------------------------------------------------------------------------
 // Small active sets (the steady state of a fit): the whole block_update_mu (caviar.py:166-172) in ONE workgroup, in LDS.
 //   1. stage the active rows' (trial, lam) lists;  2. A_ab = sigma * sum_k lam_ak lam_bk by merge-intersection of the two
@@ -788,8 +954,63 @@ __device__ __forceinline__ double cm_logit_of_sigmoid(double x, const double* et
   return cm_logit_literal(x);
 }
 
+// ndtri (the standard normal quantile of caviar.py:212; jax.scipy.special.ndtri in the reference, a third-party routine): Wichura's
+// algorithm AS 241, PPND16 (Applied Statistics 37, 1988) -- a degree-7 / degree-7 rational function of r = 0.180625 - (p - 1/2)^2 in the
+// centre |p - 1/2| <= 0.425 and of sqrt(-log(min(p, 1 - p))) in the tails, relative error about 1e-16 (measured against SciPy's ndtri over
+// 2.4e6 arguments incl. tails down to 1e-300: 1.1e-15).  ~30 instructions in the centre, ~110 in a tail, where the device library's
+// normcdfinv is a 1290-instruction routine (several hundred executed): every live row draws 2 S of these per iteration, which made the
+// quantile most of the early iterations' k_iter_mid.  p = 0 -> -inf, p = 1 -> +inf, outside [0, 1] or NaN -> NaN.
+__device__ __forceinline__ double cm_div_fast(double a, double b) {      // a / b for normal-range b: reciprocal (two Newton steps) and one residual correction
+  double r = __builtin_amdgcn_rcp(b);
+  r = fma(fma(-b, r, 1.0), r, r);
+  r = fma(fma(-b, r, 1.0), r, r);
+  const double q = a * r;
+  return fma(fma(-b, q, a), r, q);
+}
+__device__ __forceinline__ double cm_ndtri(double p) {
+  const double q = p - 0.5;
+  if (fabs(q) <= 0.425) {
+    const double r = 0.180625 - q * q;
+    double n = 2.5090809287301226727e3, d = 5.2264952788528545610e3;
+    n = fma(n, r, 3.3430575583588128105e4); d = fma(d, r, 2.8729085735721942674e4);
+    n = fma(n, r, 6.7265770927008700853e4); d = fma(d, r, 3.9307895800092710610e4);
+    n = fma(n, r, 4.5921953931549871457e4); d = fma(d, r, 2.1213794301586595867e4);
+    n = fma(n, r, 1.3731693765509461125e4); d = fma(d, r, 5.3941960214247511077e3);
+    n = fma(n, r, 1.9715909503065514427e3); d = fma(d, r, 6.8718700749205790830e2);
+    n = fma(n, r, 1.3314166789178437745e2); d = fma(d, r, 4.2313330701600911252e1);
+    n = fma(n, r, 3.3871328727963666080e0); d = fma(d, r, 1.0);
+    return q * cm_div_fast(n, d);
+  }
+  double r = q < 0.0 ? p : 1.0 - p;
+  if (!(r > 0.0)) return r == 0.0 ? (q < 0.0 ? -INFINITY : INFINITY) : NAN;      // p = 0, p = 1; p outside [0, 1] or NaN
+  r = sqrt(-log(r));
+  double n, d;
+  if (r <= 5.0) {
+    r -= 1.6;
+    n = 7.74545014278341407640e-4; d = 1.05075007164441684324e-9;
+    n = fma(n, r, 2.27238449892691845833e-2); d = fma(d, r, 5.47593808499534494600e-4);
+    n = fma(n, r, 2.41780725177450611770e-1); d = fma(d, r, 1.51986665636164571966e-2);
+    n = fma(n, r, 1.27045825245236838258e0); d = fma(d, r, 1.48103976427480074590e-1);
+    n = fma(n, r, 3.64784832476320460504e0); d = fma(d, r, 6.89767334985100004550e-1);
+    n = fma(n, r, 5.76949722146069140550e0); d = fma(d, r, 1.67638483018380384940e0);
+    n = fma(n, r, 4.63033784615654529590e0); d = fma(d, r, 2.05319162663775882187e0);
+    n = fma(n, r, 1.42343711074968357734e0); d = fma(d, r, 1.0);
+  } else {
+    r -= 5.0;
+    n = 2.01033439929228813265e-7; d = 2.04426310338993978564e-15;
+    n = fma(n, r, 2.71155556874348757815e-5); d = fma(d, r, 1.42151175831644588870e-7);
+    n = fma(n, r, 1.24266094738807843860e-3); d = fma(d, r, 1.84631831751005468180e-5);
+    n = fma(n, r, 2.65321895265761230930e-2); d = fma(d, r, 7.86869131145613259100e-4);
+    n = fma(n, r, 2.96560571828504891230e-1); d = fma(d, r, 1.48753612908506148525e-2);
+    n = fma(n, r, 1.78482653991729133580e0); d = fma(d, r, 1.36929880922735805310e-1);
+    n = fma(n, r, 5.46378491116411436990e0); d = fma(d, r, 5.99832206555887937690e-1);
+    n = fma(n, r, 6.65790464350110377720e0); d = fma(d, r, 1.0);
+  }
+  const double v = cm_div_fast(n, d);
+  return q < 0.0 ? -v : v;
+}
 // rare path of the steady-state kernel, kept out of line so that its registers do not burden the common path
-__device__ __noinline__ double cm_quantile_slow(double arg) { return normcdfinv(arg); }
+__device__ __noinline__ double cm_quantile_slow(double arg) { return cm_ndtri(arg); }
 
 // one wavefront; mc is the wave's LDS scratch [2*S]; (mean0, mean1, sd0, sd1) = phi[n], diag(phi_cov[n]); wu[2*S] = the (ndtri(u), u)
 // pairs of this sweep step (k_ndtri_table: the uniforms are data independent, so the 20 threefry rounds and the quantile of
@@ -816,7 +1037,7 @@ __device__ __forceinline__ void mc_logit_body(int n, int lane, double mean0, dou
       const double2 t = (PRE && rnd < 2) ? (rnd == 0 ? pre[comp] : pre[2 + comp]) : wu[j];
       double q;
       if (FULL) {
-        q = normcdfinv(c + t.y * (1.0 - c));           // caviar.py:212
+        q = cm_ndtri(c + t.y * (1.0 - c));             // caviar.py:212
       } else if (tiny) {
         // c is below half an ulp of every u >= 2^-52, the smallest non-zero uniform: arg = c + u (1 - c) is u bit for bit and
         // ndtri(arg) is the tabulated value.  The one exception, u == 0 (arg = c), shows in the table itself: ndtri(0) = -inf.

@@ -232,41 +232,59 @@ __global__ __launch_bounds__(CM_ITER_THREADS, (BATCH && !FULLMC) ? 4 : 1) void k
     // (no loop here: one listed row per wavefront -- a stride loop around this body costs the kernel 100 registers, i.e. two
     // wavefronts per SIMD instead of four; rows beyond the grid, if the list ever outgrows it, are taken by k_iter_overflow)
     const int n_alive = min(p.alive[0], N);
-    const int i = ((int)blockIdx.x - 2) * (int)(blockDim.x / CM_WAVE) + wave;
-    if (i < n_alive) {
-      const int n = p.alive[1 + i];
+    const int i = 2 * (((int)blockIdx.x - 2) * (int)(blockDim.x / CM_WAVE) + wave) + (lane >> 5);   // two listed rows per wavefront, one per half (phi_pair)
+    if (__any(i < n_alive)) {
+      const int n = i < n_alive ? p.alive[1 + i] : -1;
       double pc[4];
-      phi_body<SEG>(n, lane, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, pc, etab, ltab);
+      phi_pair<SEG>(n, lane, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, pc, etab, ltab);
       if (a.do_mc) {
-        const size_t off = ((size_t)a.nx * N + n) * 2 * a.S;      // (the table is stored by neuron)
-        mc_logit_body<FULLMC>(n, lane, pc[0], pc[1], pc[2], pc[3], (const double2*)p.wtab + off, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE, etab, 0.0, 0.0, nullptr, p.mce_ld);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                       // the Monte-Carlo logit of the two rows, one after the other on the whole wavefront
+          const int rown = __builtin_amdgcn_readlane(n, 32 * h);
+          if (rown < 0) continue;
+          const size_t off = ((size_t)a.nx * N + rown) * 2 * a.S;      // (the table is stored by neuron)
+          mc_logit_body<FULLMC>(rown, lane, cm_readlane_f64(pc[0], 32 * h), cm_readlane_f64(pc[1], 32 * h), cm_readlane_f64(pc[2], 32 * h), cm_readlane_f64(pc[3], 32 * h),
+                                (const double2*)p.wtab + off, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE, etab, 0.0, 0.0, nullptr, p.mce_ld);
+        }
       }
     }
     return;
   }
-  const int n = ((int)blockIdx.x - 2) * (int)(blockDim.x / CM_WAVE) + wave;
-  if (n >= N) return;
-  double pc[4];
+  // two rows per wavefront, one per 32-lane half (phi_pair): rows 2 w and 2 w + 1
+  const int nrow = 2 * (((int)blockIdx.x - 2) * (int)(blockDim.x / CM_WAVE) + wave) + (lane >> 5);
+  if (!__any(nrow < N)) return;
+  int n = nrow < N ? nrow : -1;                        // this half's row
+  double pc[4] = {0.0, 0.0, 0.0, 0.0};
   bool dead_row = false;
   double dc0 = 0.0, dc1 = 0.0;
-  if (a.do_phi && p.rs[(size_t)n * 4 + 3] < 0.0) {
-    // the row is identically zero (k_stats of this iteration): its update_phi is the per-run constant of this neuron
-    if (BATCH && a.dead_sep) return;                   // ... and k_mc_dead, launched behind this kernel, takes it (screening, one row per thread)
-    dead_row = true;
-    dead_phi_copy(p, n, lane, pc, &dc0, &dc1);
-  } else if (a.do_phi) {
-    phi_body<SEG>(n, lane, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, pc, etab, ltab);
-  } else {
+  if (a.do_phi) {
+    if (n >= 0 && p.rs[(size_t)n * 4 + 3] < 0.0) {
+      // the row is identically zero (k_stats of this iteration): its update_phi is the per-run constant of this neuron
+      if (BATCH && a.dead_sep) n = -1;                 // ... and k_mc_dead, launched behind this kernel, takes it (screening, one row per thread)
+      else dead_row = true;
+    }
+    if (!__any(n >= 0)) return;
+    double pl[4];
+    phi_pair<SEG>(dead_row ? -1 : n, lane, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, pl, etab, ltab);
+    if (dead_row) dead_phi_copy(p, n, lane & 31, pc, &dc0, &dc1);
+    else { pc[0] = pl[0]; pc[1] = pl[1]; pc[2] = pl[2]; pc[3] = pl[3]; }
+  } else if (n >= 0) {
     pc[0] = p.phi[2 * n]; pc[1] = p.phi[2 * n + 1]; pc[2] = p.phi_cov[4 * n]; pc[3] = p.phi_cov[4 * n + 3];
   }
   if (a.do_mc) {
-    // random tables of iteration nx (the next one)
-    const size_t off = ((size_t)a.nx * N + n) * 2 * a.S;
-    const double2* wu = (const double2*)p.wtab + off;   // (ndtri(u), u) of the neuron's sweep step (the table is stored by neuron)
-    if (!FULLMC && dead_row)
-      mc_logit_body<false, true>(n, lane, pc[0], pc[1], pc[2], pc[3], wu, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE, etab, dc0, dc1, nullptr, p.mce_ld);
-    else
-      mc_logit_body<FULLMC>(n, lane, pc[0], pc[1], pc[2], pc[3], wu, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE, etab, 0.0, 0.0, nullptr, p.mce_ld);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                      // the Monte-Carlo logit of the two rows, one after the other on the whole wavefront
+      const int rown = __builtin_amdgcn_readlane(n, 32 * h);
+      if (rown < 0) continue;
+      // random tables of iteration nx (the next one)
+      const size_t off = ((size_t)a.nx * N + rown) * 2 * a.S;
+      const double2* wu = (const double2*)p.wtab + off;   // (ndtri(u), u) of the neuron's sweep step (the table is stored by neuron)
+      const double m0 = cm_readlane_f64(pc[0], 32 * h), m1 = cm_readlane_f64(pc[1], 32 * h), s0 = cm_readlane_f64(pc[2], 32 * h), s1 = cm_readlane_f64(pc[3], 32 * h);
+      if (!FULLMC && __builtin_amdgcn_readlane((int)dead_row, 32 * h))
+        mc_logit_body<false, true>(rown, lane, m0, m1, s0, s1, wu, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE, etab, cm_readlane_f64(dc0, 32 * h), cm_readlane_f64(dc1, 32 * h), nullptr, p.mce_ld);
+      else
+        mc_logit_body<FULLMC>(rown, lane, m0, m1, s0, s1, wu, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE, etab, 0.0, 0.0, nullptr, p.mce_ld);
+    }
   }
 }
 
@@ -285,13 +303,20 @@ __global__ __launch_bounds__(CM_ITER_THREADS) void k_iter_overflow(cm_parg<true>
   const int N = p.N;
   const int n_alive = min(p.alive[0], N);
   const int total = (int)gridDim.x * (int)(blockDim.x / CM_WAVE);
-  for (int i = first + (int)blockIdx.x * (int)(blockDim.x / CM_WAVE) + wave; i < n_alive; i += total) {
-    const int n = p.alive[1 + i];
+  for (int i0 = first + 2 * ((int)blockIdx.x * (int)(blockDim.x / CM_WAVE) + wave); i0 < n_alive; i0 += 2 * total) {
+    const int i = i0 + (lane >> 5);                    // two listed rows per wavefront, one per half (phi_pair)
+    const int n = i < n_alive ? p.alive[1 + i] : -1;
     double pc[4];
-    phi_body<SEG>(n, lane, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, pc, etab, ltab);
+    phi_pair<SEG>(n, lane, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, pc, etab, ltab);
     if (a.do_mc) {
-      const size_t off = ((size_t)a.nx * N + n) * 2 * a.S;
-      mc_logit_body<false>(n, lane, pc[0], pc[1], pc[2], pc[3], (const double2*)p.wtab + off, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE, etab, 0.0, 0.0, nullptr, p.mce_ld);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int rown = __builtin_amdgcn_readlane(n, 32 * h);
+        if (rown < 0) continue;
+        const size_t off = ((size_t)a.nx * N + rown) * 2 * a.S;
+        mc_logit_body<false>(rown, lane, cm_readlane_f64(pc[0], 32 * h), cm_readlane_f64(pc[1], 32 * h), cm_readlane_f64(pc[2], 32 * h), cm_readlane_f64(pc[3], 32 * h),
+                             (const double2*)p.wtab + off, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE, etab, 0.0, 0.0, nullptr, p.mce_ld);
+      }
     }
   }
 }
@@ -327,7 +352,7 @@ static int launch_iter2(cm_ctx* ctx, cm_set& s, const IterDyn& a0, size_t lds, i
     CM_TRY(cm_raise_lds(ctx, slot_l, reinterpret_cast<const void*>(k_iter_mid<true, SEG, false, true>), lds, 48 * 1024));
     hipLaunchKernelGGL((k_iter_mid<true, SEG, false, true>), dim3(blocks, s.B), dim3(threads), lds, ctx->stream, cm_parg<true>{s.d_arr}, a0);
     {
-      const int waves = threads / CM_WAVE, covered = (blocks - 2) * waves;
+      const int waves = threads / CM_WAVE, covered = (blocks - 2) * waves * 2;
       if (covered < s.lead->N) {                         // (a grid that already covers N rows cannot be outgrown)
         CM_TRY(cm_raise_lds(ctx, CM_LDS_ITER_OVERFLOW + (31 - __builtin_clz((unsigned)SEG)), reinterpret_cast<const void*>(k_iter_overflow<SEG>), (size_t)waves * lds_waves, 48 * 1024));
         hipLaunchKernelGGL((k_iter_overflow<SEG>), dim3(8, s.B), dim3(threads), (size_t)waves * lds_waves, ctx->stream, cm_parg<true>{s.d_arr}, a0, covered);
@@ -390,13 +415,13 @@ int cm_launch_iter_mid(cm_ctx* ctx, cm_set& s, int it, int iters, int S, int rng
   lds = std::max(lds, s.small_lds_max);
   a.stage_ok = 0;
   if ((size_t)p->K * 9 + 16 <= 56 * 1024) { lds = std::max(lds, (size_t)p->K * 9 + 16); a.stage_ok = 1; }   // residual + flag per trial
-  int blocks = 2 + ((do_phi || a.do_mc) ? (N + waves - 1) / waves : 0);
+  int blocks = 2 + ((do_phi || a.do_mc) ? (N + 2 * waves - 1) / (2 * waves) : 0);      // two rows per wavefront
   if (a.skip_dead) {
     // rows with lam != 0 after this sweep: at most a few more than the active set the iteration started with (rows can be revived);
     // twice that, at least 64 wavefronts per circuit -- the kernel's stride loop takes care of the rest
     int want = std::min(N, std::max(64, 2 * s.na_max));
     if (const char* e = getenv("CAVIAR_HIP_TEST_LISTED_ROWS")) want = std::min(N, std::max(1, atoi(e)));   // test hook: a grid the list outgrows (k_iter_overflow)
-    blocks = 2 + (want + waves - 1) / waves;
+    blocks = 2 + (want + 2 * waves - 1) / (2 * waves);
   }
   const int V = p->V;
   static const bool split = getenv("CAVIAR_HIP_SPLIT_ITER") != nullptr;         // diagnostic: one launch per role (profiling only)

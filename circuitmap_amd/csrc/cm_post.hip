@@ -260,14 +260,16 @@ __global__ __launch_bounds__(256) void k_update_phi(cm_parg<BATCH> pa, int use_d
     }
     __syncthreads();
     const int cnt = qn;
-    for (int i = threadIdx.x / CM_WAVE; i < cnt; i += 4)
-      phi_body<SEG>(qlist[i], threadIdx.x % CM_WAVE, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, out,
+    for (int i0 = 2 * (threadIdx.x / CM_WAVE); i0 < cnt; i0 += 8) {          // two rows per wavefront, one per half (phi_pair)
+      const int i = i0 + (int)((threadIdx.x % CM_WAVE) >> 5);
+      phi_pair<SEG>(i < cnt ? qlist[i] : -1, threadIdx.x % CM_WAVE, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, out,
                     etab, ltab, p.phi_dead, p.phi_cov_dead);
+    }
     return;
   }
-  const int n = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE;
-  if (n >= p.N) return;
-  phi_body<SEG>(n, threadIdx.x % CM_WAVE, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, out,
+  const int n = 2 * (int)((blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE) + (int)((threadIdx.x % CM_WAVE) >> 5);
+  if (!__any(n < p.N)) return;
+  phi_pair<SEG>(n < p.N ? n : -1, threadIdx.x % CM_WAVE, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, out,
                 etab, ltab, use_dead ? p.phi_dead : nullptr, use_dead ? p.phi_cov_dead : nullptr);
 }
 
@@ -314,14 +316,14 @@ __global__ __launch_bounds__(256) void k_phi_dead(cm_parg<BATCH> pa) {
   cm_logtab_init(ltab);
   __syncthreads();                                   // (before any wavefront leaves)
   const cm_pdev& p = pa.get();
-  const int n = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE;
-  if (n >= p.N) return;
-  if (p.phi_rep[n] != n) return;                     // (k_phi_copy fills it in from its representative)
+  int n = 2 * (int)((blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE) + (int)((threadIdx.x % CM_WAVE) >> 5);   // two neurons per wavefront, one per half (phi_pair)
+  if (n >= p.N || p.phi_rep[n < p.N ? n : 0] != n) n = -1;     // (not a representative: k_phi_copy fills it in from its representative)
+  if (!__any(n >= 0)) return;
   double out[4];
-  phi_body<SEG, true>(n, threadIdx.x % CM_WAVE, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi_dead,
+  phi_pair<SEG, true>(n, threadIdx.x % CM_WAVE, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi_dead,
                       p.phi_cov_dead, out, etab, ltab);
   // the lower truncation points of the Monte-Carlo draws from this phi (caviar.py:212): constants of the run as well
-  if (threadIdx.x % CM_WAVE == 0) {
+  if (n >= 0 && (threadIdx.x & 31) == 0) {
     p.phi_c_dead[2 * n] = normcdf(-out[0] / out[2]);
     p.phi_c_dead[2 * n + 1] = normcdf(-out[1] / out[3]);
   }
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(256) void k_phi_copy(cm_parg<BATCH> pa) {
 }
 template <int SEG>
 static void launch_phi_dead(cm_set& s, hipStream_t st) {
-  CM_LAUNCH_SET_T(k_phi_dead, (SEG), s, (unsigned)((s.lead->N + 3) / 4), 256, 0, st);
+  CM_LAUNCH_SET_T(k_phi_dead, (SEG), s, (unsigned)((s.lead->N + 7) / 8), 256, 0, st);
 }
 int cm_launch_phi_dead(cm_ctx* ctx, cm_set& s, hipStream_t st) {
   const int V = s.lead->V, N = s.lead->N;
@@ -365,7 +367,7 @@ int cm_launch_phi_dead(cm_ctx* ctx, cm_set& s, hipStream_t st) {
 template <int SEG>
 static void launch_phi(cm_set& s, hipStream_t st, int use_dead, int screen) {
   const int N = s.lead->N;
-  CM_LAUNCH_SET_T(k_update_phi, (SEG), s, (unsigned)(screen ? (N + CM_PHI_QROWS - 1) / CM_PHI_QROWS : (N + 3) / 4), 256, 0, st, use_dead, screen);
+  CM_LAUNCH_SET_T(k_update_phi, (SEG), s, (unsigned)(screen ? (N + CM_PHI_QROWS - 1) / CM_PHI_QROWS : (N + 7) / 8), 256, 0, st, use_dead, screen);
 }
 
 int cm_launch_update_phi(cm_ctx* ctx, cm_set& s, hipStream_t st, int use_dead, int screen) {

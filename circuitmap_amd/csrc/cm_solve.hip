@@ -9,6 +9,7 @@
 // blocked Cholesky on 32x32 tiles; L^-1 comes from recursive doubling of triangular blocks (GEMM-shaped),
 // and mu, diag(Sigma) are column reductions of L^-1.  Everything fp64: the early iterations are
 // ill-conditioned enough (SURVEY 8c / tests) that fp32 would not hold the 1e-4 parity target.
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -639,8 +640,12 @@ __global__ __launch_bounds__(256) void k_chol_bulk(cm_parg<BATCH> pa, int na_arg
 // each tile holds bitwise what one rank-32 update per panel leaves (k_chol_panel, the pair family).
 // ------------------------------------------------------------------------------------------------
 #define CM_GRP 4
+#ifndef CM_WIDE_BUFS
+#define CM_WIDE_BUFS 2                                // LDS stages of the rank-128 pass: 2 = double-buffered (70 KB: two workgroups per CU), 1 = one stage + register prefetch (44 KB: three)
+#endif
 #define CM_GSLOTS 8                                   // tile slots of dynamic LDS (TS x TP doubles each)
 static constexpr size_t CM_GROUP_LDS = (size_t)CM_GSLOTS * TS * TP * sizeof(double);
+static constexpr size_t CM_WIDE_LDS = (size_t)(CM_WIDE_BUFS == 2 ? 8 : 5) * TS * TP * sizeof(double);   // (the diagonal-block factorisation of workgroup 0 needs five slots)
 typedef double (*cm_tile_t)[TP];
 __device__ __forceinline__ cm_tile_t cm_slot(double* sm, int s) { return reinterpret_cast<cm_tile_t>(sm + (size_t)s * TS * TP); }
 // a wavefront's 16 x 16 block (rb, cb) of a 32 x 32 tile <-> 4 registers (the matrix-core accumulator layout)
@@ -814,14 +819,23 @@ __device__ __forceinline__ void chol_wide_supertile(const cm_pdev& p, double* sm
     for (int k = 0; k < 4; ++k) tile_put(cm_slot(sm, 4 * s + k), st[k]);
   };
   fetch(0);
+#if CM_WIDE_BUFS == 2
   put(0);
+#endif
 #pragma unroll
   for (int pp = 0; pp < CM_GRP; ++pp) {
+#if CM_WIDE_BUFS == 2
     if (pp + 1 < CM_GRP) fetch(pp + 1);              // in flight behind this panel's 32 matrix instructions
     __syncthreads();
+#else
+    __syncthreads();                                 // (every wavefront is done with the last stage: one buffer, the next stage waits in registers)
+    put(0);
+    __syncthreads();
+    if (pp + 1 < CM_GRP) fetch(pp + 1);              // in flight behind this panel's 32 matrix instructions
+#endif
     if (valid) {
-      const double (*Ai)[TP] = cm_slot(sm, 4 * (pp & 1) + qi);
-      const double (*Bl)[TP] = cm_slot(sm, 4 * (pp & 1) + 2 + ql);
+      const double (*Ai)[TP] = cm_slot(sm, (CM_WIDE_BUFS == 2 ? 4 * (pp & 1) : 0) + qi);
+      const double (*Bl)[TP] = cm_slot(sm, (CM_WIDE_BUFS == 2 ? 4 * (pp & 1) : 0) + 2 + ql);
       const int r = lane & 15, kk = lane >> 4;
       cm_d4 c00 = {0.0, 0.0, 0.0, 0.0}, c01 = c00, c10 = c00, c11 = c00;
 #pragma unroll
@@ -834,7 +848,9 @@ __device__ __forceinline__ void chol_wide_supertile(const cm_pdev& p, double* sm
       }
       blk_sub(o[0][0], c00); blk_sub(o[0][1], c01); blk_sub(o[1][0], c10); blk_sub(o[1][1], c11);
     }
+#if CM_WIDE_BUFS == 2
     if (pp + 1 < CM_GRP) put((pp + 1) & 1);          // (that buffer was last read before this iteration's barrier)
+#endif
   }
   if (valid) {
 #pragma unroll
@@ -845,7 +861,7 @@ __device__ __forceinline__ void chol_wide_supertile(const cm_pdev& p, double* sm
 }
 
 template <bool BATCH>
-__global__ __launch_bounds__(256, 2) void k_chol_wide(cm_parg<BATCH> pa, int na_arg, int skip_own, int j0, int large_min) {
+__global__ __launch_bounds__(256, CM_WIDE_BUFS == 2 ? 2 : 3) void k_chol_wide(cm_parg<BATCH> pa, int na_arg, int skip_own, int j0, int large_min) {
   int bx = (int)blockIdx.x, circ = 0;
   if (BATCH) cm_xcd_remap(bx, circ, skip_own >> 8);  // all super-tiles of a circuit on one XCD: its panel tiles go through one L2
   CM_SOLVE_PROLOGUE_AT(2, pa.get(circ))
@@ -1038,6 +1054,131 @@ __global__ __launch_bounds__(256) void k_inv_X21(cm_parg<BATCH> pa, int na_arg, 
   for (int reg = 0; reg < 4; ++reg) out[(size_t)BLK_ROW(rb, lane, reg) * ld + BLK_COL(cb, lane)] = -acc[reg];
 }
 
+// The two products of a level on 64 x 64 SUPER-TILES (levels b >= 2: the b x b blocks of tiles split into 2 x 2 groups): a workgroup computes
+// four output tiles, a wavefront one 32 x 32 tile as four 16 x 16 matrix-core blocks -- every operand fragment read from LDS feeds two
+// products (one LDS read per matrix instruction where the one-tile kernels above need two, which put them at the LDS port's limit), the four
+// operand tiles of a step are fetched once for four tile products (8 KB through the CU's fetch path per product instead of 16), and a
+// wavefront issues 32 matrix instructions between two barriers instead of 8.  Every 16 x 16 block still accumulates its products in the
+// same order over the same k range (a tile whose k range starts later -- the triangular operand -- skips the steps before it): bitwise the
+// X of the one-tile kernels.
+template <bool BATCH>
+__global__ __launch_bounds__(256) void k_inv_T2(cm_parg<BATCH> pa, int na_arg, int skip_own, int b) {
+  int bx = (int)blockIdx.x, circ = 0;
+  if (BATCH) cm_xcd_remap(bx, circ, skip_own >> 8);
+  CM_SOLVE_PROLOGUE_AT(2, pa.get(circ))
+  double* __restrict__ A = p.A;
+  const double* __restrict__ Lf = p.Lf;
+  const double* __restrict__ X = p.X;
+  __shared__ __attribute__((aligned(16))) double Lt[2][TS][TP], Xt[2][TS][TPN];
+  const int hb = b >> 1, per = hb * hb;
+  const int q = bx / per, rem = bx % per;
+  const int J2 = (2 * q + 1) * b + 2 * (rem / hb);   // first of the two tile rows (second half of the pair)
+  const int C = 2 * q * b + 2 * (rem % hb);          // first of the two tile columns (first half)
+  if (J2 >= nblk) return;
+  const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE, wr = wave >> 1, wc = wave & 1;
+  const int j2 = J2 + wr, c = C + wc;
+  const bool valid = j2 < nblk;
+  const int J2b = min(J2 + 1, nblk - 1);             // (a missing second tile row re-reads the first: loaded, never used)
+  const int jend = (2 * q + 1) * b;                  // X11[j1][c] is non-zero only for j1 >= c
+  cm_d4 c00 = {0.0, 0.0, 0.0, 0.0}, c01 = c00, c10 = c00, c11 = c00;
+  double ra[2][4], rx[2][4];
+  auto fetch = [&](int j1) {
+    tile_fetch(ra[0], Lf + (size_t)J2 * TS * ld + (size_t)j1 * TS, ld);
+    tile_fetch(ra[1], Lf + (size_t)J2b * TS * ld + (size_t)j1 * TS, ld);
+    tile_fetch(rx[0], X + (size_t)j1 * TS * ld + (size_t)C * TS, ld);
+    tile_fetch(rx[1], X + (size_t)j1 * TS * ld + (size_t)(C + 1) * TS, ld);   // (j1 == C: a strictly-upper tile -- loaded, never used)
+  };
+  fetch(C);
+  const int r = lane & 15, kk = lane >> 4;
+  for (int j1 = C; j1 < jend; ++j1) {
+    __syncthreads();
+    tile_put(Lt[0], ra[0]); tile_put(Lt[1], ra[1]);
+    tile_put<256, TPN>(Xt[0], rx[0]); tile_put<256, TPN>(Xt[1], rx[1]);
+    __syncthreads();
+    if (j1 + 1 < jend) fetch(j1 + 1);
+    if (valid && j1 >= c) {
+      const double (*Aw)[TP] = Lt[wr];
+      const double (*Bw)[TPN] = Xt[wc];
+#pragma unroll
+      for (int ks = 0; ks < TS / 4; ++ks) {
+        const double a0 = Aw[r][4 * ks + kk], a1 = Aw[16 + r][4 * ks + kk], b0 = Bw[4 * ks + kk][r], b1 = Bw[4 * ks + kk][16 + r];
+        c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c00, 0, 0, 0);
+        c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, c01, 0, 0, 0);
+        c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, c10, 0, 0, 0);
+        c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c11, 0, 0, 0);
+      }
+    }
+  }
+  if (!valid) return;
+  double* out = A + (size_t)c * TS * ld + (size_t)j2 * TS;    // scratch: strictly-upper tile (c, j2)
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    out[(size_t)BLK_ROW(0, lane, reg) * ld + BLK_COL(0, lane)] = c00[reg];
+    out[(size_t)BLK_ROW(0, lane, reg) * ld + BLK_COL(1, lane)] = c01[reg];
+    out[(size_t)BLK_ROW(1, lane, reg) * ld + BLK_COL(0, lane)] = c10[reg];
+    out[(size_t)BLK_ROW(1, lane, reg) * ld + BLK_COL(1, lane)] = c11[reg];
+  }
+}
+
+template <bool BATCH>
+__global__ __launch_bounds__(256) void k_inv_X212(cm_parg<BATCH> pa, int na_arg, int skip_own, int b) {
+  int bx = (int)blockIdx.x, circ = 0;
+  if (BATCH) cm_xcd_remap(bx, circ, skip_own >> 8);
+  CM_SOLVE_PROLOGUE_AT(2, pa.get(circ))
+  const double* __restrict__ A = p.A;
+  double* __restrict__ X = p.X;
+  __shared__ __attribute__((aligned(16))) double Xa[2][TS][TP], Tt[2][TS][TPN];
+  const int hb = b >> 1, per = hb * hb;
+  const int q = bx / per, rem = bx % per;
+  const int I = (2 * q + 1) * b + 2 * (rem / hb);
+  const int C = 2 * q * b + 2 * (rem % hb);
+  if (I >= nblk) return;
+  const int wave = threadIdx.x / CM_WAVE, lane = threadIdx.x % CM_WAVE, wr = wave >> 1, wc = wave & 1;
+  const int i = I + wr, c = C + wc;
+  const bool valid = i < nblk;
+  const int Ib = min(I + 1, nblk - 1);
+  const int jbeg = (2 * q + 1) * b;                  // X22[i][j2] is non-zero only for j2 <= i
+  const int jlast = Ib;                              // the longer of the two tile rows' k ranges
+  cm_d4 c00 = {0.0, 0.0, 0.0, 0.0}, c01 = c00, c10 = c00, c11 = c00;
+  double ra[2][4], rx[2][4];
+  auto fetch = [&](int j2) {
+    tile_fetch(ra[0], X + (size_t)I * TS * ld + (size_t)j2 * TS, ld);        // (j2 == I + 1: a strictly-upper tile -- loaded, never used)
+    tile_fetch(ra[1], X + (size_t)Ib * TS * ld + (size_t)j2 * TS, ld);
+    tile_fetch(rx[0], A + (size_t)C * TS * ld + (size_t)j2 * TS, ld);
+    tile_fetch(rx[1], A + (size_t)(C + 1) * TS * ld + (size_t)j2 * TS, ld);
+  };
+  fetch(jbeg);
+  const int r = lane & 15, kk = lane >> 4;
+  for (int j2 = jbeg; j2 <= jlast; ++j2) {
+    __syncthreads();
+    tile_put(Xa[0], ra[0]); tile_put(Xa[1], ra[1]);
+    tile_put<256, TPN>(Tt[0], rx[0]); tile_put<256, TPN>(Tt[1], rx[1]);
+    __syncthreads();
+    if (j2 + 1 <= jlast) fetch(j2 + 1);
+    if (valid && j2 <= i) {
+      const double (*Aw)[TP] = Xa[wr];
+      const double (*Bw)[TPN] = Tt[wc];
+#pragma unroll
+      for (int ks = 0; ks < TS / 4; ++ks) {
+        const double a0 = Aw[r][4 * ks + kk], a1 = Aw[16 + r][4 * ks + kk], b0 = Bw[4 * ks + kk][r], b1 = Bw[4 * ks + kk][16 + r];
+        c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c00, 0, 0, 0);
+        c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, c01, 0, 0, 0);
+        c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, c10, 0, 0, 0);
+        c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c11, 0, 0, 0);
+      }
+    }
+  }
+  if (!valid) return;
+  double* out = X + (size_t)i * TS * ld + (size_t)c * TS;
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    out[(size_t)BLK_ROW(0, lane, reg) * ld + BLK_COL(0, lane)] = -c00[reg];
+    out[(size_t)BLK_ROW(0, lane, reg) * ld + BLK_COL(1, lane)] = -c01[reg];
+    out[(size_t)BLK_ROW(1, lane, reg) * ld + BLK_COL(0, lane)] = -c10[reg];
+    out[(size_t)BLK_ROW(1, lane, reg) * ld + BLK_COL(1, lane)] = -c11[reg];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // mu = X^T (X rhs), beta = colsum(X^2)  (X = L^-1: Sigma = X^T X, caviar.py:170-172) in ONE pass over X.
 //
@@ -1208,17 +1349,17 @@ static int cm_solve_group_launch(cm_ctx* ctx, const cm_solve_sub& g, int nblk, i
       if (g.single) {
         CM_TRY(cm_raise_lds(ctx, CM_LDS_CHOL_DIAG, reinterpret_cast<const void*>(k_chol_diag<false>), CM_GROUP_LDS, 48 * 1024));
         CM_TRY(cm_raise_lds(ctx, CM_LDS_CHOL_GPANEL, reinterpret_cast<const void*>(k_chol_gpanel<false>), CM_GROUP_LDS, 48 * 1024));
-        CM_TRY(cm_raise_lds(ctx, CM_LDS_CHOL_WIDE, reinterpret_cast<const void*>(k_chol_wide<false>), CM_GROUP_LDS, 48 * 1024));
+        CM_TRY(cm_raise_lds(ctx, CM_LDS_CHOL_WIDE, reinterpret_cast<const void*>(k_chol_wide<false>), CM_WIDE_LDS, 48 * 1024));
       } else {
         CM_TRY(cm_raise_lds(ctx, CM_LDS_CHOL_DIAG_B, reinterpret_cast<const void*>(k_chol_diag<true>), CM_GROUP_LDS, 48 * 1024));
         CM_TRY(cm_raise_lds(ctx, CM_LDS_CHOL_GPANEL_B, reinterpret_cast<const void*>(k_chol_gpanel<true>), CM_GROUP_LDS, 48 * 1024));
-        CM_TRY(cm_raise_lds(ctx, CM_LDS_CHOL_WIDE_B, reinterpret_cast<const void*>(k_chol_wide<true>), CM_GROUP_LDS, 48 * 1024));
+        CM_TRY(cm_raise_lds(ctx, CM_LDS_CHOL_WIDE_B, reinterpret_cast<const void*>(k_chol_wide<true>), CM_WIDE_LDS, 48 * 1024));
       }
       CM_LAUNCH_G(k_chol_diag, 1, 256, CM_GROUP_LDS, na1, skip_le, 0, large_min);
       for (int j0 = 0; j0 + CM_GRP < nblk; j0 += CM_GRP) {
         const int t = nblk - j0 - CM_GRP, ns = (t + 1) / 2, nst = ns * (ns + 1) / 2;
         CM_LAUNCH_G(k_chol_gpanel, t, 256, CM_GROUP_LDS, na1, xflags, j0, large_min);
-        CM_LAUNCH_G(k_chol_wide, ns >= 2 ? nst - 2 : 1, 256, CM_GROUP_LDS, na1, xflags, j0, large_min);
+        CM_LAUNCH_G(k_chol_wide, ns >= 2 ? nst - 2 : 1, 256, CM_WIDE_LDS, na1, xflags, j0, large_min);
       }
     } else if (large_g) {                              // panels in pairs: panel solve, thin column, panel solve, rank-64 trailing update
       CM_LAUNCH_G(k_chol_first, 1, 256, 0, na1, skip_le);
@@ -1240,11 +1381,17 @@ static int cm_solve_group_launch(cm_ctx* ctx, const cm_solve_sub& g, int nblk, i
   }
   if (parts & 4) {
     // inverse of the factor (strictly-upper tiles of X are never read: no clearing needed)
+    static const bool inv_super = getenv("CAVIAR_HIP_INV_ONE_TILE") == nullptr;   // (diagnostic / test hook: the one-tile kernels at every level)
     CM_LAUNCH_G(k_inv_seed, nblk, 256, 0, na1, skip_le);
     for (int b = 1; b < nblk; b *= 2) {
       const int npairs = (nblk + 2 * b - 1) / (2 * b);
-      CM_LAUNCH_G(k_inv_T, npairs * b * b, 256, 0, na1, xflags, b);
-      CM_LAUNCH_G(k_inv_X21, npairs * b * b, 256, 0, na1, xflags, b);
+      if (b >= 2 && inv_super) {                       // 64 x 64 super-tiles (bitwise the X of the one-tile kernels)
+        CM_LAUNCH_G(k_inv_T2, npairs * (b / 2) * (b / 2), 256, 0, na1, xflags, b);
+        CM_LAUNCH_G(k_inv_X212, npairs * (b / 2) * (b / 2), 256, 0, na1, xflags, b);
+      } else {
+        CM_LAUNCH_G(k_inv_T, npairs * b * b, 256, 0, na1, xflags, b);
+        CM_LAUNCH_G(k_inv_X21, npairs * b * b, 256, 0, na1, xflags, b);
+      }
     }
   }
   if (parts & 8) {

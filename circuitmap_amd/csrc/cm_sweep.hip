@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64) void k_ndtri_table(const uint32_t* __restrict__
   for (int j = threadIdx.x; j < 2 * S; j += CM_WAVE) {
     const double u = uexp_all ? uexp_all[base + j] : cm_uniform64(k0, k1, j, S);
     if (wtab) {
-      const double q = normcdfinv(u);
+      const double q = cm_ndtri(u);
       wtab[2 * (wbase + j)] = q; wtab[2 * (wbase + j) + 1] = u;   // (ndtri(u), u) pairs
       fin = fin && isfinite(q);
       if (j & 1) { s1 += q; mn1 = fmin(mn1, q); } else { s0 += q; mx0 = fmax(mx0, q); mnu0 = fmin(mnu0, u); }
@@ -960,6 +960,17 @@ int cm_launch_ndtri_table(cm_ctx* ctx, cm_problem* p, int it0, int n_it, int S, 
     hipLaunchKernelGGL(k_invert_orders, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p->orders_all + (size_t)it0 * p->N,
                        p->inv_all + (size_t)it0 * p->N, p->N, total);
   }
+  CM_HIP(hipGetLastError());
+  return CM_OK;
+}
+
+// per-phase test hook: the device's standard normal quantile (cm_ndtri, caviar.py:212) on n arguments
+__global__ __launch_bounds__(256) void k_ndtri_hook(const double* __restrict__ p, double* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = cm_ndtri(p[i]);
+}
+int cm_k_ndtri_impl(cm_ctx* ctx, int n, const double* d_p, double* d_out) {
+  hipLaunchKernelGGL(k_ndtri_hook, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_p, d_out, n);
   CM_HIP(hipGetLastError());
   return CM_OK;
 }

@@ -257,6 +257,8 @@ int cm_k_reconnect(cm_ctx* ctx, int32_t N, int32_t K, const double* stim, double
                    double minimax_spk_prob, double minimum_spike_count);
 /* Threefry streams as the device generates them (for comparison with oracle/threefry.py): order[N], u[N*S*2] of iteration `it` */
 int cm_k_rng_streams(cm_ctx* ctx, uint64_t seed, int32_t it, int32_t N, int32_t S, int32_t* order, double* u);
+/* the standard normal quantile the Monte-Carlo draws use (ndtri of reference caviar.py:212; Wichura AS 241 on the device) on n host values */
+int cm_k_ndtri(cm_ctx* ctx, int32_t n, const double* p, double* out);
 
 /* Measurement aid: cm_timings brackets a kernel with two HIP events recorded on the stream, so each figure contains one
  * dependent-launch boundary besides the kernel itself.  This returns that boundary, measured the same way around a kernel that
