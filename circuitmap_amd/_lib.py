@@ -123,6 +123,7 @@ SYMBOLS = {
     "cm_k_reconnect": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_double]),
     "cm_k_rng_streams": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, _ip, _dp]),
     "cm_k_ndtri": (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp]),
+    "cm_k_mfma_peak": (C.c_int, [C.c_void_p, C.c_int32, _dp]),
     "cm_k_event_pair_overhead": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float)]),
     "cm_k_solve_bench": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "cm_test_lds_request": (C.c_int64, [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64]),

@@ -778,7 +778,7 @@ extern "C" int cm_caviar_run_batch(cm_ctx* ctx, int32_t n, cm_problem* const* pr
 static int seg_class(int V) { int c = 1; while (c < V) c <<= 1; return c; }
 bool cm_same_launch_config(const cm_problem* a, const cm_problem* b) {
   if (a->N != b->N || a->K != b->K || seg_class(a->V) != seg_class(b->V)) return false;
-  return cm_par_class(a->K, a->max_row_len, a->max_col_len, a->nnz) == cm_par_class(b->K, b->max_row_len, b->max_col_len, b->nnz);
+  return cm_par_class(0, a->K, a->max_row_len, a->max_col_len, a->nnz) == cm_par_class(0, b->K, b->max_row_len, b->max_col_len, b->nnz);   // (static limits only)
 }
 
 static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_options* o, cm_timings* tm) {

@@ -309,8 +309,13 @@ __host__ __device__ static inline int cm_solve_kind(int na, int small_cap, bool 
 // buffers + 32-bit tickets (K up to ~5600 trials, rows up to 511 trials) / 512-record buffers + 8-bit tickets (K up to ~10900, rows up to 255);
 // 0 = the single-consumer kernel (anything else: longer rows, more than 255 neurons per trial, K beyond the LDS budget).
 static inline int cm_pack_limit(int cap) { return cap / 2 - 1; }
-static inline int cm_par_class(int K, int max_row_len, int max_col_len, long long nnz) {
+// A DENSE dependency graph leaves the tickets nothing to overlap: two chain rows share on average (trials per row) x (targets per trial - 1) /
+// (N - 1) trials -- 0.18 at N = 1000 / K = 2000 / H = 10 (critical path ~130 of 1000 rows), 8 at the reference's demo shape N = 200 / K = 3600
+// (every row waits for its predecessor: measured 143 us per sweep on the multi-wave kernel against 119 us on the single-consumer kernel).  Above
+// 4 shared trials the single-consumer kernel walks the chain.  (Any choice is correct: the kernels give bitwise the same sweep.)
+static inline int cm_par_class(int N, int K, int max_row_len, int max_col_len, long long nnz) {
   if (max_col_len > 255 || nnz >= (1 << 24)) return 0;
+  if (N > 1 && K > 0 && ((double)nnz / N) * ((double)nnz / K - 1.0) / (double)(N - 1) > 4.0) return 0;
   if ((size_t)K * 12 <= 68 * 1024 && max_row_len <= cm_pack_limit(1024)) return 1;
   if ((size_t)K * 9 + 16 <= 96 * 1024 && max_row_len <= cm_pack_limit(512)) return 2;
   return 0;

@@ -1415,6 +1415,44 @@ __global__ __launch_bounds__(256) void k_bench_fill_spd(double* __restrict__ A, 
   else if (r == c) v = 1.0;
   A[i] = v;
 }
+// Measurement aid: the fp64 matrix-core rate this device sustains with operands in registers and no memory traffic -- four independent
+// accumulation chains of v_mfma_f64_16x16x4_f64 per wavefront, eight wavefronts per SIMD (tools/micro/mfma_peak.hip is the stand-alone form;
+// profiles/r04_mfma_peak.txt).  On the MI355X boxes of this pool: 48.8 TFLOP/s, 62 % of the 78.6 TFLOP/s the guide lists (the vector fp64 FMA
+// pipe reaches 69.6) -- the practical roof of every tile-product kernel above; bench.py reports it beside the nominal peak.
+__global__ __launch_bounds__(256) void k_mfma_peak(double* out, int iters, double a0, double b0) {
+  cm_d4 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc[c] = cm_d4{0.0, 0.0, 0.0, 0.0};
+  const double a = a0 + threadIdx.x * 1e-9, b = b0 + threadIdx.x * 1e-9;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[c], 0, 0, 0);
+  }
+  double sum = 0.0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) sum += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
+  if (sum == 12345.678) out[0] = sum;                // (never true: keeps the chains alive)
+}
+extern "C" int cm_k_mfma_peak(cm_ctx* ctx, int32_t iters, double* tflops) {
+  if (!ctx || !tflops || iters < 1) { cm_set_error("cm_k_mfma_peak: bad argument"); return CM_ERR_INVALID; }
+  CM_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  double* d = nullptr;
+  CM_HIP(hipMalloc(&d, 64));
+  const int blocks = ctx->num_cus * 8;
+  float ms = 0.0f;
+  for (int r = 0; r < 2; ++r) {                      // (first repetition: warm-up)
+    hipEventRecord(ctx->ev[0], st);
+    hipLaunchKernelGGL(k_mfma_peak, dim3(blocks), dim3(256), 0, st, d, iters, 1.0, 1.0);
+    hipEventRecord(ctx->ev[1], st);
+    if (hipStreamSynchronize(st) != hipSuccess) { hipFree(d); cm_set_error("cm_k_mfma_peak: %s", hipGetErrorString(hipGetLastError())); return CM_ERR_HIP; }
+    hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]);
+  }
+  hipFree(d);
+  *tflops = (double)blocks * 4.0 * 4.0 * (double)iters * 2048.0 / ((double)ms * 1e-3) / 1e12;
+  return CM_OK;
+}
+
 extern "C" int cm_k_solve_bench(cm_ctx* ctx, int32_t n, int32_t B, int32_t reps, float* ms_chol, float* ms_inv) {
   if (!ctx || n < 1 || B < 1 || B > CM_MAX_BATCH || reps < 1 || !ms_chol || !ms_inv) { cm_set_error("cm_k_solve_bench: bad argument"); return CM_ERR_INVALID; }
   CM_HIP(hipSetDevice(ctx->device));

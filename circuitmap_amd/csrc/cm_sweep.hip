@@ -664,7 +664,28 @@ __device__ __forceinline__ void sweep_row_packed_long(const SweepArgs& a, SeqRec
     for (int j = 0; j < 8; ++j) { const bool in = g == j + 1; psum[j] += in ? est : 0.0; pcnt[j] += __popcll(__ballot(in)); }
   }
   double pava = 1.0;
-  if (a.gated) {
+  if (a.gated && P <= 8) {
+    // at most eight powers: rates and the isotonic tail in registers (closed form max_j mean(srates[j:]), the P divisions in P lanes at once),
+    // as row_gate_small does for a row of one segment
+    total = cm_wave_sum(total);
+    double num = 0.0, den = 1.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < P) { const double s = cm_wave_sum(psum[j]); if (lane == j) { num = s; den = (double)pcnt[j] + 1e-4 * (double)(pcnt[j] == 0); } }   // caviar.py:183
+    const double sr_l = num / den;
+    double S = 0.0, numj = 0.0, denj = 1.0;
+    int c = 0;
+#pragma unroll
+    for (int j = 7; j >= 0; --j)
+      if (j < P) { S += cm_readlane_f64(sr_l, j); ++c; if (lane == j) { numj = S; denj = (double)c; } }
+    const double m_l = numj / denj;
+    double best = -1.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < P) { const double m = cm_readlane_f64(m_l, j); best = m > best ? m : best; }
+    const double iso = P > 0 ? best : 0.0;
+    pava = (iso >= thresh && total >= a.min_count) ? 1.0 : 0.0;                       // caviar.py:220-221
+  } else if (a.gated) {
     double* srate = scr;
 #pragma unroll
     for (int j = 0; j < 8; ++j)
@@ -1060,8 +1081,9 @@ int cm_launch_sweep(cm_ctx* ctx, cm_set& s, int it, const cm_options* o, hipEven
 // set) keeps the single-consumer kernel for one circuit, as before.
 int cm_sweep_variant(const cm_set& s, int rows_hint) {
   static const bool no_par = getenv("CAVIAR_HIP_NO_PAR_SWEEP") != nullptr;
+  static const bool force_par = getenv("CAVIAR_HIP_FORCE_PAR_SWEEP") != nullptr;   // (test hook: the multi-wave kernel whatever the density of the chain)
   const cm_problem* p = s.lead;
   int par = 0;
-  if (!no_par && rows_hint > CM_PAR_MIN_ROWS) par = cm_par_class(p->K, s.max_row_len_max, s.max_col_len_max, s.nnz_max);
+  if (!no_par && rows_hint > CM_PAR_MIN_ROWS) par = cm_par_class(force_par ? 0 : p->N, p->K, s.max_row_len_max, s.max_col_len_max, s.nnz_max);
   return par;
 }

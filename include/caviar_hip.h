@@ -270,6 +270,9 @@ int cm_k_event_pair_overhead(cm_ctx* ctx, int32_t reps, int32_t blocks, int32_t 
  * factor exactly as a lock-step batch of B circuits with n active rows each launches them (B = 1: the single-circuit launches); average
  * milliseconds over `reps` repetitions after one warm-up (tools/solve_bench.py). */
 int cm_k_solve_bench(cm_ctx* ctx, int32_t n, int32_t B, int32_t reps, float* ms_chol, float* ms_inv);
+/* measurement aid: the fp64 matrix-core rate (TFLOP/s) the device sustains with operands in registers and no memory traffic; `iters` MFMA
+   rounds per wavefront (200000 runs ~0.3 s) */
+int cm_k_mfma_peak(cm_ctx* ctx, int32_t iters, double* tflops);
 
 /* Test hook for the library's dynamic-LDS bookkeeping (no GPU needed): hipFuncAttributeMaxDynamicSharedMemorySize REPLACES the value in
  * force for a (kernel, device), so the library keeps one process-wide table and only ever raises it.  Returns the value the runtime

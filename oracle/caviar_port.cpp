@@ -12,7 +12,7 @@
 // the Gauss-Seidel sweep is sequential as in the reference (caviar.py:229).
 //
 // NOT part of the product: nothing under circuitmap_amd/ includes, links or loads this file (the product has no CPU path at all).
-// Build (by __graft_entry__.build()):  g++ -O3 -march=native -fopenmp -shared -fPIC oracle/caviar_port.cpp -o oracle/libcaviar_port.so
+// Build (by __graft_entry__.build()):  g++ -O3 -march=x86-64-v3 -fopenmp -shared -fPIC oracle/caviar_port.cpp -o oracle/libcaviar_port.so
 #include <math.h>
 #include <stdint.h>
 #include <string.h>

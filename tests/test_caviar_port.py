@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def cp():
     from oracle import caviar_port
     if not os.path.exists(caviar_port.LIB_PATH):        # (the driver runs build() first; a bare checkout builds it here)
-        subprocess.run(["g++", "-O3", "-march=native", "-fopenmp", "-shared", "-fPIC", "-std=c++17", os.path.join(ROOT, "oracle", "caviar_port.cpp"),
+        subprocess.run(["g++", "-O3", "-march=x86-64-v3", "-fopenmp", "-shared", "-fPIC", "-std=c++17", os.path.join(ROOT, "oracle", "caviar_port.cpp"),
                         "-o", caviar_port.LIB_PATH], check=True)
     return caviar_port
 

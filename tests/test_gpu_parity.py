@@ -1016,10 +1016,12 @@ def test_long_rows_par_chain_equals_single_consumer(tmp_path):
     specs = [dict(N=200, K=3600, B=2, seed0=8100, batch=False, opts=opts, sim=dict(connection_prob=0.1)),
              dict(N=200, K=3600, B=8, seed0=8200, batch=True, opts=opts, sim=dict(connection_prob=0.1)),
              dict(N=60, K=1500, B=3, seed0=8300, batch=True, H=8, opts=dict(opts, msrmp=0.2), sim=dict(powers=[30.0 + 5 * i for i in range(9)], connection_prob=0.2))]
-    ours = fit_specs(specs)
+    ours = fit_specs(specs)                             # the library's own choice (dense chains: the single-consumer kernel, cm_par_class)
+    forced = run_child(specs, {"CAVIAR_HIP_FORCE_PAR_SWEEP": "1"}, tmp_path)
     theirs = run_child(specs, {"CAVIAR_HIP_NO_PAR_SWEEP": "1"}, tmp_path)
-    assert sorted(ours) == sorted(theirs)
+    assert sorted(ours) == sorted(theirs) == sorted(forced)
     for k in ours:
+        np.testing.assert_array_equal(forced[k], theirs[k], err_msg=k)
         np.testing.assert_array_equal(ours[k], theirs[k], err_msg=k)
     assert np.count_nonzero(ours["0_0_mu"]) > 0 and np.count_nonzero(ours["2_0_mu"]) > 0        # real fits: connections were found
 
