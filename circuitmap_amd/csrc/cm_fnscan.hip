@@ -12,6 +12,8 @@
 // examined (identical outcome, as in cm_host_reconnect).  Event counts per candidate live in LDS, built from the events' side (a
 // few percent of the trials carry one; each lists its targeted cells through the CSC) with integer atomics -- exact, order-free.
 // Every floating-point sum is taken by one thread in the row's CSR order, as the host takes it: the results are bit-identical.
+#include <stdlib.h>
+
 #include "cm_bodies.h"
 
 #define CM_FN_THREADS 256
@@ -219,20 +221,30 @@ static int fn_scan_shape(const cm_set& s, int* vmax_out, int* kmax_out) {
   *vmax_out = vmax; *kmax_out = kmax;
   return std::max(1, vmax - 1);
 }
-bool cm_fn_scan_fits(const cm_set& s) {
-  // the LDS-resident form only: on the global arrays every round is a chain of dependent loads, and with the dozens of rounds of a large
-  // circuit (N = 5000 / K = 10000: 7.7 ms measured) the host scan (0.7 ms incl. its copies) is the faster path -- the caller takes it
+// Where reconnect_spont_cells runs: 2 = the LDS-resident kernel, 1 = the same kernel on the global arrays, 0 = on the host.
+// On the global arrays every round is a chain of dependent loads: for ONE large circuit (N = 5000 / K = 10000: 7.7 ms measured) the host scan
+// (0.6 ms incl. its copies) is the faster path.  The kernel takes all circuits of a batch side by side, though, where the host scans them one
+// after the other behind a stream synchronisation (35 ms for 64 such circuits: 7 % of the step): from eight circuits on the batch stays on the
+// device.  CAVIAR_HIP_FN_SCAN_GLOBAL=1 (test hook) takes the global-array form wherever its own state fits.
+static int cm_fn_scan_mode(const cm_set& s) {
+  static const bool force_global = getenv("CAVIAR_HIP_FN_SCAN_GLOBAL") != nullptr;
   int vmax, kmax;
   const int P = fn_scan_shape(s, &vmax, &kmax);
-  return vmax - 1 <= CM_FN_MAXP && s.max_row_len_max < 65536 && fn_scan_lds(s.lead->N, kmax, P, std::max(1, s.max_row_len_max), true) <= 150 * 1024;
+  if (vmax - 1 > CM_FN_MAXP || s.max_row_len_max >= 65536) return 0;
+  const int row_cap = std::max(1, s.max_row_len_max);
+  if (!force_global && fn_scan_lds(s.lead->N, kmax, P, row_cap, true) <= 150 * 1024) return 2;
+  if ((force_global || s.B >= 8) && fn_scan_lds(s.lead->N, kmax, P, row_cap, false) <= 150 * 1024) return 1;
+  return 0;
 }
+bool cm_fn_scan_fits(const cm_set& s) { return cm_fn_scan_mode(s) != 0; }
 int cm_launch_fn_scan(cm_ctx* ctx, cm_set& s, double minimax_spk_prob, double minimum_spike_count) {
   const int row_cap = std::max(1, s.max_row_len_max);
   int vmax, kmax;
   const int P = fn_scan_shape(s, &vmax, &kmax);
-  if (!cm_fn_scan_fits(s)) { cm_set_error("cm_launch_fn_scan: the circuit does not fit the scan kernel (N = %d, %d powers)", s.lead->N, vmax - 1); return CM_ERR_INVALID; }
+  const int mode = cm_fn_scan_mode(s);
+  if (mode == 0) { cm_set_error("cm_launch_fn_scan: the circuit does not fit the scan kernel (N = %d, %d powers)", s.lead->N, vmax - 1); return CM_ERR_INVALID; }
   // the LDS-resident form needs 16-bit trial counts per (cell, power) and the whole state in 150 KB
-  const bool cached = s.max_row_len_max < 65536 && fn_scan_lds(s.lead->N, kmax, P, row_cap, true) <= 150 * 1024;
+  const bool cached = mode == 2;
   const size_t lds = fn_scan_lds(s.lead->N, kmax, P, row_cap, cached);
   if (cached) {
     if (s.B == 1) CM_TRY(cm_raise_lds(ctx, CM_LDS_FN_SCAN, reinterpret_cast<const void*>(k_fn_scan<false, true>), lds, 48 * 1024));

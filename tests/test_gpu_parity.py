@@ -298,7 +298,7 @@ def test_ticket_timeout_is_reported_not_hung():
         "except _lib.CaviarHipError as e:\n"
         "    print('ERROR:', e)\n"
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CAVIAR_HIP_TEST_BAD_TICKET="1")
+    env = dict(os.environ, CAVIAR_HIP_TEST_BAD_TICKET="1", CAVIAR_HIP_FORCE_PAR_SWEEP="1")   # (at this small shape the dense chain would take the single-consumer kernel)
     p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
     out = p.stdout.decode()
     assert p.returncode == 0, p.stderr.decode()[-2000:]
@@ -646,13 +646,15 @@ def _device_circuits(cx, N, K, B, seed0, T=900, host_copy_of=()):
 
 
 @pytest.mark.parametrize("N,K,B,iters", [(200, 400, 16, 14), (200, 400, 33, 14), (200, 400, 128, 14), (1000, 2000, 16, 50), (1000, 2000, 256, 50),
-                                         (200, 3600, 16, 14)])
+                                         (200, 3600, 16, 14), (5000, 10000, 8, 3)])
 def test_run_batch_many_per_xcd(ctx, N, K, B, iters):
     """cm_caviar_run_batch with 2 and 16 circuits per XCD (cm_xcd_remap mode 3 with per > 1, which needs gridDim.y % 8 == 0): every
     circuit bit-identical to its own cm_caviar_run; circuit 0 within 1e-6 of the running-residual oracle (the small shape; the
     N = 1000 oracle trajectory is test_caviar_vs_oracle_bench_sizes).  N = 200 / K = 400 starts with a 7-tile-row tiled solve; N = 200 / K = 3600
     is the reference's published workload (examples/demo_compressive_connectivity_mapping.ipynb:172-175: ~180 trials per cell, every chain row is
-    three 64-entry record segments in the multi-wave chain kernel);
+    three 64-entry record segments in the multi-wave chain kernel); N = 5000 / K = 10000 is BASELINE configs[4] as a batch (bench.py --workload cfg5
+    --circuits-per-gpu 16 / 64): 157-tile-row matrices through the grouped Cholesky family against the single fits' pair family, the false-negative
+    scan on the global arrays (eight circuits) against the single fits' host scan;
     (1000, 2000, 256) is bench.py's default step: timed as one lock-step batch, and as the two interleaved half-batches that are the
     library's default scheduling (cm_options.interleave) -- both forms are checked."""
     from circuitmap_amd.optimise.caviar import run_batch
@@ -875,6 +877,22 @@ def test_device_fn_scan_vs_oracle_random(ctx):
         _lib.check(ctx.lib.cm_k_reconnect(ctx.handle, N, K, _lib.dptr(_lib.f64(stim)), _lib.dptr(gl), _lib.dptr(gm), _lib.dptr(gb), _lib.dptr(gz), minimax, mc))
         assert np.array_equal(gm, want[0]) and np.array_equal(gl, want[2]) and np.array_equal(gz, want[3]), trial
         assert np.allclose(gb, want[1], rtol=1e-14, atol=0, equal_nan=True), trial
+
+
+def test_device_fn_scan_on_global_arrays():
+    """Shapes whose scan state does not fit LDS (N = 5000 / K = 10000) run k_fn_scan on the global arrays when they come as a batch of eight
+    circuits or more.  CAVIAR_HIP_FN_SCAN_GLOBAL=1 selects that instantiation for every shape: the random reconnect_spont_cells scenarios of
+    test_device_fn_scan_vs_oracle_random (oracle: caviar.py:102-144, bit for bit) and a fit with reconnections, in ONE child process (the flag is
+    read once per process)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, CAVIAR_HIP_FN_SCAN_GLOBAL="1")
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "test_device_fn_scan_vs_oracle_random or test_caviar_vs_golden"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    out = p.stdout.decode()
+    assert p.returncode == 0 and " passed" in out, out[-3000:]
 
 
 def test_fit_lockstep_accepts_scattered_device_circuits():
