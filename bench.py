@@ -93,12 +93,13 @@ def cpu_baseline(sim, pri, wl, fit=None):
     from oracle import caviar_port as cport
     args = (sim["psc"], sim["stim_matrix"], pri["mu"], pri["beta"], pri["shape"], pri["rate"], pri["phi"], pri["phi_cov"])
     fit = dict(fit or {})
-    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # (threads: the box's CPU share for one GPU is 16 cores whatever os.cpu_count() says -- 256 OpenMP threads on it took 58 s per fit, one thread 0.9 s)
+    ncpu = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     out = {}
     iters = 50 if wl["N"] <= 2000 else 3
     cport.caviar(*args, iters=1, seed=0, n_threads=ncpu, **fit)                 # warm-up (thread pool, page faults)
     reps, t = 0, time.time()
-    while reps < 3 or (time.time() - t < 3.0 and reps < 20):
+    while reps < 3 or (time.time() - t < 3.0 and reps < 10):
         cport.caviar(*args, iters=iters, seed=0, n_threads=ncpu, **fit)
         reps += 1
     dt = (time.time() - t) / reps

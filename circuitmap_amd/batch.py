@@ -60,6 +60,23 @@ def _fit_lockstep(circuits, mine, priors, fit_options, device_id, max_group, str
     from . import _lib
     from .optimise.caviar import Problem, fetch_batch, run_batch
     names = ["mu", "beta", "lam", "shape", "rate", "phi", "phi_cov", "z"]
+    # A group must fit the GPU: a circuit holds three ld x ld float64 solve matrices (ld = N rounded up to 32: 24 MB at N = 1000, 0.6 GB at
+    # N = 5000), the staged dense inputs of its encoding and ~100 bytes per targeted entry; the group is capped at 60 % of the free device
+    # memory (256 circuits of N = 5000 would ask for 155 GB + staging).
+    if mine:
+        c0 = circuits[mine[0]]
+        if len(c0) == 2:
+            n0, k0, t0 = np.asarray(c0[1]).shape[0], np.asarray(c0[1]).shape[1], np.asarray(c0[0]).shape[1]
+        else:
+            n0, k0, t0 = c0[2], c0[3], c0[4]
+        ld = (n0 + 31) // 32 * 32
+        per = 3 * ld * ld * 8 + (n0 * k0 + k0 * t0) * 8 + 64 * n0 * 8 * 3 + 200 * 10 * k0 + (1 << 20)
+        try:
+            import torch
+            free = torch.cuda.mem_get_info(device_id)[0]
+            max_group = max(1, min(max_group, int(0.6 * free / streams) // per))
+        except Exception:
+            pass
     groups = [mine[g0:g0 + max_group] for g0 in range(0, len(mine), max_group)]
     out = {}
 
@@ -85,6 +102,7 @@ def _fit_lockstep(circuits, mine, priors, fit_options, device_id, max_group, str
         ctx = _lib.default_context(device_id)
         for idx in groups:
             fit_group(ctx, idx)
+        ctx.release_cache()          # the shared default context lives as long as the process: its pooled slabs go back to the driver (torch's allocator cannot see them)
     else:
         from concurrent.futures import ThreadPoolExecutor
         import queue

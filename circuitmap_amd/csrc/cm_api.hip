@@ -1157,6 +1157,7 @@ extern "C" int cm_caviar_fetch_batch(cm_ctx* ctx, int32_t n, cm_problem* const* 
     cm_problem* p = problems[c];
     cm_result& r = results[c];
     if (!p) { cm_set_error("cm_caviar_fetch_batch: problem %d is NULL", c); return CM_ERR_INVALID; }
+    if (p->ctx != ctx) { cm_set_error("cm_caviar_fetch_batch: problem %d belongs to another context (its results are ordered on that context's stream)", c); return CM_ERR_INVALID; }
     if (!p->ran) { cm_set_error("cm_caviar_fetch_batch: no completed run on problem %d", c); return CM_ERR_STATE; }
     const bool hist = p->hist_iters > 0 && (r.mu_hist || r.beta_hist || r.lam_hist || r.shape_hist || r.rate_hist || r.phi_hist || r.phi_cov_hist || r.z_hist);
     if (r.lam || hist) continue;                                      // below, one by one

@@ -23,6 +23,7 @@
 
 struct IterDyn {     // what changes from iteration to iteration (common to all circuits of a batch)
   int it, max_iters; double penalty, scale_factor, tol; int do_sigma, seq, do_solve, stage_ok, do_phi, do_mc, S, roles, nx, explicit_rng, skip_dead;
+  int rpw;             // rows per wavefront of the per-neuron role (phi_pair): 2 = a row per 32-lane half (throughput: the early iterations of a batch), 1 = lower half only (latency: one circuit, listed rows)
   int mc_screen, dead_sep; double msrmp, min_count;   // k_mc_dead: the next sweep is gated -> all-zero rows whose gate cannot pass need no Monte-Carlo logit
   long long* dbg;      // diagnostic (CAVIAR_HIP_TRACE_BLOCK0): device clock at the phase boundaries of block 0, 8 words per launch
 };
@@ -232,9 +233,10 @@ __global__ __launch_bounds__(CM_ITER_THREADS, (BATCH && !FULLMC) ? 4 : 1) void k
     // (no loop here: one listed row per wavefront -- a stride loop around this body costs the kernel 100 registers, i.e. two
     // wavefronts per SIMD instead of four; rows beyond the grid, if the list ever outgrows it, are taken by k_iter_overflow)
     const int n_alive = min(p.alive[0], N);
-    const int i = 2 * (((int)blockIdx.x - 2) * (int)(blockDim.x / CM_WAVE) + wave) + (lane >> 5);   // two listed rows per wavefront, one per half (phi_pair)
-    if (__any(i < n_alive)) {
-      const int n = i < n_alive ? p.alive[1 + i] : -1;
+    const int i = a.rpw * (((int)blockIdx.x - 2) * (int)(blockDim.x / CM_WAVE) + wave) + (lane >> 5);   // rpw listed rows per wavefront, one per half (phi_pair)
+    const bool mine = i < n_alive && (lane >> 5) < a.rpw;
+    if (__any(mine)) {
+      const int n = mine ? p.alive[1 + i] : -1;
       double pc[4];
       phi_pair<SEG>(n, lane, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, pc, etab, ltab);
       if (a.do_mc) {
@@ -251,9 +253,10 @@ __global__ __launch_bounds__(CM_ITER_THREADS, (BATCH && !FULLMC) ? 4 : 1) void k
     return;
   }
   // two rows per wavefront, one per 32-lane half (phi_pair): rows 2 w and 2 w + 1
-  const int nrow = 2 * (((int)blockIdx.x - 2) * (int)(blockDim.x / CM_WAVE) + wave) + (lane >> 5);
-  if (!__any(nrow < N)) return;
-  int n = nrow < N ? nrow : -1;                        // this half's row
+  const int nrow = a.rpw * (((int)blockIdx.x - 2) * (int)(blockDim.x / CM_WAVE) + wave) + (lane >> 5);
+  const bool mine = nrow < N && (lane >> 5) < a.rpw;
+  if (!__any(mine)) return;
+  int n = mine ? nrow : -1;                            // this half's row
   double pc[4] = {0.0, 0.0, 0.0, 0.0};
   bool dead_row = false;
   double dc0 = 0.0, dc1 = 0.0;
@@ -303,9 +306,9 @@ __global__ __launch_bounds__(CM_ITER_THREADS) void k_iter_overflow(cm_parg<true>
   const int N = p.N;
   const int n_alive = min(p.alive[0], N);
   const int total = (int)gridDim.x * (int)(blockDim.x / CM_WAVE);
-  for (int i0 = first + 2 * ((int)blockIdx.x * (int)(blockDim.x / CM_WAVE) + wave); i0 < n_alive; i0 += 2 * total) {
-    const int i = i0 + (lane >> 5);                    // two listed rows per wavefront, one per half (phi_pair)
-    const int n = i < n_alive ? p.alive[1 + i] : -1;
+  for (int i0 = first + a.rpw * ((int)blockIdx.x * (int)(blockDim.x / CM_WAVE) + wave); i0 < n_alive; i0 += a.rpw * total) {
+    const int i = i0 + (lane >> 5);                    // rpw listed rows per wavefront, one per half (phi_pair)
+    const int n = (i < n_alive && (lane >> 5) < a.rpw) ? p.alive[1 + i] : -1;
     double pc[4];
     phi_pair<SEG>(n, lane, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, pc, etab, ltab);
     if (a.do_mc) {
@@ -352,7 +355,7 @@ static int launch_iter2(cm_ctx* ctx, cm_set& s, const IterDyn& a0, size_t lds, i
     CM_TRY(cm_raise_lds(ctx, slot_l, reinterpret_cast<const void*>(k_iter_mid<true, SEG, false, true>), lds, 48 * 1024));
     hipLaunchKernelGGL((k_iter_mid<true, SEG, false, true>), dim3(blocks, s.B), dim3(threads), lds, ctx->stream, cm_parg<true>{s.d_arr}, a0);
     {
-      const int waves = threads / CM_WAVE, covered = (blocks - 2) * waves * 2;
+      const int waves = threads / CM_WAVE, covered = (blocks - 2) * waves * a0.rpw;
       if (covered < s.lead->N) {                         // (a grid that already covers N rows cannot be outgrown)
         CM_TRY(cm_raise_lds(ctx, CM_LDS_ITER_OVERFLOW + (31 - __builtin_clz((unsigned)SEG)), reinterpret_cast<const void*>(k_iter_overflow<SEG>), (size_t)waves * lds_waves, 48 * 1024));
         hipLaunchKernelGGL((k_iter_overflow<SEG>), dim3(8, s.B), dim3(threads), (size_t)waves * lds_waves, ctx->stream, cm_parg<true>{s.d_arr}, a0, covered);
@@ -415,13 +418,17 @@ int cm_launch_iter_mid(cm_ctx* ctx, cm_set& s, int it, int iters, int S, int rng
   lds = std::max(lds, s.small_lds_max);
   a.stage_ok = 0;
   if ((size_t)p->K * 9 + 16 <= 56 * 1024) { lds = std::max(lds, (size_t)p->K * 9 + 16); a.stage_ok = 1; }   // residual + flag per trial
-  int blocks = 2 + ((do_phi || a.do_mc) ? (N + 2 * waves - 1) / (2 * waves) : 0);      // two rows per wavefront
+  // rows per wavefront: a batch's early iterations (every row alive: the launch is bound by its instruction stream) put a row in each half; one
+  // circuit and the listed rows of the steady state (a wavefront or two per SIMD: the launch is as long as one wavefront's chain) keep one row
+  // per wavefront -- the second row's Monte-Carlo logit would only lengthen that chain.  The results do not depend on the choice (phi_pair).
+  a.rpw = (s.B > 1 && !a.skip_dead) ? 2 : 1;
+  int blocks = 2 + ((do_phi || a.do_mc) ? (N + a.rpw * waves - 1) / (a.rpw * waves) : 0);
   if (a.skip_dead) {
     // rows with lam != 0 after this sweep: at most a few more than the active set the iteration started with (rows can be revived);
     // twice that, at least 64 wavefronts per circuit -- the kernel's stride loop takes care of the rest
     int want = std::min(N, std::max(64, 2 * s.na_max));
     if (const char* e = getenv("CAVIAR_HIP_TEST_LISTED_ROWS")) want = std::min(N, std::max(1, atoi(e)));   // test hook: a grid the list outgrows (k_iter_overflow)
-    blocks = 2 + (want + 2 * waves - 1) / (2 * waves);
+    blocks = 2 + (want + a.rpw * waves - 1) / (a.rpw * waves);
   }
   const int V = p->V;
   static const bool split = getenv("CAVIAR_HIP_SPLIT_ITER") != nullptr;         // diagnostic: one launch per role (profiling only)
