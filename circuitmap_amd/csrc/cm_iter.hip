@@ -418,10 +418,10 @@ int cm_launch_iter_mid(cm_ctx* ctx, cm_set& s, int it, int iters, int S, int rng
   lds = std::max(lds, s.small_lds_max);
   a.stage_ok = 0;
   if ((size_t)p->K * 9 + 16 <= 56 * 1024) { lds = std::max(lds, (size_t)p->K * 9 + 16); a.stage_ok = 1; }   // residual + flag per trial
-  // rows per wavefront: a batch's early iterations (every row alive: the launch is bound by its instruction stream) put a row in each half; one
-  // circuit and the listed rows of the steady state (a wavefront or two per SIMD: the launch is as long as one wavefront's chain) keep one row
-  // per wavefront -- the second row's Monte-Carlo logit would only lengthen that chain.  The results do not depend on the choice (phi_pair).
-  a.rpw = (s.B > 1 && !a.skip_dead) ? 2 : 1;
+  // rows per wavefront: batches put a row in each half (measured at 256 circuits: early iterations 1.99 -> 1.66 ms per launch, listed rows 8.9
+  // -> 8.2 ms per step); one circuit keeps one row per wavefront -- its launch is as long as one wavefront's chain, which the second row's
+  // Monte-Carlo logit would only lengthen (26.9 against 30.3 us per launch).  The results do not depend on the choice (phi_pair).
+  a.rpw = s.B > 1 ? 2 : 1;
   int blocks = 2 + ((do_phi || a.do_mc) ? (N + a.rpw * waves - 1) / (a.rpw * waves) : 0);
   if (a.skip_dead) {
     // rows with lam != 0 after this sweep: at most a few more than the active set the iteration started with (rows can be revived);
