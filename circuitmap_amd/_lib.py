@@ -35,6 +35,30 @@ class CmOptions(C.Structure):
                 ("verbose", C.c_int32), ("timing", C.c_int32), ("interleave", C.c_int32)]
 
 
+class CmStimTriple(C.Structure):
+    _fields_ = [("trial", C.c_int32), ("neuron", C.c_int32), ("power", C.c_float)]
+
+
+class CmInputs(C.Structure):
+    _fields_ = [("psc_dtype", C.c_int32), ("stim_layout", C.c_int32), ("psc", C.c_void_p), ("stim", C.c_void_p), ("n_triples", C.c_int64)]
+
+
+CM_DTYPE_F64, CM_DTYPE_F32 = 0, 1
+CM_STIM_DENSE_F64, CM_STIM_DENSE_F32, CM_STIM_TRIPLES = 0, 1, 2
+
+
+def compact_inputs(psc, stim, keep):
+    """cm_inputs for one circuit from host arrays: psc as float32, the stimulus matrix as (trial, neuron, power) triples of its non-zero entries.
+    Exact when the values are float32-representable (recorded traces and laser powers are); `keep` receives the buffers the struct points into."""
+    p32 = np.ascontiguousarray(psc, dtype=np.float32)
+    st = np.asarray(stim)
+    nz_n, nz_k = np.nonzero(st)
+    tr = np.empty(len(nz_n), dtype=np.dtype([("trial", np.int32), ("neuron", np.int32), ("power", np.float32)]))
+    tr["trial"], tr["neuron"], tr["power"] = nz_k, nz_n, st[nz_n, nz_k]
+    keep += [p32, tr]
+    return CmInputs(CM_DTYPE_F32, CM_STIM_TRIPLES, p32.ctypes.data, tr.ctypes.data if len(tr) else None, len(tr))
+
+
 class CmResult(C.Structure):
     _fields_ = [("mu", _dp), ("beta", _dp), ("lam", _dp), ("shape", C.c_double), ("rate", C.c_double), ("phi", _dp),
                 ("phi_cov", _dp), ("z", _dp), ("mu_hist", _dp), ("beta_hist", _dp), ("lam_hist", _dp), ("shape_hist", _dp),
@@ -101,6 +125,10 @@ SYMBOLS = {
     "cm_problem_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "cm_problem_create_batch": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_void_p),
                                           C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)]),
+    "cm_problem_create_batch_ex": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(CmInputs),
+                                             C.c_int, C.POINTER(C.c_void_p)]),
+    "cm_caviar_fit_batch_ex": (C.c_int, [C.c_int32, _ip, _ip, _ip, C.POINTER(CmInputs), C.POINTER(CmPriors), C.POINTER(CmOptions),
+                                         _ip, C.c_int32, C.POINTER(CmResult), C.POINTER(CmTimings)]),
     "cm_caviar_fetch_batch": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(CmResult)]),
     "cm_problem_destroy": (C.c_int, [C.c_void_p]),
     "cm_problem_nnz": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),

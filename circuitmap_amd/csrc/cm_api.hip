@@ -324,7 +324,20 @@ static int stage_reserve(cm_ctx* ctx, size_t bytes);
 // group (sizes of the nnz-dependent slabs; completion) instead of twice per circuit, and the memory comes from the context's pool.  Host
 // inputs are staged through pooled device buffers, at most CM_CREATE_CHUNK circuits at a time (30 MB per circuit at the headline shape).
 #define CM_CREATE_CHUNK 64
-static int create_chunk(cm_ctx* ctx, int n, const int32_t* N, const int32_t* K, const int32_t* T, const double* const* psc, const double* const* stim,
+// compact inputs (cm_inputs): expanded on the device into the dense float64 arrays the encoding reads -- the circuit is, bit for bit, the one
+// cm_problem_create would build from those arrays
+__global__ __launch_bounds__(256) void k_in_f32_to_f64(const float* __restrict__ src, double* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (double)src[i];
+}
+__global__ __launch_bounds__(256) void k_in_triples(const cm_stim_triple* __restrict__ t, long long n, int N, int K, double* __restrict__ dense, int* __restrict__ bad) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const cm_stim_triple e = t[i];
+  if (e.trial < 0 || e.trial >= K || e.neuron < 0 || e.neuron >= N) { *bad = 1; return; }
+  dense[(size_t)e.neuron * K + e.trial] = (double)e.power;
+}
+
+static int create_chunk(cm_ctx* ctx, int n, const int32_t* N, const int32_t* K, const int32_t* T, const cm_inputs* in,
                         int mem_kind, cm_problem** out) {
   hipStream_t st = ctx->stream;
   std::vector<cm_problem*> ps(n, nullptr);
@@ -338,6 +351,7 @@ static int create_chunk(cm_ctx* ctx, int n, const int32_t* N, const int32_t* K, 
   };
   std::vector<cm_enc> enc(n);
   int N_max = 0, K_max = 0;
+  int* d_bad = nullptr;                                                // set by k_in_triples: an entry outside the matrix
   for (int c = 0; c < n; ++c) {
     cm_problem* p = ps[c] = new cm_problem();
     p->ctx = ctx; p->N = N[c]; p->K = K[c]; p->T = T[c];
@@ -347,19 +361,47 @@ static int create_chunk(cm_ctx* ctx, int n, const int32_t* N, const int32_t* K, 
     if (cm_pool_alloc(ctx, &p->slabA, sz.off) != CM_OK) return cleanup(CM_ERR_HIP);
     cm_carver cv; cv.base = (char*)p->slabA;
     carve_a(p, cv);
-    const double *d_psc = psc[c], *d_stim = stim[c];
-    if (mem_kind == CM_MEM_HOST) {
-      void *a = nullptr, *b = nullptr;
-      const size_t nb_psc = (size_t)K[c] * T[c] * sizeof(double), nb_stim = (size_t)N[c] * K[c] * sizeof(double);
-      if (cm_pool_alloc(ctx, &a, nb_psc) != CM_OK) return cleanup(CM_ERR_HIP);
-      tmp.push_back(a);
-      if (cm_pool_alloc(ctx, &b, nb_stim) != CM_OK) return cleanup(CM_ERR_HIP);
-      tmp.push_back(b);
-      if (hipMemcpyAsync(a, psc[c], nb_psc, hipMemcpyHostToDevice, st) != hipSuccess || hipMemcpyAsync(b, stim[c], nb_stim, hipMemcpyHostToDevice, st) != hipSuccess) {
-        cm_set_error("upload of psc/stim failed");
-        return cleanup(CM_ERR_HIP);
-      }
-      d_psc = (const double*)a; d_stim = (const double*)b;
+    // the dense float64 arrays the encoding reads: the caller's own (device, float64 dense), or pooled staging filled by an upload and / or
+    // an expansion kernel (float32 -> float64; (trial, neuron, power) triples scattered into a zeroed matrix)
+    const cm_inputs& ic = in[c];
+    const size_t n_psc = (size_t)K[c] * T[c], n_stim = (size_t)N[c] * K[c];
+    auto pooled = [&](size_t bytes) -> void* { void* q = nullptr; if (cm_pool_alloc(ctx, &q, bytes ? bytes : 8) != CM_OK) return nullptr; tmp.push_back(q); return q; };
+    auto raw_on_device = [&](const void* src, size_t bytes) -> const void* {       // the caller's bytes where a kernel can read them
+      if (mem_kind != CM_MEM_HOST) return src;
+      void* q = pooled(bytes);
+      if (!q) return nullptr;
+      if (hipMemcpyAsync(q, src, bytes, hipMemcpyHostToDevice, st) != hipSuccess) { cm_set_error("upload of psc/stim failed"); return nullptr; }
+      return q;
+    };
+    const double *d_psc = nullptr, *d_stim = nullptr;
+    if (ic.psc_dtype == CM_DTYPE_F64) {
+      d_psc = (const double*)raw_on_device(ic.psc, n_psc * sizeof(double));
+      if (!d_psc) return cleanup(CM_ERR_HIP);
+    } else {
+      const float* r = (const float*)raw_on_device(ic.psc, n_psc * sizeof(float));
+      double* a = (double*)pooled(n_psc * sizeof(double));
+      if (!r || !a) return cleanup(CM_ERR_HIP);
+      hipLaunchKernelGGL(k_in_f32_to_f64, dim3((unsigned)std::min<size_t>((n_psc + 255) / 256, 4096)), dim3(256), 0, st, r, a, n_psc);
+      d_psc = a;
+    }
+    if (ic.stim_layout == CM_STIM_DENSE_F64) {
+      d_stim = (const double*)raw_on_device(ic.stim, n_stim * sizeof(double));
+      if (!d_stim) return cleanup(CM_ERR_HIP);
+    } else if (ic.stim_layout == CM_STIM_DENSE_F32) {
+      const float* r = (const float*)raw_on_device(ic.stim, n_stim * sizeof(float));
+      double* b = (double*)pooled(n_stim * sizeof(double));
+      if (!r || !b) return cleanup(CM_ERR_HIP);
+      hipLaunchKernelGGL(k_in_f32_to_f64, dim3((unsigned)std::min<size_t>((n_stim + 255) / 256, 4096)), dim3(256), 0, st, r, b, n_stim);
+      d_stim = b;
+    } else {
+      const cm_stim_triple* r = (const cm_stim_triple*)raw_on_device(ic.stim, (size_t)ic.n_triples * sizeof(cm_stim_triple));
+      double* b = (double*)pooled(n_stim * sizeof(double));
+      if (!r || !b) return cleanup(CM_ERR_HIP);
+      if (!d_bad) { d_bad = (int*)pooled(sizeof(int)); if (!d_bad || hipMemsetAsync(d_bad, 0, sizeof(int), st) != hipSuccess) return cleanup(CM_ERR_HIP); }
+      if (hipMemsetAsync(b, 0, n_stim * sizeof(double), st) != hipSuccess) return cleanup(CM_ERR_HIP);
+      if (ic.n_triples > 0)
+        hipLaunchKernelGGL(k_in_triples, dim3((unsigned)((ic.n_triples + 255) / 256)), dim3(256), 0, st, r, (long long)ic.n_triples, (int)N[c], (int)K[c], b, d_bad);
+      d_stim = b;
     }
     cm_enc& e = enc[c];
     memset(&e, 0, sizeof(e));
@@ -381,10 +423,13 @@ static int create_chunk(cm_ctx* ctx, int n, const int32_t* N, const int32_t* K, 
   memcpy(h_enc, enc.data(), enc_bytes);
   if (hipMemcpyAsync(d_enc, h_enc, enc_bytes, hipMemcpyHostToDevice, st) != hipSuccess) return cleanup(CM_ERR_HIP);
   if ((rc = cm_encode_stage1(ctx, (const cm_enc*)d_enc, n, N_max, K_max, (int*)d_rep)) != CM_OK) return cleanup(rc);
+  int h_bad = 0;
+  if (d_bad && hipMemcpyAsync(&h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return cleanup(CM_ERR_HIP);
   if (hipMemcpyAsync(h_rep, d_rep, rep_bytes, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
     cm_set_error("encoding (stage 1) failed: %s", hipGetErrorString(hipGetLastError()));
     return cleanup(CM_ERR_HIP);
   }
+  if (h_bad) { cm_set_error("stimulus triples: a (trial, neuron) index lies outside the N x K matrix"); return cleanup(CM_ERR_INVALID); }
   long long nnz_max = 0;
   for (int c = 0; c < n; ++c) {                                       // (too many values?, V, longest row, -, nnz)
     cm_problem* p = ps[c];
@@ -415,18 +460,42 @@ static int create_chunk(cm_ctx* ctx, int n, const int32_t* N, const int32_t* K, 
   return cleanup(CM_OK);
 }
 
-extern "C" int cm_problem_create_batch(cm_ctx* ctx, int32_t n, const int32_t* N, const int32_t* K, const int32_t* T, const double* const* psc,
-                                       const double* const* stim, int mem_kind, cm_problem** out) {
-  if (!ctx || !N || !K || !T || !psc || !stim || !out || n < 1) { cm_set_error("cm_problem_create_batch: NULL argument or n < 1"); return CM_ERR_INVALID; }
+extern "C" int cm_problem_create_batch_ex(cm_ctx* ctx, int32_t n, const int32_t* N, const int32_t* K, const int32_t* T, const cm_inputs* in, int mem_kind,
+                                          cm_problem** out) {
+  if (!ctx || !N || !K || !T || !in || !out || n < 1) { cm_set_error("cm_problem_create_batch_ex: NULL argument or n < 1"); return CM_ERR_INVALID; }
   for (int c = 0; c < n; ++c) {
     out[c] = nullptr;
-    if (!psc[c] || !stim[c]) { cm_set_error("cm_problem_create_batch: NULL psc / stim (circuit %d)", c); return CM_ERR_INVALID; }
+    if (!in[c].psc || (!in[c].stim && !(in[c].stim_layout == CM_STIM_TRIPLES && in[c].n_triples == 0))) { cm_set_error("cm_problem_create_batch: NULL psc / stim (circuit %d)", c); return CM_ERR_INVALID; }
     if (N[c] < 2 || K[c] < 1 || T[c] < 1) { cm_set_error("cm_problem_create_batch: need N >= 2, K >= 1, T >= 1 (circuit %d: %d, %d, %d)", c, N[c], K[c], T[c]); return CM_ERR_INVALID; }
+    if ((in[c].psc_dtype != CM_DTYPE_F64 && in[c].psc_dtype != CM_DTYPE_F32) || in[c].stim_layout < CM_STIM_DENSE_F64 || in[c].stim_layout > CM_STIM_TRIPLES ||
+        (in[c].stim_layout == CM_STIM_TRIPLES && in[c].n_triples < 0)) { cm_set_error("cm_problem_create_batch_ex: unknown dtype / layout (circuit %d)", c); return CM_ERR_INVALID; }
   }
   CM_HIP(hipSetDevice(ctx->device));
   for (int c0 = 0; c0 < n; c0 += CM_CREATE_CHUNK) {
     const int m = std::min(CM_CREATE_CHUNK, n - c0);
-    const int rc = create_chunk(ctx, m, N + c0, K + c0, T + c0, psc + c0, stim + c0, mem_kind, out + c0);
+    const int rc = create_chunk(ctx, m, N + c0, K + c0, T + c0, in + c0, mem_kind, out + c0);
+    if (rc != CM_OK) {
+      for (int c = 0; c < c0; ++c) { cm_problem_destroy(out[c]); out[c] = nullptr; }
+      return rc;
+    }
+  }
+  return CM_OK;
+}
+
+extern "C" int cm_problem_create_batch(cm_ctx* ctx, int32_t n, const int32_t* N, const int32_t* K, const int32_t* T, const double* const* psc,
+                                       const double* const* stim, int mem_kind, cm_problem** out) {
+  if (!ctx || !N || !K || !T || !psc || !stim || !out || n < 1) { cm_set_error("cm_problem_create_batch: NULL argument or n < 1"); return CM_ERR_INVALID; }
+  std::vector<cm_inputs> in((size_t)n);
+  for (int c = 0; c < n; ++c) {
+    out[c] = nullptr;
+    if (!psc[c] || !stim[c]) { cm_set_error("cm_problem_create_batch: NULL psc / stim (circuit %d)", c); return CM_ERR_INVALID; }
+    if (N[c] < 2 || K[c] < 1 || T[c] < 1) { cm_set_error("cm_problem_create_batch: need N >= 2, K >= 1, T >= 1 (circuit %d: %d, %d, %d)", c, N[c], K[c], T[c]); return CM_ERR_INVALID; }
+    in[c].psc_dtype = CM_DTYPE_F64; in[c].stim_layout = CM_STIM_DENSE_F64; in[c].psc = psc[c]; in[c].stim = stim[c]; in[c].n_triples = 0;
+  }
+  CM_HIP(hipSetDevice(ctx->device));
+  for (int c0 = 0; c0 < n; c0 += CM_CREATE_CHUNK) {
+    const int m = std::min(CM_CREATE_CHUNK, n - c0);
+    const int rc = create_chunk(ctx, m, N + c0, K + c0, T + c0, in.data() + c0, mem_kind, out + c0);
     if (rc != CM_OK) {
       for (int c = 0; c < c0; ++c) { cm_problem_destroy(out[c]); out[c] = nullptr; }
       return rc;
@@ -1219,10 +1288,23 @@ extern "C" int cm_caviar_fit(cm_ctx* ctx, int32_t N, int32_t K, int32_t T, const
 
 // Batch of circuits over the GPUs of this process: circuit c goes to device_ids[c % n_devices]; every device gets one
 // host thread with its own context, which creates its circuits, runs them as ONE lock-step batch, fetches and destroys them.
+static int fit_batch_impl(int32_t n, const int32_t* N, const int32_t* K, const int32_t* T, const cm_inputs* in, const cm_priors* priors, const cm_options* o,
+                          const int32_t* device_ids, int32_t n_devices, cm_result* results, cm_timings* timings);
 extern "C" int cm_caviar_fit_batch(int32_t n, const int32_t* N, const int32_t* K, const int32_t* T, const double* const* psc,
                                    const double* const* stim, const cm_priors* priors, const cm_options* o, const int32_t* device_ids,
                                    int32_t n_devices, cm_result* results, cm_timings* timings) {
   if (n < 1 || !N || !K || !T || !psc || !stim || !priors || !o || !results) { cm_set_error("cm_caviar_fit_batch: NULL argument or n_circuits < 1"); return CM_ERR_INVALID; }
+  std::vector<cm_inputs> in((size_t)n);
+  for (int c = 0; c < n; ++c) { in[c].psc_dtype = CM_DTYPE_F64; in[c].stim_layout = CM_STIM_DENSE_F64; in[c].psc = psc[c]; in[c].stim = stim[c]; in[c].n_triples = 0; }
+  return fit_batch_impl(n, N, K, T, in.data(), priors, o, device_ids, n_devices, results, timings);
+}
+extern "C" int cm_caviar_fit_batch_ex(int32_t n, const int32_t* N, const int32_t* K, const int32_t* T, const cm_inputs* inputs, const cm_priors* priors,
+                                      const cm_options* o, const int32_t* device_ids, int32_t n_devices, cm_result* results, cm_timings* timings) {
+  if (n < 1 || !N || !K || !T || !inputs || !priors || !o || !results) { cm_set_error("cm_caviar_fit_batch_ex: NULL argument or n_circuits < 1"); return CM_ERR_INVALID; }
+  return fit_batch_impl(n, N, K, T, inputs, priors, o, device_ids, n_devices, results, timings);
+}
+static int fit_batch_impl(int32_t n, const int32_t* N, const int32_t* K, const int32_t* T, const cm_inputs* in, const cm_priors* priors, const cm_options* o,
+                          const int32_t* device_ids, int32_t n_devices, cm_result* results, cm_timings* timings) {
   const int32_t dev0 = 0;
   if (!device_ids || n_devices < 1) { device_ids = &dev0; n_devices = 1; }
   std::vector<int> rcs(n_devices, CM_OK);
@@ -1238,15 +1320,15 @@ extern "C" int cm_caviar_fit_batch(int32_t n, const int32_t* N, const int32_t* K
     std::vector<cm_problem*> ps(mine.size(), nullptr);
     std::vector<cm_priors> prs;
     std::vector<int32_t> n_(mine.size()), k_(mine.size()), t_(mine.size());
-    std::vector<const double*> psc_(mine.size()), stim_(mine.size());
+    std::vector<cm_inputs> in_(mine.size());
     std::vector<cm_result> res_(mine.size());
     for (size_t i = 0; i < mine.size(); ++i) {
       const int c = mine[i];
-      n_[i] = N[c]; k_[i] = K[c]; t_[i] = T[c]; psc_[i] = psc[c]; stim_[i] = stim[c];
+      n_[i] = N[c]; k_[i] = K[c]; t_[i] = T[c]; in_[i] = in[c];
       prs.push_back(priors[c]);
       res_[i] = results[c];
     }
-    if (!mine.empty()) rc = cm_problem_create_batch(ctx, (int)mine.size(), n_.data(), k_.data(), t_.data(), psc_.data(), stim_.data(), CM_MEM_HOST, ps.data());
+    if (!mine.empty()) rc = cm_problem_create_batch_ex(ctx, (int)mine.size(), n_.data(), k_.data(), t_.data(), in_.data(), CM_MEM_HOST, ps.data());
     if (rc) ps.clear();
     std::vector<cm_timings> tms(mine.size());
     if (!rc && !ps.empty()) rc = cm_caviar_run_batch(ctx, (int)ps.size(), ps.data(), prs.data(), o, timings ? tms.data() : nullptr);

@@ -191,6 +191,25 @@ int cm_problem_create(cm_ctx* ctx, int32_t N, int32_t K, int32_t T, const double
  * the arrays of circuit c (all host or all device, mem_kind); out[n] receives the problems (on failure none is left allocated). */
 int cm_problem_create_batch(cm_ctx* ctx, int32_t n, const int32_t* N, const int32_t* K, const int32_t* T, const double* const* psc,
                             const double* const* stim, int mem_kind, cm_problem** out);
+/* Compact inputs.  The reference's callers hold float arrays with K x T recorded samples and an N x K stimulus matrix that is zero in all but
+ * H of N entries per trial (scripts/run_circuitmap_main.py:22-32); as dense float64 that is 30 MB per circuit at N = 1000 / K = 2000 / T = 900, and
+ * moving it over PCIe was 5x the fit of 256 circuits.  cm_problem_create_batch_ex takes, per circuit, psc as float64 or float32 and the stimulus
+ * matrix dense (float64 / float32) or as its non-zero entries; the library expands them on the device to the float64 arrays of
+ * cm_problem_create_batch, so the circuit -- and every result -- is bitwise the one built from those arrays (float32 values enter as their exact
+ * float64 equals; entries of the stimulus matrix that no triple names are 0; a (trial, neuron) pair named twice takes either power: list each once).
+ * A triple outside the N x K matrix fails the call with CM_ERR_INVALID. */
+enum { CM_DTYPE_F64 = 0, CM_DTYPE_F32 = 1 };
+enum { CM_STIM_DENSE_F64 = 0, CM_STIM_DENSE_F32 = 1, CM_STIM_TRIPLES = 2 };
+typedef struct cm_stim_triple { int32_t trial, neuron; float power; } cm_stim_triple;   /* stim_matrix[neuron][trial] = power */
+typedef struct cm_inputs {
+  int32_t psc_dtype;      /* CM_DTYPE_*: element type of psc [K * T], row-major */
+  int32_t stim_layout;    /* CM_STIM_*: stim is [N * K] float64 / float32 row-major, or n_triples cm_stim_triple */
+  const void* psc;
+  const void* stim;
+  int64_t n_triples;
+} cm_inputs;
+int cm_problem_create_batch_ex(cm_ctx* ctx, int32_t n, const int32_t* N, const int32_t* K, const int32_t* T, const cm_inputs* inputs, int mem_kind,
+                               cm_problem** out);
 int cm_problem_destroy(cm_problem* p);
 int cm_problem_nnz(const cm_problem* p, int64_t* nnz, int32_t* n_vals);
 
@@ -224,6 +243,10 @@ int cm_caviar_run_batch(cm_ctx* ctx, int32_t n_circuits, cm_problem* const* prob
 int cm_caviar_fit_batch(int32_t n_circuits, const int32_t* N, const int32_t* K, const int32_t* T, const double* const* psc,
                         const double* const* stim, const cm_priors* priors, const cm_options* options, const int32_t* device_ids,
                         int32_t n_devices, cm_result* results, cm_timings* timings);
+/* cm_caviar_fit_batch on compact inputs (cm_inputs: float32 psc, the stimulus matrix as float32 or as its non-zero entries): 7.4 instead of 30 MB
+ * per circuit over PCIe at the headline shape; results bitwise those of the dense float64 call on the same values. */
+int cm_caviar_fit_batch_ex(int32_t n_circuits, const int32_t* N, const int32_t* K, const int32_t* T, const cm_inputs* inputs, const cm_priors* priors,
+                           const cm_options* options, const int32_t* device_ids, int32_t n_devices, cm_result* results, cm_timings* timings);
 
 /* ---- per-phase entry points (parity tests exercise each kernel in isolation; host buffers in/out) ---- */
 

@@ -733,6 +733,63 @@ def test_create_batch_and_fetch_batch(ctx):
     ctx.release_cache()                                                  # the pool hands everything back
 
 
+def test_compact_inputs_build_the_same_circuits(ctx):
+    """cm_problem_create_batch_ex / cm_caviar_fit_batch_ex: psc as float32, the stimulus matrix as (trial, neuron, power) triples or dense float32
+    (what the reference's callers hold before `.astype(float)`, scripts/run_downsampling_experiments.py:51) -> fits bitwise those of the dense
+    float64 arrays of the same values; a triple outside the matrix is an error code, an all-zero stimulus matrix (no triples) a valid circuit."""
+    from circuitmap_amd import _lib
+    from circuitmap_amd.optimise.caviar import Problem, make_options, run_batch, _priors_struct
+    lib = ctx.lib
+    shapes = [(60, 150), (120, 400), (60, 150)]
+    sims = [_sim_case(N, K, 990 + i)[0] for i, (N, K) in enumerate(shapes)]
+    circuits = [(np.asarray(s_["psc"], dtype=np.float32).astype(np.float64), s_["stim_matrix"]) for s_ in sims]     # float32-representable traces
+    pris = [default_priors(N) for N, _ in shapes]
+    opts = dict(iters=8, seed=2)
+    dense = Problem.create_batch(ctx, circuits)
+    run_batch(dense, pris, **opts)
+    want = [q.fetch() for q in dense]
+    comp = Problem.create_batch(ctx, circuits, compact=True)
+    assert [q.nnz for q in comp] == [q.nnz for q in dense]
+    run_batch(comp, pris, **opts)
+    for q, w in zip(comp, want):
+        _assert_same_fit(q.fetch(), w, "compact inputs")
+    # dense float32 stimulus matrix + float32 psc through the one-call entry point
+    n = len(circuits)
+    keep = []
+    ins = (_lib.CmInputs * n)()
+    for i, (psc, stim) in enumerate(circuits):
+        p32, s32 = np.ascontiguousarray(psc, dtype=np.float32), np.ascontiguousarray(stim, dtype=np.float32)
+        keep += [p32, s32]
+        ins[i] = _lib.CmInputs(_lib.CM_DTYPE_F32, _lib.CM_STIM_DENSE_F32, p32.ctypes.data, s32.ctypes.data, 0)
+    o = make_options(lib, **opts)
+    prs = (_lib.CmPriors * n)(*[_priors_struct(N, *prior_args(pri), keep) for (N, _), pri in zip(shapes, pris)])
+    res, outs = (_lib.CmResult * n)(), []
+    for c, (N, K) in enumerate(shapes):
+        ob = dict(mu=np.empty(N), beta=np.empty(N), lam=np.empty((N, K)), phi=np.empty((N, 2)), phi_cov=np.empty((N, 2, 2)), z=np.empty(K))
+        for k, v in ob.items():
+            setattr(res[c], k, _lib.dptr(v))
+        outs.append(ob)
+    i32 = lambda v: (C.c_int32 * n)(*v)
+    _lib.check(lib.cm_caviar_fit_batch_ex(n, i32([s_[0] for s_ in shapes]), i32([s_[1] for s_ in shapes]), i32([900] * n), ins, prs, C.byref(o), None, 0, res, None))
+    for c in range(n):
+        for i, nm in enumerate(["mu", "beta", "lam"]):
+            np.testing.assert_array_equal(outs[c][nm], want[c][i], err_msg=nm)
+        assert res[c].shape == want[c][3] and res[c].rate == want[c][4]
+    # a triple outside the matrix
+    bad = np.array([(0, 0, 50.0), (150, 3, 50.0)], dtype=np.dtype([("trial", np.int32), ("neuron", np.int32), ("power", np.float32)]))
+    p32 = np.ascontiguousarray(circuits[0][0], dtype=np.float32)
+    one = (_lib.CmInputs * 1)(_lib.CmInputs(_lib.CM_DTYPE_F32, _lib.CM_STIM_TRIPLES, p32.ctypes.data, bad.ctypes.data, 2))
+    h = (C.c_void_p * 1)()
+    assert lib.cm_problem_create_batch_ex(ctx.handle, 1, (C.c_int32 * 1)(60), (C.c_int32 * 1)(150), (C.c_int32 * 1)(900), one, _lib.CM_MEM_HOST, h) == -1
+    assert b"outside" in lib.cm_last_error()
+    # no triples at all: a circuit nobody targets (lam stays 0, mu stays the prior)
+    one = (_lib.CmInputs * 1)(_lib.CmInputs(_lib.CM_DTYPE_F32, _lib.CM_STIM_TRIPLES, p32.ctypes.data, None, 0))
+    _lib.check(lib.cm_problem_create_batch_ex(ctx.handle, 1, (C.c_int32 * 1)(60), (C.c_int32 * 1)(150), (C.c_int32 * 1)(900), one, _lib.CM_MEM_HOST, h))
+    lib.cm_problem_destroy(C.c_void_p(h[0]))
+    for q in dense + comp:
+        q.close()
+
+
 def test_listed_column_sums_never_matter(ctx, monkeypatch):
     """The column sums R = lam^T mu / colany over the LISTED trials (k_stats lists the trials of the rows with lam != 0, the pre-sweep adds those of
     revived rows, everything else is zeroed) give bitwise the results of the walk over all columns: forced on for a small shape
