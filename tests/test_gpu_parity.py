@@ -501,6 +501,14 @@ def test_run_batch_explicit_streams_and_argument_checks(ctx):
     assert b"twice" in ctx.lib.cm_last_error()
     bad = (_lib.CmPriors * 1)(_lib.CmPriors())
     assert ctx.lib.cm_caviar_run_batch(ctx.handle, 1, (C.c_void_p * 1)(probs[0].handle), bad, C.byref(o), None) == -1   # NULL prior arrays
+    # cm_caviar_fetch_batch refuses a problem of another context (its results are ordered on that context's stream: ADVICE r3)
+    foreign.run(*prior_args(pri), **opts)
+    rs = (_lib.CmResult * 2)()
+    bufs = [np.empty(60), np.empty(60)]
+    for r_, b_ in zip(rs, bufs):
+        r_.mu = _lib.dptr(b_)
+    assert ctx.lib.cm_caviar_fetch_batch(ctx.handle, 2, (C.c_void_p * 2)(probs[0].handle, foreign.handle), rs) == -1
+    assert b"another context" in ctx.lib.cm_last_error()
     foreign.close(); other.close()
     for q in probs:
         q.close()
