@@ -43,6 +43,98 @@ __device__ __forceinline__ void dead_phi_copy(const cm_pdev& p, int n, int lane,
   }
 }
 
+// The exact Monte-Carlo logit (caviar.py:209-215) of TWO rows, one per 32-lane half (`need`, n, the row's phi = (mean0, mean1), variance diagonal
+// (sd0, sd1: used as standard deviations, quirk 2) and truncation points c = ndtr(-mean / sdev) are per half): the per-row overhead (constants,
+// address arithmetic, the reductions' instruction streams, the division) is issued once for two rows.  Every row's sums are bitwise those of
+// mc_logit_body (one row per wavefront): there lane l accumulates the samples l, l + 64 and cm_wave_sum reduces the 64 lanes as four 16-lane
+// rows, (r0 + r1) + (r2 + r3); here physical lane j of a half carries the two virtual lanes j (samples j, j + 64) and j + 32 (samples j + 32,
+// j + 96) in separate accumulators, the 16-lane reductions run on both sets, and the four row sums are combined in the same order.  A lane's
+// samples never leave its registers: no LDS.  At most four powers (gi / vk: their value codes and values) and 128 samples: the callers take the
+// general body otherwise.
+__device__ __forceinline__ void mc_logit_pair(const cm_pdev& p, bool need, int n, double mean0, double mean1, double sd0, double sd1, double c0, double c1,
+                                              int nx, int S, int P, const int (&gi)[4], const double (&vk)[4], const double* etab, int lane) {
+  const int j = lane & 31;
+  const int N = p.N;
+  {
+    const double2* __restrict__ wu = (const double2*)p.wtab + ((size_t)nx * N + (need ? n : 0)) * 2 * S;
+    double2 t[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int s_ = j + 32 * (q >> 1) + 64 * (q & 1);               // slots: j, j + 64 (virtual lane j), j + 32, j + 96 (virtual lane j + 32)
+#pragma unroll
+      for (int comp = 0; comp < 2; ++comp) t[q][comp] = (need && s_ < S) ? wu[2 * s_ + comp] : make_double2(0.0, 0.0);
+    }
+    const bool tiny0 = c0 < 0x1p-106, tiny1 = c1 < 0x1p-106;
+    double acc[4][2] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int s_ = j + 32 * (q >> 1) + 64 * (q & 1);
+      if (need && s_ < S) {
+        // the draw of mc_logit_body<false> (caviar.py:212): the tabulated quantile whenever arg = c + u (1 - c) is u bit for bit
+        double qq[2];
+#pragma unroll
+        for (int comp = 0; comp < 2; ++comp) {
+          const double c = comp ? c1 : c0;
+          const bool tiny = comp ? tiny1 : tiny0;
+          const double2 tt = t[q][comp];
+          if (tiny) qq[comp] = (tt.x == -INFINITY && c != 0.0) ? cm_quantile_slow(c) : tt.x;
+          else { const double arg = c + tt.y * (1.0 - c); qq[comp] = (arg == tt.y) ? tt.x : cm_quantile_slow(arg); }
+        }
+        const double m0 = qq[0] * sd0 + mean0, m1 = qq[1] * sd1 + mean1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k < P) acc[k][q >> 1] += cm_logit_of_sigmoid(m0 * vk[k] - m1, etab);
+      }
+    }
+    double tot = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k < P) {
+        double r01 = cm_seg_sum<16>(acc[k][0]), r23 = cm_seg_sum<16>(acc[k][1]);   // r0 | r1 and r2 | r3 in the two 16-lane rows of the half
+        r01 += __shfl_xor(r01, 16, CM_WAVE);                                          // r0 + r1 (the other row: r1 + r0, the same bits)
+        r23 += __shfl_xor(r23, 16, CM_WAVE);
+        const double sum = r01 + r23;
+        if (j == k) tot = sum;
+      }
+    }
+    const double mean = tot / (double)S;                 // lane k of the half: the mean of power k -- one division serves all of them
+    if (need && j < P) p.mcE[(size_t)n * p.mce_ld + (j == 0 ? gi[0] : (j == 1 ? gi[1] : (j == 2 ? gi[2] : gi[3])))] = mean;
+  }
+}
+
+// the next Monte-Carlo logit of the rows of a wavefront's two halves (n < 0: none; pc = phi_0, phi_1, cov_00, cov_11 of the half's row; dead: the
+// row is all zero and (dc0, dc1) are its tabulated truncation points): both rows at once (mc_logit_pair) where its shape limits hold and two rows
+// are there, one after the other on the whole wavefront otherwise.  Either way every row's sums are those of mc_logit_body.
+template <bool FULLMC>
+__device__ __forceinline__ void mc_logit_rows(const cm_pdev& p, const IterDyn& a, int n, const double (&pc)[4], bool dead, double dc0, double dc1, int lane, int wave,
+                                              double* sm, const double* etab) {
+  const int N = p.N;
+  int gi[4] = {0, 0, 0, 0}, P = 0;
+  for (int g = 0; g < p.V; ++g)
+    if (p.vals[g] > 0.0) { if (P < 4) gi[P] = g; ++P; }
+  if (!FULLMC && a.rpw == 2 && P >= 1 && P <= 4 && a.S <= 2 * CM_WAVE) {
+    double vk[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) vk[k] = p.vals[gi[k]];
+    const bool need = n >= 0;
+    const double c0 = dead ? dc0 : normcdf(-pc[0] / pc[2]), c1 = dead ? dc1 : normcdf(-pc[1] / pc[3]);   // (mc_logit_body evaluates the same expressions)
+    mc_logit_pair(p, need, n, pc[0], pc[1], pc[2], pc[3], c0, c1, a.nx, a.S, P, gi, vk, etab, lane);
+    return;
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {                        // one row after the other on the whole wavefront
+    const int rown = __builtin_amdgcn_readlane(n, 32 * h);
+    if (rown < 0) continue;
+    const size_t off = ((size_t)a.nx * N + rown) * 2 * a.S;      // random tables of iteration nx (the next one), stored by neuron
+    const double2* wu = (const double2*)p.wtab + off;
+    const double m0 = cm_readlane_f64(pc[0], 32 * h), m1 = cm_readlane_f64(pc[1], 32 * h), s0 = cm_readlane_f64(pc[2], 32 * h), s1 = cm_readlane_f64(pc[3], 32 * h);
+    if (!FULLMC && __builtin_amdgcn_readlane((int)dead, 32 * h))
+      mc_logit_body<false, true>(rown, lane, m0, m1, s0, s1, wu, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE, etab, cm_readlane_f64(dc0, 32 * h), cm_readlane_f64(dc1, 32 * h), nullptr, p.mce_ld);
+    else
+      mc_logit_body<FULLMC>(rown, lane, m0, m1, s0, s1, wu, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE, etab, 0.0, 0.0, nullptr, p.mce_ld);
+  }
+}
+
 // Batches: the all-zero rows of every circuit (95 % of the rows in the steady state) in a kernel of their own -- copy of the
 // constants + the next Monte-Carlo logit, nothing else, so that no workgroup waits for a Newton iteration.  Rows with lam != 0 are not
 // touched (k_iter_mid takes them).
@@ -146,49 +238,7 @@ __global__ __launch_bounds__(256) void k_mc_dead(cm_parg<BATCH> pa, IterDyn a, i
       }
       continue;
     }
-    const double2* __restrict__ wu = (const double2*)p.wtab + ((size_t)a.nx * N + n) * 2 * S;
-    double2 t[4][2];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int s_ = j + 32 * (q >> 1) + 64 * (q & 1);               // slots: j, j + 64 (virtual lane j), j + 32, j + 96 (virtual lane j + 32)
-#pragma unroll
-      for (int comp = 0; comp < 2; ++comp) t[q][comp] = (need && s_ < S) ? wu[2 * s_ + comp] : make_double2(0.0, 0.0);
-    }
-    const bool tiny0 = c0 < 0x1p-106, tiny1 = c1 < 0x1p-106;
-    double acc[4][2] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int s_ = j + 32 * (q >> 1) + 64 * (q & 1);
-      if (need && s_ < S) {
-        // the draw of mc_logit_body<false> (caviar.py:212): the tabulated quantile whenever arg = c + u (1 - c) is u bit for bit
-        double qq[2];
-#pragma unroll
-        for (int comp = 0; comp < 2; ++comp) {
-          const double c = comp ? c1 : c0;
-          const bool tiny = comp ? tiny1 : tiny0;
-          const double2 tt = t[q][comp];
-          if (tiny) qq[comp] = (tt.x == -INFINITY && c != 0.0) ? cm_quantile_slow(c) : tt.x;
-          else { const double arg = c + tt.y * (1.0 - c); qq[comp] = (arg == tt.y) ? tt.x : cm_quantile_slow(arg); }
-        }
-        const double m0 = qq[0] * sd0 + mean0, m1 = qq[1] * sd1 + mean1;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (k < P) acc[k][q >> 1] += cm_logit_of_sigmoid(m0 * vk[k] - m1, etab);
-      }
-    }
-    double tot = 0.0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (k < P) {
-        double r01 = cm_seg_sum<16>(acc[k][0]), r23 = cm_seg_sum<16>(acc[k][1]);   // r0 | r1 and r2 | r3 in the two 16-lane rows of the half
-        r01 += __shfl_xor(r01, 16, CM_WAVE);                                          // r0 + r1 (the other row: r1 + r0, the same bits)
-        r23 += __shfl_xor(r23, 16, CM_WAVE);
-        const double sum = r01 + r23;
-        if (j == k) tot = sum;
-      }
-    }
-    const double mean = tot / (double)S;                 // lane k of the half: the mean of power k -- one division serves all of them
-    if (need && j < P) p.mcE[(size_t)n * p.mce_ld + (j == 0 ? gi[0] : (j == 1 ? gi[1] : (j == 2 ? gi[2] : gi[3])))] = mean;
+    mc_logit_pair(p, need, n, mean0, mean1, sd0, sd1, c0, c1, a.nx, S, P, gi, vk, etab, lane);
   }
 }
 
@@ -239,16 +289,7 @@ __global__ __launch_bounds__(CM_ITER_THREADS, (BATCH && !FULLMC) ? 4 : 1) void k
       const int n = mine ? p.alive[1 + i] : -1;
       double pc[4];
       phi_pair<SEG>(n, lane, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, pc, etab, ltab);
-      if (a.do_mc) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {                       // the Monte-Carlo logit of the two rows, one after the other on the whole wavefront
-          const int rown = __builtin_amdgcn_readlane(n, 32 * h);
-          if (rown < 0) continue;
-          const size_t off = ((size_t)a.nx * N + rown) * 2 * a.S;      // (the table is stored by neuron)
-          mc_logit_body<FULLMC>(rown, lane, cm_readlane_f64(pc[0], 32 * h), cm_readlane_f64(pc[1], 32 * h), cm_readlane_f64(pc[2], 32 * h), cm_readlane_f64(pc[3], 32 * h),
-                                (const double2*)p.wtab + off, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE, etab, 0.0, 0.0, nullptr, p.mce_ld);
-        }
-      }
+      if (a.do_mc) mc_logit_rows<FULLMC>(p, a, n, pc, false, 0.0, 0.0, lane, wave, sm, etab);
     }
     return;
   }
@@ -274,21 +315,7 @@ __global__ __launch_bounds__(CM_ITER_THREADS, (BATCH && !FULLMC) ? 4 : 1) void k
   } else if (n >= 0) {
     pc[0] = p.phi[2 * n]; pc[1] = p.phi[2 * n + 1]; pc[2] = p.phi_cov[4 * n]; pc[3] = p.phi_cov[4 * n + 3];
   }
-  if (a.do_mc) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {                      // the Monte-Carlo logit of the two rows, one after the other on the whole wavefront
-      const int rown = __builtin_amdgcn_readlane(n, 32 * h);
-      if (rown < 0) continue;
-      // random tables of iteration nx (the next one)
-      const size_t off = ((size_t)a.nx * N + rown) * 2 * a.S;
-      const double2* wu = (const double2*)p.wtab + off;   // (ndtri(u), u) of the neuron's sweep step (the table is stored by neuron)
-      const double m0 = cm_readlane_f64(pc[0], 32 * h), m1 = cm_readlane_f64(pc[1], 32 * h), s0 = cm_readlane_f64(pc[2], 32 * h), s1 = cm_readlane_f64(pc[3], 32 * h);
-      if (!FULLMC && __builtin_amdgcn_readlane((int)dead_row, 32 * h))
-        mc_logit_body<false, true>(rown, lane, m0, m1, s0, s1, wu, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE, etab, cm_readlane_f64(dc0, 32 * h), cm_readlane_f64(dc1, 32 * h), nullptr, p.mce_ld);
-      else
-        mc_logit_body<FULLMC>(rown, lane, m0, m1, s0, s1, wu, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE, etab, 0.0, 0.0, nullptr, p.mce_ld);
-    }
-  }
+  if (a.do_mc) mc_logit_rows<FULLMC>(p, a, n, pc, dead_row, dc0, dc1, lane, wave, sm, etab);
 }
 
 // Listed rows beyond the grid of the LISTED k_iter_mid (`first` = the rows that launch covers): a stride loop over whatever is left.
@@ -311,16 +338,7 @@ __global__ __launch_bounds__(CM_ITER_THREADS) void k_iter_overflow(cm_parg<true>
     const int n = (i < n_alive && (lane >> 5) < a.rpw) ? p.alive[1 + i] : -1;
     double pc[4];
     phi_pair<SEG>(n, lane, p.lam, p.row_ptr, p.grp, p.rowcnt, p.vals, p.V, p.phi_prior, p.phi_cov_prior, p.phi, p.phi_cov, pc, etab, ltab);
-    if (a.do_mc) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int rown = __builtin_amdgcn_readlane(n, 32 * h);
-        if (rown < 0) continue;
-        const size_t off = ((size_t)a.nx * N + rown) * 2 * a.S;
-        mc_logit_body<false>(rown, lane, cm_readlane_f64(pc[0], 32 * h), cm_readlane_f64(pc[1], 32 * h), cm_readlane_f64(pc[2], 32 * h), cm_readlane_f64(pc[3], 32 * h),
-                             (const double2*)p.wtab + off, p.vals, p.V, a.S, sm + (size_t)wave * 2 * a.S, p.mcE, etab, 0.0, 0.0, nullptr, p.mce_ld);
-      }
-    }
+    if (a.do_mc) mc_logit_rows<false>(p, a, n, pc, false, 0.0, 0.0, lane, wave, sm, etab);
   }
 }
 
