@@ -394,9 +394,9 @@ static int create_chunk(cm_ctx* ctx, int n, const int32_t* N, const int32_t* K, 
       hipLaunchKernelGGL(k_in_f32_to_f64, dim3((unsigned)std::min<size_t>((n_stim + 255) / 256, 4096)), dim3(256), 0, st, r, b, n_stim);
       d_stim = b;
     } else {
-      const cm_stim_triple* r = (const cm_stim_triple*)raw_on_device(ic.stim, (size_t)ic.n_triples * sizeof(cm_stim_triple));
+      const cm_stim_triple* r = ic.n_triples > 0 ? (const cm_stim_triple*)raw_on_device(ic.stim, (size_t)ic.n_triples * sizeof(cm_stim_triple)) : nullptr;
       double* b = (double*)pooled(n_stim * sizeof(double));
-      if (!r || !b) return cleanup(CM_ERR_HIP);
+      if ((ic.n_triples > 0 && !r) || !b) return cleanup(CM_ERR_HIP);
       if (!d_bad) { d_bad = (int*)pooled(sizeof(int)); if (!d_bad || hipMemsetAsync(d_bad, 0, sizeof(int), st) != hipSuccess) return cleanup(CM_ERR_HIP); }
       if (hipMemsetAsync(b, 0, n_stim * sizeof(double), st) != hipSuccess) return cleanup(CM_ERR_HIP);
       if (ic.n_triples > 0)
