@@ -129,6 +129,7 @@ SYMBOLS = {
                                              C.c_int, C.POINTER(C.c_void_p)]),
     "cm_caviar_fit_batch_ex": (C.c_int, [C.c_int32, _ip, _ip, _ip, C.POINTER(CmInputs), C.POINTER(CmPriors), C.POINTER(CmOptions),
                                          _ip, C.c_int32, C.POINTER(CmResult), C.POINTER(CmTimings)]),
+    "cm_caviar_fit_batch_release": (C.c_int, []),
     "cm_caviar_fetch_batch": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(CmResult)]),
     "cm_problem_destroy": (C.c_int, [C.c_void_p]),
     "cm_problem_nnz": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),

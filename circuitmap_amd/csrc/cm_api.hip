@@ -460,6 +460,71 @@ static int create_chunk(cm_ctx* ctx, int n, const int32_t* N, const int32_t* K, 
   return cleanup(CM_OK);
 }
 
+// ---- host inputs: pageable memory staged through pinned slots by a few copy threads ----
+// hipMemcpyAsync from pageable memory pins the caller's pages on first touch: 13.6 GB/s for the 1.9 GB of a 256-circuit batch (tools/micro/h2d.hip).
+// CM_UPLOAD_THREADS threads copying 4 MB pieces into pinned slots (two per thread, one being filled while the other is on the DMA engine) reach
+// 45-55 GB/s, the rate of a pinned source, whatever the caller's allocation is.  Slots, streams and events are made once per device and process.
+#define CM_UPLOAD_THREADS 4
+#define CM_UPLOAD_SLOT ((size_t)4 << 20)
+struct cm_upload_res {
+  hipStream_t st[CM_UPLOAD_THREADS] = {};
+  char* slot[CM_UPLOAD_THREADS][2] = {};
+  hipEvent_t ev[CM_UPLOAD_THREADS][2] = {};
+  bool used[CM_UPLOAD_THREADS][2] = {};
+  std::mutex use;                                                      // one problem_create_batch at a time per device
+};
+static cm_upload_res* upload_res(int device) {
+  static std::mutex m;
+  static std::map<int, cm_upload_res*> all;                            // never freed: a few pinned MB per device for the life of the process
+  std::lock_guard<std::mutex> lk(m);
+  auto it = all.find(device);
+  if (it != all.end()) return it->second;
+  cm_upload_res* r = new cm_upload_res();
+  bool ok = true;
+  for (int t = 0; ok && t < CM_UPLOAD_THREADS; ++t) {
+    ok = hipStreamCreateWithFlags(&r->st[t], hipStreamNonBlocking) == hipSuccess;
+    for (int s = 0; ok && s < 2; ++s)
+      ok = hipHostMalloc((void**)&r->slot[t][s], CM_UPLOAD_SLOT, hipHostMallocDefault) == hipSuccess &&
+           hipEventCreateWithFlags(&r->ev[t][s], hipEventDisableTiming) == hipSuccess;
+  }
+  if (!ok) { cm_set_error("pinned staging for host inputs: %s", hipGetErrorString(hipGetLastError())); return nullptr; }   // (partial allocations are left to the process)
+  return all[device] = r;
+}
+struct cm_upload_piece { char* dst; const char* src; size_t bytes; };
+struct cm_upload_run {
+  std::vector<cm_upload_piece> pieces;
+  std::atomic<size_t> next{0};
+  std::atomic<int> err{0};
+  std::vector<std::thread> th;
+  void add(void* dst, const void* src, size_t bytes) {
+    for (size_t o = 0; o < bytes; o += CM_UPLOAD_SLOT) pieces.push_back({(char*)dst + o, (const char*)src + o, std::min(CM_UPLOAD_SLOT, bytes - o)});
+  }
+};
+static void upload_start(cm_upload_res* r, int device, cm_upload_run& u) {
+  u.next = 0; u.err = 0;
+  const int nt = (int)std::min<size_t>(CM_UPLOAD_THREADS, u.pieces.size());
+  for (int t = 0; t < nt; ++t) u.th.emplace_back([r, device, &u, t] {
+    if (hipSetDevice(device) != hipSuccess) { u.err = 1; return; }
+    for (int k = 0;; ++k) {
+      const size_t i = u.next.fetch_add(1);
+      if (i >= u.pieces.size()) break;
+      const cm_upload_piece& pc = u.pieces[i];
+      const int s = k & 1;
+      if (r->used[t][s] && hipEventSynchronize(r->ev[t][s]) != hipSuccess) { u.err = 1; break; }   // the slot's last copy has left it
+      memcpy(r->slot[t][s], pc.src, pc.bytes);
+      if (hipMemcpyAsync(pc.dst, r->slot[t][s], pc.bytes, hipMemcpyHostToDevice, r->st[t]) != hipSuccess || hipEventRecord(r->ev[t][s], r->st[t]) != hipSuccess) { u.err = 1; break; }
+      r->used[t][s] = true;
+    }
+    if (hipStreamSynchronize(r->st[t]) != hipSuccess) u.err = 1;
+  });
+}
+static int upload_wait(cm_upload_run& u) {
+  for (auto& t : u.th) t.join();
+  u.th.clear(); u.pieces.clear();
+  if (u.err) { cm_set_error("upload of psc / stim failed: %s", hipGetErrorString(hipGetLastError())); return CM_ERR_HIP; }
+  return CM_OK;
+}
+
 extern "C" int cm_problem_create_batch_ex(cm_ctx* ctx, int32_t n, const int32_t* N, const int32_t* K, const int32_t* T, const cm_inputs* in, int mem_kind,
                                           cm_problem** out) {
   if (!ctx || !N || !K || !T || !in || !out || n < 1) { cm_set_error("cm_problem_create_batch_ex: NULL argument or n < 1"); return CM_ERR_INVALID; }
@@ -471,13 +536,62 @@ extern "C" int cm_problem_create_batch_ex(cm_ctx* ctx, int32_t n, const int32_t*
         (in[c].stim_layout == CM_STIM_TRIPLES && in[c].n_triples < 0)) { cm_set_error("cm_problem_create_batch_ex: unknown dtype / layout (circuit %d)", c); return CM_ERR_INVALID; }
   }
   CM_HIP(hipSetDevice(ctx->device));
-  for (int c0 = 0; c0 < n; c0 += CM_CREATE_CHUNK) {
+  auto undo = [&](int c0) { for (int c = 0; c < c0; ++c) { cm_problem_destroy(out[c]); out[c] = nullptr; } };
+  static const bool plain_upload = getenv("CAVIAR_HIP_PLAIN_UPLOAD") != nullptr;      // diagnostic: hipMemcpyAsync straight from the caller's pages
+  if (mem_kind != CM_MEM_HOST || plain_upload) {
+    for (int c0 = 0; c0 < n; c0 += CM_CREATE_CHUNK) {
+      const int m = std::min(CM_CREATE_CHUNK, n - c0);
+      const int rc = create_chunk(ctx, m, N + c0, K + c0, T + c0, in + c0, mem_kind, out + c0);
+      if (rc != CM_OK) { undo(c0); return rc; }
+    }
+    return CM_OK;
+  }
+  // Host inputs: the raw bytes of group g + 1 travel (copy threads -> pinned slots -> DMA) while the encoding kernels of group g run; the
+  // group is then created from device-resident inputs.
+  cm_upload_res* R = upload_res(ctx->device);
+  if (!R) return CM_ERR_HIP;
+  std::lock_guard<std::mutex> lk(R->use);
+  CM_HIP(hipStreamSynchronize(ctx->stream));                            // the copy streams write pool memory: nothing of this context may still be reading it
+  struct staged { std::vector<cm_inputs> in; std::vector<void*> bufs; cm_upload_run run; } S[2];
+  auto release = [&](staged& g) { for (void* q : g.bufs) cm_pool_free(ctx, q); g.bufs.clear(); };
+  auto stage = [&](int c0, staged& g) -> int {
     const int m = std::min(CM_CREATE_CHUNK, n - c0);
-    const int rc = create_chunk(ctx, m, N + c0, K + c0, T + c0, in + c0, mem_kind, out + c0);
+    g.in.assign(in + c0, in + c0 + m);
+    for (int c = 0; c < m; ++c) {
+      cm_inputs& ic = g.in[c];
+      const size_t n_psc = (size_t)K[c0 + c] * T[c0 + c], n_stim = (size_t)N[c0 + c] * K[c0 + c];
+      const size_t b_psc = n_psc * (ic.psc_dtype == CM_DTYPE_F64 ? 8 : 4);
+      const size_t b_stim = ic.stim_layout == CM_STIM_DENSE_F64 ? n_stim * 8 : ic.stim_layout == CM_STIM_DENSE_F32 ? n_stim * 4 : (size_t)ic.n_triples * sizeof(cm_stim_triple);
+      void *q = nullptr, *r = nullptr;
+      if (cm_pool_alloc(ctx, &q, b_psc) != CM_OK) return CM_ERR_HIP;
+      g.bufs.push_back(q);
+      g.run.add(q, ic.psc, b_psc); ic.psc = q;
+      if (b_stim) {
+        if (cm_pool_alloc(ctx, &r, b_stim) != CM_OK) return CM_ERR_HIP;
+        g.bufs.push_back(r);
+        g.run.add(r, ic.stim, b_stim); ic.stim = r;
+      }
+    }
+    upload_start(R, ctx->device, g.run);
+    return CM_OK;
+  };
+  int rc = stage(0, S[0]);
+  for (int c0 = 0, g = 0; c0 < n; c0 += CM_CREATE_CHUNK, ++g) {
+    staged& cur = S[g & 1];
+    staged& nxt = S[(g + 1) & 1];
+    const int rc_up = upload_wait(cur.run);
+    if (rc == CM_OK) rc = rc_up;
+    const bool more = c0 + CM_CREATE_CHUNK < n;
+    if (rc == CM_OK && more) rc = stage(c0 + CM_CREATE_CHUNK, nxt);
+    if (rc == CM_OK) rc = create_chunk(ctx, std::min(CM_CREATE_CHUNK, n - c0), N + c0, K + c0, T + c0, cur.in.data(), CM_MEM_DEVICE, out + c0);
     if (rc != CM_OK) {
-      for (int c = 0; c < c0; ++c) { cm_problem_destroy(out[c]); out[c] = nullptr; }
+      upload_wait(nxt.run);                                             // (joins whatever was started)
+      hipStreamSynchronize(ctx->stream);
+      release(cur); release(nxt);
+      undo(c0);
       return rc;
     }
+    release(cur);                                                       // (create_chunk returns with its stream drained)
   }
   return CM_OK;
 }
@@ -489,19 +603,9 @@ extern "C" int cm_problem_create_batch(cm_ctx* ctx, int32_t n, const int32_t* N,
   for (int c = 0; c < n; ++c) {
     out[c] = nullptr;
     if (!psc[c] || !stim[c]) { cm_set_error("cm_problem_create_batch: NULL psc / stim (circuit %d)", c); return CM_ERR_INVALID; }
-    if (N[c] < 2 || K[c] < 1 || T[c] < 1) { cm_set_error("cm_problem_create_batch: need N >= 2, K >= 1, T >= 1 (circuit %d: %d, %d, %d)", c, N[c], K[c], T[c]); return CM_ERR_INVALID; }
     in[c].psc_dtype = CM_DTYPE_F64; in[c].stim_layout = CM_STIM_DENSE_F64; in[c].psc = psc[c]; in[c].stim = stim[c]; in[c].n_triples = 0;
   }
-  CM_HIP(hipSetDevice(ctx->device));
-  for (int c0 = 0; c0 < n; c0 += CM_CREATE_CHUNK) {
-    const int m = std::min(CM_CREATE_CHUNK, n - c0);
-    const int rc = create_chunk(ctx, m, N + c0, K + c0, T + c0, in.data() + c0, mem_kind, out + c0);
-    if (rc != CM_OK) {
-      for (int c = 0; c < c0; ++c) { cm_problem_destroy(out[c]); out[c] = nullptr; }
-      return rc;
-    }
-  }
-  return CM_OK;
+  return cm_problem_create_batch_ex(ctx, n, N, K, T, in.data(), mem_kind, out);
 }
 
 extern "C" int cm_problem_create(cm_ctx* ctx, int32_t N, int32_t K, int32_t T, const double* psc, const double* stim, int mem_kind,
@@ -1303,6 +1407,38 @@ extern "C" int cm_caviar_fit_batch_ex(int32_t n, const int32_t* N, const int32_t
   if (n < 1 || !N || !K || !T || !inputs || !priors || !o || !results) { cm_set_error("cm_caviar_fit_batch_ex: NULL argument or n_circuits < 1"); return CM_ERR_INVALID; }
   return fit_batch_impl(n, N, K, T, inputs, priors, o, device_ids, n_devices, results, timings);
 }
+// The contexts of cm_caviar_fit_batch* stay with the process, one per device, their memory pools warm: building a context's pool for 256 circuits
+// and handing ~20 GB back to the driver cost 30 + 115 ms per call, more than the fit (CAVIAR_HIP_FIT_BATCH_TIMES).  cm_caviar_fit_batch_release
+// destroys them; CAVIAR_HIP_FIT_BATCH_NO_CACHE keeps none.
+static std::mutex g_fb_m;
+static std::map<int, cm_ctx*> g_fb_ctx;
+static cm_ctx* fb_take(int device) {
+  std::lock_guard<std::mutex> lk(g_fb_m);
+  auto it = g_fb_ctx.find(device);
+  if (it == g_fb_ctx.end()) return nullptr;
+  cm_ctx* c = it->second;
+  g_fb_ctx.erase(it);
+  return c;
+}
+static void fb_give(int device, cm_ctx* c) {
+  static const bool no_cache = getenv("CAVIAR_HIP_FIT_BATCH_NO_CACHE") != nullptr;
+  if (!no_cache) {
+    std::lock_guard<std::mutex> lk(g_fb_m);
+    if (!g_fb_ctx.count(device)) { g_fb_ctx[device] = c; return; }
+  }
+  cm_ctx_destroy(c);                                                   // (a concurrent call on the same device already left its own)
+}
+extern "C" int cm_caviar_fit_batch_release(void) {
+  std::vector<cm_ctx*> all;
+  {
+    std::lock_guard<std::mutex> lk(g_fb_m);
+    for (auto& kv : g_fb_ctx) all.push_back(kv.second);
+    g_fb_ctx.clear();
+  }
+  int rc = CM_OK;
+  for (cm_ctx* c : all) { const int r = cm_ctx_destroy(c); if (r != CM_OK) rc = r; }
+  return rc;
+}
 static int fit_batch_impl(int32_t n, const int32_t* N, const int32_t* K, const int32_t* T, const cm_inputs* in, const cm_priors* priors, const cm_options* o,
                           const int32_t* device_ids, int32_t n_devices, cm_result* results, cm_timings* timings) {
   const int32_t dev0 = 0;
@@ -1315,8 +1451,14 @@ static int fit_batch_impl(int32_t n, const int32_t* N, const int32_t* K, const i
     for (int c = d; c < n; c += n_devices) mine.push_back(c);
     if (mine.empty()) return;
     cm_ctx* ctx = nullptr;
-    int rc = cm_ctx_create(device_ids[d], nullptr, &ctx);
+    static const bool show = getenv("CAVIAR_HIP_FIT_BATCH_TIMES") != nullptr;        // diagnostic: where the call's time goes (stderr)
+    double tq[8] = {}; int nq = 0;
+    auto stamp = [&] { if (nq < 8) tq[nq++] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    stamp();
+    int rc = CM_OK;
+    if (!(ctx = fb_take(device_ids[d]))) rc = cm_ctx_create(device_ids[d], nullptr, &ctx);
     if (rc) return fail(rc);
+    stamp();
     std::vector<cm_problem*> ps(mine.size(), nullptr);
     std::vector<cm_priors> prs;
     std::vector<int32_t> n_(mine.size()), k_(mine.size()), t_(mine.size());
@@ -1330,16 +1472,23 @@ static int fit_batch_impl(int32_t n, const int32_t* N, const int32_t* K, const i
     }
     if (!mine.empty()) rc = cm_problem_create_batch_ex(ctx, (int)mine.size(), n_.data(), k_.data(), t_.data(), in_.data(), CM_MEM_HOST, ps.data());
     if (rc) ps.clear();
+    stamp();
     std::vector<cm_timings> tms(mine.size());
     if (!rc && !ps.empty()) rc = cm_caviar_run_batch(ctx, (int)ps.size(), ps.data(), prs.data(), o, timings ? tms.data() : nullptr);
+    stamp();
     if (!rc && !ps.empty()) rc = cm_caviar_fetch_batch(ctx, (int)ps.size(), ps.data(), res_.data());
+    stamp();
     for (size_t i = 0; !rc && i < mine.size(); ++i) {
       results[mine[i]].shape = res_[i].shape; results[mine[i]].rate = res_[i].rate;
       if (timings) timings[mine[i]] = tms[i];
     }
     if (rc) fail(rc);
     for (cm_problem* q : ps) cm_problem_destroy(q);
-    cm_ctx_destroy(ctx);
+    stamp();
+    if (rc) cm_ctx_destroy(ctx); else fb_give(device_ids[d], ctx);
+    stamp();
+    if (show) fprintf(stderr, "cm_caviar_fit_batch device %d: context %.1f ms, create (upload + encoding) %.1f, fit %.1f, fetch %.1f, destroy %.1f, context kept / destroyed %.1f\n",
+                      device_ids[d], tq[1] - tq[0], tq[2] - tq[1], tq[3] - tq[2], tq[4] - tq[3], tq[5] - tq[4], tq[6] - tq[5]);
   };
   if (n_devices == 1) work(0);
   else {

@@ -248,6 +248,10 @@ int cm_caviar_fit_batch(int32_t n_circuits, const int32_t* N, const int32_t* K, 
 int cm_caviar_fit_batch_ex(int32_t n_circuits, const int32_t* N, const int32_t* K, const int32_t* T, const cm_inputs* inputs, const cm_priors* priors,
                            const cm_options* options, const int32_t* device_ids, int32_t n_devices, cm_result* results, cm_timings* timings);
 
+/* cm_caviar_fit_batch* keep one context per device between calls, its memory pool warm (creating the pool for 256 circuits and handing its ~20 GB
+ * back to the driver cost more than the fit).  This destroys them; CAVIAR_HIP_FIT_BATCH_NO_CACHE in the environment keeps none. */
+int cm_caviar_fit_batch_release(void);
+
 /* ---- per-phase entry points (parity tests exercise each kernel in isolation; host buffers in/out) ---- */
 
 /* caviar.py:28-30: y[K] = trapz(psc[k,:]), ss[K] = sum_t psc[k,t]^2 */

@@ -798,6 +798,63 @@ def test_compact_inputs_build_the_same_circuits(ctx):
         q.close()
 
 
+def test_staged_upload_builds_the_same_circuits(ctx):
+    """Host inputs reach the device through pinned slots filled by copy threads (4 MB pieces; the bytes of group g + 1 of 64 circuits travel while
+    group g is encoded): 70 small circuits (two groups) and one whose arrays span several pieces are, bit for bit, the circuits built from the same
+    arrays already in HBM; cm_caviar_fit_batch keeps its context between calls and cm_caviar_fit_batch_release drops it."""
+    from circuitmap_amd import _lib
+    from circuitmap_amd.optimise.caviar import Problem, make_options, run_batch, _priors_struct
+    lib = ctx.lib
+    shapes = [(40, 100)] * 69 + [(300, 1300)]                       # psc of the last one: 1300 x 900 x 8 B = 9.4 MB = three pieces
+    sims = [_sim_case(N, K, 1200 + i)[0] for i, (N, K) in enumerate(shapes[:3])] + [_sim_case(300, 1300, 1290)[0]]
+    pick = lambda i: sims[3] if i == 69 else sims[i % 3]
+    rng = np.random.default_rng(5)
+    circuits = []
+    for i in range(70):
+        s_ = pick(i)
+        circuits.append((np.ascontiguousarray(s_["psc"] * (1.0 + 0.01 * (i // 3))), np.ascontiguousarray(s_["stim_matrix"], dtype=np.float64)))
+    host = Problem.create_batch(ctx, circuits)
+    ptrs = []
+    for psc, stim in circuits:
+        a, b = ctx.alloc(psc.nbytes), ctx.alloc(stim.nbytes)
+        ctx.upload(a, psc); ctx.upload(b, stim)
+        ptrs.append((a, b))
+    ctx.synchronize()
+    dev = Problem.create_batch(ctx, [("device", st.shape[0], st.shape[1], ps.shape[1], a, b) for (ps, st), (a, b) in zip(circuits, ptrs)])
+    assert [q.nnz for q in host] == [q.nnz for q in dev]
+    idx = [0, 1, 63, 64, 68, 69]
+    opts = dict(iters=6, seed=4)
+    for grp in (host, dev):
+        run_batch([grp[i] for i in idx[:-1]], [default_priors(40)] * 5, **opts)
+        run_batch([grp[69]], [default_priors(300)], **opts)
+    for i in idx:
+        _assert_same_fit(host[i].fetch(), dev[i].fetch(), "staged upload, circuit %d" % i)
+    for q in host + dev:
+        q.close()
+    for a, b in ptrs:
+        ctx.free(a); ctx.free(b)
+    # the one-call entry point twice (second call: the kept context), then the release
+    n = 3
+    keep = []
+    o = make_options(lib, **opts)
+    prs = (_lib.CmPriors * n)(*[_priors_struct(40, *prior_args(default_priors(40)), keep) for _ in range(n)])
+    i32 = lambda v: (C.c_int32 * n)(*v)
+    dpp = lambda arrs: (C.POINTER(C.c_double) * n)(*[_lib.dptr(x) for x in arrs])
+    mus = []
+    for rep in range(2):
+        res = (_lib.CmResult * n)()
+        mu = [np.empty(40) for _ in range(n)]
+        for c in range(n):
+            res[c].mu = _lib.dptr(mu[c])
+        _lib.check(lib.cm_caviar_fit_batch(n, i32([40] * n), i32([100] * n), i32([900] * n), dpp([c[0] for c in circuits[:n]]), dpp([c[1] for c in circuits[:n]]),
+                                           prs, C.byref(o), None, 0, res, None))
+        mus.append(mu)
+    for c in range(n):
+        np.testing.assert_array_equal(mus[0][c], mus[1][c])
+    assert lib.cm_caviar_fit_batch_release() == 0
+    assert lib.cm_caviar_fit_batch_release() == 0                   # nothing kept: still fine
+
+
 def test_listed_column_sums_never_matter(ctx, monkeypatch):
     """The column sums R = lam^T mu / colany over the LISTED trials (k_stats lists the trials of the rows with lam != 0, the pre-sweep adds those of
     revived rows, everything else is zeroed) give bitwise the results of the walk over all columns: forced on for a small shape
