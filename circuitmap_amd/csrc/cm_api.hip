@@ -1091,7 +1091,8 @@ static int run_set(cm_ctx* ctx, cm_set& s, const cm_priors* prs, const cm_option
     if (any_big && timed) CM_HIP(hipEventRecord(EV(it, 11), st));
     fact_it[it] = any_big && s.last_fact;
     if (phases) CM_HIP(hipEventRecord(EV(it, 1), st));
-    CM_TRY(cm_launch_sweep(ctx, s, it, o, timed ? EV(it, 3) : nullptr));  // :81  update_lam
+    // (every circuit took the in-LDS solve of the last k_iter_mid: block 0 left the chain tables of this sweep, the pre-sweep packs the records)
+    CM_TRY(cm_launch_sweep(ctx, s, it, o, timed ? EV(it, 3) : nullptr, -1, (!any_big && s.scan_it == it) ? 1 : 0));  // :81  update_lam
     if (timed) CM_HIP(hipEventRecord(EV(it, 4), st));
     CM_TRY(cm_launch_stats(ctx, s, o->spont_orthogonality, cm_sweep_quiescent(ctx, s, it, o), it));   // row + column statistics of the new lam
     if (rng_deferred) {

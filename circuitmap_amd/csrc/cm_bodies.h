@@ -1130,4 +1130,70 @@ __device__ __forceinline__ void mc_logit_body(int n, int lane, double mean0, dou
   }
 }
 
-
+// The chain of a sweep: ordered compaction of the rows with mu != 0 (in sweep order) + record offsets + chunk table, by the first NT threads of
+// ONE workgroup (NT = 1024: the last block of k_presweep; NT = CM_POST_THREADS: block 0 of k_iter_mid behind its in-LDS solve, which leaves the
+// tables for the next sweep so that the pre-sweep packs the records itself -- cm_launch_sweep).  The per-run totals are added by the packing.
+template <int NT>
+__device__ __forceinline__ void seq_scan_body(const int* __restrict__ order, const double* __restrict__ mu,
+                                              const int* __restrict__ row_ptr, int N, int* __restrict__ seq_n,
+                                              int* __restrict__ seq_off, int* __restrict__ chunk_first, int* __restrict__ meta,
+                                              int* __restrict__ seq_pos, int gran, int pack_max, int (*wsum)[NT / CM_WAVE], int* carry) {
+  constexpr int E = 4;                           // consecutive sweep positions per thread: their loads in flight together, one scan round per E * NT rows
+  if (threadIdx.x < 2) carry[threadIdx.x] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x % CM_WAVE, w = threadIdx.x / CM_WAVE;
+  for (int m0 = 0; m0 < N; m0 += E * NT) {
+    const int mb = m0 + E * (int)threadIdx.x;
+    int n[E], f[E], recs[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) n[e] = (mb + e < N) ? order[mb + e] : -1;
+    int tf = 0, tr = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      f[e] = 0; recs[e] = 0;
+      if (n[e] >= 0) {
+        f[e] = mu[n[e]] != 0.0;
+        const int len = row_ptr[n[e] + 1] - row_ptr[n[e]];
+        recs[e] = f[e] ? 1 + (len <= pack_max ? len : 0) : 0;     // (a row beyond pack_max keeps its header only: the single-consumer kernel walks it from the CSR arrays)
+      }
+      tf += f[e]; tr += recs[e];
+    }
+    int sf = tf, sr = tr;                      // inclusive wave scans of the threads' totals
+    for (int o = 1; o < CM_WAVE; o <<= 1) {
+      const int uf = __shfl_up(sf, o, CM_WAVE), ur = __shfl_up(sr, o, CM_WAVE);
+      if (lane >= o) { sf += uf; sr += ur; }
+    }
+    if (lane == CM_WAVE - 1) { wsum[0][w] = sf; wsum[1][w] = sr; }
+    __syncthreads();
+    int bf = carry[0], br = carry[1];
+    for (int i = 0; i < w; ++i) { bf += wsum[0][i]; br += wsum[1][i]; }
+    int j = bf + sf - tf, off = br + sr - tr;    // exclusive positions of the thread's first row
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      if (f[e]) {
+        seq_n[j] = n[e];
+        seq_off[j] = off;
+        // chunk of this row = floor((end offset - 1) / B); first row of each chunk registers itself
+        const int c = (off + recs[e] - 1) / gran;
+        const int cprev = off == 0 ? -1 : (off - 1) / gran;       // previous row ends at `off`
+        if (c != cprev) chunk_first[c] = j;
+      }
+      if (n[e] >= 0) seq_pos[n[e]] = f[e] ? j : -1;               // position in the chain, for the per-trial tickets
+      j += f[e]; off += recs[e];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int uf = 0, ur = 0;
+      for (int i = 0; i < NT / CM_WAVE; ++i) { uf += wsum[0][i]; ur += wsum[1][i]; }
+      carry[0] += uf; carry[1] += ur;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int nseq = carry[0], total = carry[1];
+    const int nchunks = total > 0 ? (total - 1) / gran + 1 : 0;
+    seq_off[nseq] = total;
+    chunk_first[nchunks] = nseq;
+    meta[0] = nseq; meta[1] = total; meta[2] = nchunks;
+  }
+}

@@ -336,6 +336,7 @@ struct cm_set {
   bool lists_ok = false;                 // every prior mean of the set is zero: a row outside the active set has mu = 0, only rows with lam != 0 feed R (run_set)
   int tlist_it = -1;                     // iteration for which k_stats listed the trials of the rows with lam != 0 (-1: no list)
   int tlist_sweep_it = -1;               // iteration whose pre-sweep ran on that list (and appended the trials of revived rows)
+  int scan_it = -2;                      // iteration whose chain tables block 0 of the last k_iter_mid leaves in every circuit that takes its in-LDS solve (-2: none)
   std::vector<int> na;                   // last active-set sizes read from the mailboxes
   int na_max = 0;
 };
@@ -509,7 +510,9 @@ int cm_launch_iter_mid(cm_ctx* ctx, cm_set& s, int it, int iters, int S, int rng
                        hipEvent_t between = nullptr);   // between: recorded between k_iter_mid and k_mc_dead (batches)
 int cm_launch_ndtri_table(cm_ctx* ctx, cm_problem* p, int it0, int n_it, int S, int rng_mode, hipStream_t st);
 int cm_launch_rng(cm_ctx* ctx, cm_problem* p, int it0, int n_it, hipStream_t st);
-int cm_launch_sweep(cm_ctx* ctx, cm_set& s, int it, const cm_options* o, hipEvent_t mid, int table_it = -1);   // table_it: iteration whose sweep order is used (default: it)
+int cm_launch_sweep(cm_ctx* ctx, cm_set& s, int it, const cm_options* o, hipEvent_t mid, int table_it = -1, int fused_pack = 0);   // table_it: iteration whose sweep order is used (default: it); fused_pack: the chain tables exist (cm_set::scan_it), the pre-sweep packs
+void cm_sweep_chunking(const cm_set& s, int par, int* cap, int* pack_max, int* gran);
+int cm_par_min_rows();
 int cm_launch_sum_y(cm_ctx* ctx, cm_set& s);
 int cm_sweep_variant(const cm_set& s, int rows_hint);
 int cm_launch_stats(cm_ctx* ctx, cm_set& s, double spont_orthogonality, int quiescent = 0, int it = -1);   // quiescent: cm_sweep_quiescent() of the sweep just launched

@@ -26,6 +26,10 @@ struct IterDyn {     // what changes from iteration to iteration (common to all 
   int rpw;             // rows per wavefront of the per-neuron role (phi_pair): 2 = a row per 32-lane half (throughput: the early iterations of a batch), 1 = lower half only (latency: one circuit, listed rows)
   int mc_screen, dead_sep; double msrmp, min_count;   // k_mc_dead: the next sweep is gated -> all-zero rows whose gate cannot pass need no Monte-Carlo logit
   long long* dbg;      // diagnostic (CAVIAR_HIP_TRACE_BLOCK0): device clock at the phase boundaries of block 0, 8 words per launch
+  // block 0, behind its in-LDS solve: the chain tables of the NEXT sweep (seq_scan_body) -- granule and packed-row limit of that sweep's
+  // chunking for the single-consumer kernel [0] and for the multi-wave class of the set [1] (one circuit: chosen by the active-set size as
+  // cm_launch_sweep chooses, cm_sweep_variant)
+  int scan_on, scan_gran[2], scan_pack[2], scan_min_rows;
 };
 
 // an all-zero row takes the per-run constants of its neuron: phi, phi_cov (written by lane 0) and the truncation points c0, c1
@@ -265,6 +269,17 @@ __global__ __launch_bounds__(CM_ITER_THREADS, (BATCH && !FULLMC) ? 4 : 1) void k
       __syncthreads();
       solve_small_body(sm, p.lam, p.row_ptr, p.col, p.act_idx, p.rs, p.scal, p.mu_prior, p.beta_prior, n, p.N, n * p.max_row_len, p.mu,
                        p.beta, p.n_act + 1, CM_POST_THREADS);
+      if (a.scan_on) {
+        // mu of the next sweep is final: its chain tables now, beside the Newton chains of the other blocks -- the pre-sweep then packs the
+        // (few) chain rows itself and the sweep is one launch shorter
+        __shared__ int wsum[2][CM_POST_THREADS / CM_WAVE];
+        __shared__ int carry[2];
+        __threadfence_block();
+        __syncthreads();
+        const int sel = (BATCH || n > a.scan_min_rows) ? 1 : 0;
+        seq_scan_body<CM_POST_THREADS>(p.orders_all + (size_t)(a.it + 1) * p.N, p.mu, p.row_ptr, p.N, p.seq_n, p.seq_off, p.chunk_first, p.seq_meta, p.seq_pos,
+                                       a.scan_gran[sel], a.scan_pack[sel], wsum, carry);
+      }
     }
     if (a.dbg && threadIdx.x == 0) { a.dbg[4] = wall_clock64(); a.dbg[6] = n; }
     return;
@@ -430,6 +445,16 @@ int cm_launch_iter_mid(cm_ctx* ctx, cm_set& s, int it, int iters, int S, int rng
   // but the all-zero ones -- most rows from the first gated sweep on -- go to k_mc_dead, where nearly all of them are screened
   a.dead_sep = (s.B > 1 && do_phi && it >= 0 && roles == 3 && a.mc_screen && !a.skip_dead && nxt < iters) ? 1 : 0;
   a.dbg = (ctx->dbg_block0 && it >= 0 && it < 64) ? ctx->dbg_block0 + 8 * it : nullptr;
+  // the chain tables of the next sweep from block 0 (cm_launch_sweep packs in the pre-sweep when every circuit of the set got them)
+  a.scan_on = (a.do_solve && (roles & 1)) ? 1 : 0;
+  {
+    const int par = cm_sweep_variant(s, 1 << 30);
+    cm_sweep_chunking(s, 0, nullptr, &a.scan_pack[0], &a.scan_gran[0]);
+    cm_sweep_chunking(s, par, nullptr, &a.scan_pack[1], &a.scan_gran[1]);
+    a.scan_min_rows = cm_par_min_rows();
+    if (par == 0) { a.scan_pack[1] = a.scan_pack[0]; a.scan_gran[1] = a.scan_gran[0]; }
+  }
+  s.scan_it = a.scan_on ? nxt : -2;
   const int threads = s.B == 1 ? CM_ITER_THREADS : CM_ITER_THREADS_BATCH;
   const int waves = threads / CM_WAVE;
   size_t lds = (size_t)waves * 2 * S * sizeof(double);

@@ -1319,6 +1319,7 @@ int cm_solve_mu(cm_ctx* ctx, cm_set& s, int* n_active_out) {
 // Which family factors matrices above `large_min` tile rows: batches take the grouped one (throughput: 26 against 19 TFLOP/s at 128 x
 // n = 1000); one large matrix is bound by the chain of diagonal blocks, which the pair family walks in slightly shorter steps (cfg5: 11.0
 // against 12.0 ms per fit), so it stays there.  CAVIAR_HIP_CHOL_FAMILY: 0 = pairs everywhere, 1 = this default, 2 = grouped everywhere.
+static inline int cm_large_tiles() { static const int v = getenv("CAVIAR_HIP_LARGE_TILES") ? atoi(getenv("CAVIAR_HIP_LARGE_TILES")) : CM_LARGE_TILES; return v; }   // (diagnostic)
 static inline bool cm_use_grouped(const cm_ctx* ctx, bool single) { return ctx->chol_family == 2 || (ctx->chol_family == 1 && !single); }
 
 // One group of circuits through the tiled solve; `parts`: 1 = precision matrices, 2 = Cholesky, 4 = inverse of the factor, 8 = mu / beta.
@@ -1491,7 +1492,7 @@ extern "C" int cm_k_solve_bench(cm_ctx* ctx, int32_t n, int32_t B, int32_t reps,
     for (int c = 0; c < B; ++c) hipLaunchKernelGGL(k_bench_fill_spd, dim3((unsigned)((msz + 255) / 256)), dim3(256), 0, st, h[c].A, n, ld, 0.01 * c);
     cm_solve_sub g;
     g.B = B; g.single = B == 1; g.h0 = h[0]; g.d_arr = d_arr;
-    const int large_min = B > 1 ? 1 : CM_LARGE_TILES;
+    const int large_min = B > 1 ? 1 : cm_large_tiles();
     const int xflags = 0 | (ctx->xcd_mode << 8);
     rc = cm_solve_group_launch(ctx, g, nblk, n, B == 1 ? n : 0, 0, xflags, large_min, 2, ctx->ev[0], ctx->ev[1]);
     if (rc == CM_OK) rc = cm_solve_group_launch(ctx, g, nblk, n, B == 1 ? n : 0, 0, xflags, large_min, 4, nullptr, nullptr);
@@ -1523,7 +1524,7 @@ int cm_solve_launch(cm_ctx* ctx, cm_set& s, int skip_mode, hipEvent_t fact_begin
   // Two families of trailing-update kernels with bitwise the same results: one launch per panel, every workgroup re-deriving the
   // panel solve (shortest dependent chain: one circuit, up to CM_LARGE_TILES tile rows), or panel solve once + lean 256-thread
   // trailing update (least traffic per tile: large matrices, and every batch -- there the launches are throughput-bound).
-  const int large_min = s.B > 1 ? 1 : CM_LARGE_TILES;
+  const int large_min = s.B > 1 ? 1 : cm_large_tiles();
   bool any_small = false, any_tiled = false, any_panel = false, any_large = false;
   int na_small = 0, nblk_max = 0, nblk_panel = 0, na_tiled = 0;
   size_t lds_small = 0;

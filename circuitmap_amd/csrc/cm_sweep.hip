@@ -459,59 +459,49 @@ struct __align__(16) SeqRec {
 #define CM_SEQ_B (CM_SEQ_CAP - CM_WAVE - 1)   // chunking granule: a chunk spans < B + 65 <= CAP records
 #define CM_SEQ_LDS_CHUNKS 512
 
-__device__ __forceinline__ void seq_scan_body(const int* __restrict__ order, const double* __restrict__ mu,
-                                              const int* __restrict__ row_ptr, int N, int* __restrict__ seq_n,
-                                              int* __restrict__ seq_off, int* __restrict__ chunk_first, int* __restrict__ meta,
-                                              int* __restrict__ seq_pos, int gran, int pack_max, int (*wsum)[16], int* carry) {
-  if (threadIdx.x < 2) carry[threadIdx.x] = 0;
-  __syncthreads();
-  const int lane = threadIdx.x % CM_WAVE, w = threadIdx.x / CM_WAVE;
-  for (int m0 = 0; m0 < N; m0 += 1024) {
-    const int m = m0 + threadIdx.x;
-    int f = 0, recs = 0, n = 0;
-    if (m < N) {
-      n = order[m];
-      f = mu[n] != 0.0;
-      const int len = row_ptr[n + 1] - row_ptr[n];
-      recs = f ? 1 + (len <= pack_max ? len : 0) : 0;     // (a row beyond pack_max keeps its header only: the single-consumer kernel walks it from the CSR arrays)
+// `turns` != 0: also store in bits 24..31 of the slot word how many EARLIER chain rows touch the entry's trial (its ticket
+// in the multi-wave chain kernel); requires nnz < 2^24 and at most 255 targeted neurons per trial.
+// Wavefront `w` of `nw` takes the chain rows w, w + nw, ...  (k_seq_pack: the whole grid; k_presweep: the blocks of its fourth role.)
+__device__ __forceinline__ void seq_pack_body(const cm_pdev& p, const SweepArgs& a, int turns, int pack_max, int w, int nw, int lane) {
+  const int* __restrict__ seq_n = p.seq_n;
+  const int* __restrict__ seq_off = p.seq_off;
+  const int* __restrict__ seq_pos = p.seq_pos;
+  const int* __restrict__ col_ptr = p.col_ptr;
+  const int* __restrict__ csc_row = p.csc_row;
+  SeqRec* __restrict__ packed = (SeqRec*)p.packed;
+  const int nseq = p.seq_meta[0];
+  if (w == 0 && lane == 0) { p.seq_meta[4] += nseq; p.seq_meta[5] += p.seq_meta[1]; }   // per-run totals (reported in cm_timings): once per sweep
+  const double sig = a.scal[CM_S_SHAPE] / a.scal[CM_S_RATE];
+  // The grid is sized by the host for twice the largest active set of the batch (the chain rows, mu != 0, are normally among the rows the last
+  // solve covered: a wavefront then takes one row); whatever lies beyond it -- a prior mean that is not zero makes every row a chain row -- is
+  // reached by the stride.  A grid of N / 4 workgroups per circuit, of which 95 % found nothing to do, was most of this kernel's time in a batch.
+  for (int j = w; j < nseq; j += nw) {
+    const int n = seq_n[j], off = seq_off[j];
+    const int beg = a.row_ptr[n], len = a.row_ptr[n + 1] - beg;
+    const double mu = a.mu[n], be = a.beta[n];
+    if (lane == 0) {
+      SeqRec h;
+      h.a = (uint32_t)n; h.b = len; h.x = mu; h.y = sig * (mu * mu + be * be); h.z = 0.0;   // caviar.py:206
+      packed[off] = h;
     }
-    int sf = f, sr = recs;                     // inclusive wave scans
-    for (int o = 1; o < CM_WAVE; o <<= 1) {
-      const int tf = __shfl_up(sf, o, CM_WAVE), tr = __shfl_up(sr, o, CM_WAVE);
-      if (lane >= o) { sf += tf; sr += tr; }
+    if (len > pack_max) continue;                     // (header only: see seq_scan_body)
+    for (int l = lane; l < len; l += CM_WAVE) {       // a row of more than 64 trials: ceil(len / 64) segments of records, in trial order
+      const int e = beg + l;
+      const int k = a.col[e], g = a.grp[e];
+      SeqRec r;
+      r.a = (uint32_t)k | ((uint32_t)g << 24) | ((uint32_t)(a.me[e] != 0) << 31);
+      int turn = 0;
+      if (turns)     // (gathering four neurons at a time was measured slower than this plain loop: 28.3 vs 26.8 us at 128 circuits, 6.6 vs 5.4 us for one)
+        for (int ce = col_ptr[k]; ce < col_ptr[k + 1]; ++ce) { const int q = seq_pos[csc_row[ce]]; turn += (q >= 0 && q < j); }
+      if (turns == 2 && j == 1 && l == 0) turn = (turn + 1) & 0xFF;   // fault injection (CAVIAR_HIP_TEST_BAD_TICKET): a turn that never comes
+      r.b = e | (turn << 24);
+      r.x = a.lam[e];
+      r.y = a.mcE[(size_t)n * a.mld + g];
+      r.z = -2.0 * sig * a.ye[e] * mu;                                                      // caviar.py:205, first term (ye[e] = y[k])
+      packed[off + 1 + l] = r;
     }
-    if (lane == CM_WAVE - 1) { wsum[0][w] = sf; wsum[1][w] = sr; }
-    __syncthreads();
-    int bf = carry[0], br = carry[1];
-    for (int i = 0; i < w; ++i) { bf += wsum[0][i]; br += wsum[1][i]; }
-    if (f) {
-      const int j = bf + sf - 1, off = br + sr - recs;     // exclusive positions
-      seq_n[j] = n;
-      seq_off[j] = off;
-      // chunk of this row = floor((end offset - 1) / B); first row of each chunk registers itself
-      const int c = (off + recs - 1) / gran;
-      const int cprev = off == 0 ? -1 : (off - 1) / gran;       // previous row ends at `off`
-      if (c != cprev) chunk_first[c] = j;
-    }
-    if (m < N) seq_pos[n] = f ? (bf + sf - 1) : -1;         // position in the chain, for the per-trial tickets
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int tf = 0, tr = 0;
-      for (int i = 0; i < 16; ++i) { tf += wsum[0][i]; tr += wsum[1][i]; }
-      carry[0] += tf; carry[1] += tr;
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    const int nseq = carry[0], total = carry[1];
-    const int nchunks = total > 0 ? (total - 1) / gran + 1 : 0;
-    seq_off[nseq] = total;
-    chunk_first[nchunks] = nseq;
-    meta[0] = nseq; meta[1] = total; meta[2] = nchunks;
-    meta[4] += nseq; meta[5] += total;            // per-run totals (reported in cm_timings)
   }
 }
-
 // One launch, three independent roles (1024-thread blocks):
 //   blocks [0, nbI)        rows with mu == 0, one wave per row (they neither read nor change R)
 //   blocks [nbI, nbI+nbC)  R_k = sum_n mu_n lam_nk per trial (= lam.T @ mu), 16 lanes per trial.  Rows handled by the
@@ -526,7 +516,7 @@ __device__ __forceinline__ void seq_scan_body(const int* __restrict__ order, con
 // rows: a handful) are walked by the workgroup's wavefronts.  1 workgroup per 1024 rows instead of 32 or 64.
 template <bool BATCH, bool LEAN>
 __global__ __launch_bounds__(1024, (BATCH && LEAN) ? 8 : 4) void k_presweep(cm_parg<BATCH> pa, int it, int gated, double msrmp, double min_count, int nbI, int nbC,
-                                                    int roles, int gran, int quiescent, int nbL, int list_it, int pack_max) {
+                                                    int roles, int gran, int quiescent, int nbL, int list_it, int pack_max, int scan_done, int turns) {
   __shared__ double scr_all[16][3 * CM_MAX_VALS];
   __shared__ int wsum[2][16];
   __shared__ int carry[2];
@@ -576,58 +566,26 @@ __global__ __launch_bounds__(1024, (BATCH && LEAN) ? 8 : 4) void k_presweep(cm_p
     }
     if (BATCH) cm_col_dot16x2((b - nbI) * 1024 + threadIdx.x, p.K, a.mu, a.lam, p.col_ptr, p.csc_row, p.csc_pos, 0.0, p.R, nullptr);
     else cm_col_dot16((b - nbI) * 1024 + threadIdx.x, p.K, a.mu, a.lam, p.col_ptr, p.csc_row, p.csc_pos, 0.0, p.R, nullptr);
-  } else {
+  } else if (b == nbI + nbC) {
     if (!(roles & 4)) return;
     if (BATCH && threadIdx.x == 0) p.alive[0] = 0;     // list of rows with lam != 0 that k_stats rebuilds after the sweep
     if (threadIdx.x == 0) { const int qn = (it + 1) & 1; p.tcnt[qn] = 0; p.tcnt[2 + qn] = 0; }   // the trial lists of the next iteration start empty
-    seq_scan_body(p.orders_all + (size_t)it * N, a.mu, a.row_ptr, N, p.seq_n, p.seq_off, p.chunk_first, p.seq_meta, p.seq_pos, gran, pack_max, wsum, carry);
+    // (scan_done: block 0 of the k_iter_mid that produced this iteration's mu has left the chain's tables already -- every circuit of the set
+    // took the in-LDS solve -- and the blocks behind this one pack the records in this launch)
+    if (!scan_done) seq_scan_body<1024>(p.orders_all + (size_t)it * N, a.mu, a.row_ptr, N, p.seq_n, p.seq_off, p.chunk_first, p.seq_meta, p.seq_pos, gran, pack_max, wsum, carry);
+  } else {
+    // the chain's records (k_seq_pack's work as a fourth role: a short chain -- at most small_cap rows per circuit -- is not worth a launch)
+    if (!(roles & 4)) return;
+    const int nw = (int)(gridDim.x - (nbI + nbC + 1)) * 16;
+    seq_pack_body(p, a, turns, pack_max, (b - (nbI + nbC + 1)) * 16 + (int)threadIdx.x / CM_WAVE, nw, threadIdx.x % CM_WAVE);
   }
 }
 
-// `turns` != 0: also store in bits 24..31 of the slot word how many EARLIER chain rows touch the entry's trial (its ticket
-// in the multi-wave chain kernel); requires nnz < 2^24 and at most 255 targeted neurons per trial.
 template <bool BATCH>
 __global__ __launch_bounds__(256) void k_seq_pack(cm_parg<BATCH> pa, int gated, double msrmp, double min_count, int turns, int pack_max) {
   const cm_pdev& p = pa.get();
   const SweepArgs a = sweep_args(p, gated, msrmp, min_count);
-  const int* __restrict__ seq_n = p.seq_n;
-  const int* __restrict__ seq_off = p.seq_off;
-  const int* __restrict__ seq_pos = p.seq_pos;
-  const int* __restrict__ col_ptr = p.col_ptr;
-  const int* __restrict__ csc_row = p.csc_row;
-  SeqRec* __restrict__ packed = (SeqRec*)p.packed;
-  const int lane = threadIdx.x % CM_WAVE;
-  const int nseq = p.seq_meta[0];
-  const double sig = a.scal[CM_S_SHAPE] / a.scal[CM_S_RATE];
-  // The grid is sized by the host for twice the largest active set of the batch (the chain rows, mu != 0, are normally among the rows the last
-  // solve covered: a wavefront then takes one row); whatever lies beyond it -- a prior mean that is not zero makes every row a chain row -- is
-  // reached by the stride.  A grid of N / 4 workgroups per circuit, of which 95 % found nothing to do, was most of this kernel's time in a batch.
-  for (int j = (blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE; j < nseq; j += (int)(gridDim.x * blockDim.x) / CM_WAVE) {
-    const int n = seq_n[j], off = seq_off[j];
-    const int beg = a.row_ptr[n], len = a.row_ptr[n + 1] - beg;
-    const double mu = a.mu[n], be = a.beta[n];
-    if (lane == 0) {
-      SeqRec h;
-      h.a = (uint32_t)n; h.b = len; h.x = mu; h.y = sig * (mu * mu + be * be); h.z = 0.0;   // caviar.py:206
-      packed[off] = h;
-    }
-    if (len > pack_max) continue;                     // (header only: see seq_scan_body)
-    for (int l = lane; l < len; l += CM_WAVE) {       // a row of more than 64 trials: ceil(len / 64) segments of records, in trial order
-      const int e = beg + l;
-      const int k = a.col[e], g = a.grp[e];
-      SeqRec r;
-      r.a = (uint32_t)k | ((uint32_t)g << 24) | ((uint32_t)(a.me[e] != 0) << 31);
-      int turn = 0;
-      if (turns)     // (gathering four neurons at a time was measured slower than this plain loop: 28.3 vs 26.8 us at 128 circuits, 6.6 vs 5.4 us for one)
-        for (int ce = col_ptr[k]; ce < col_ptr[k + 1]; ++ce) { const int q = seq_pos[csc_row[ce]]; turn += (q >= 0 && q < j); }
-      if (turns == 2 && j == 1 && l == 0) turn = (turn + 1) & 0xFF;   // fault injection (CAVIAR_HIP_TEST_BAD_TICKET): a turn that never comes
-      r.b = e | (turn << 24);
-      r.x = a.lam[e];
-      r.y = a.mcE[(size_t)n * a.mld + g];
-      r.z = -2.0 * sig * a.ye[e] * mu;                                                      // caviar.py:205, first term (ye[e] = y[k])
-      packed[off + 1 + l] = r;
-    }
-  }
+  seq_pack_body(p, a, turns, pack_max, (int)(blockIdx.x * blockDim.x + threadIdx.x) / CM_WAVE, (int)(gridDim.x * blockDim.x) / CM_WAVE, threadIdx.x % CM_WAVE);
 }
 
 // A chain row of MORE than 64 trials from its packed records (LDS; `rec` = the row's first entry record, `len` entries in trial order), as
@@ -1009,7 +967,19 @@ int cm_sweep_quiescent(const cm_ctx* ctx, const cm_set& s, int it, const cm_opti
   return (it > o->delay_spont_est && 2 * s.na_max < s.lead->N) ? 1 : 0;
 }
 
-int cm_launch_sweep(cm_ctx* ctx, cm_set& s, int it, const cm_options* o, hipEvent_t mid, int table_it) {
+// Chunking of the chain's records for sweep variant `par` (cm_sweep_variant): chain rows of up to pack_max trials travel as packed records (rows
+// of more than 64 as several 64-entry segments); a longer row keeps its header only and is walked from the CSR arrays by the single-consumer kernel
+// (the multi-wave kernel requires every row packed).  Chunking granule: a chunk spans < gran + 1 + pack_max <= cap records.
+void cm_sweep_chunking(const cm_set& s, int par, int* cap_out, int* pack_max_out, int* gran_out) {
+  const int cap = (par == 2) ? 512 : CM_SEQ_CAP;
+  const int pack_max = std::max(CM_WAVE, std::min(s.max_row_len_max, cm_pack_limit(cap)));
+  if (cap_out) *cap_out = cap;
+  if (pack_max_out) *pack_max_out = pack_max;
+  if (gran_out) *gran_out = cap - pack_max - 1;
+}
+int cm_par_min_rows() { return CM_PAR_MIN_ROWS; }
+
+int cm_launch_sweep(cm_ctx* ctx, cm_set& s, int it, const cm_options* o, hipEvent_t mid, int table_it, int fused_pack) {
   const cm_problem* p = s.lead;
   const int gated = it > o->delay_spont_est;
   const double msrmp = o->msrmp, min_count = o->minimum_spike_count;
@@ -1021,12 +991,8 @@ int cm_launch_sweep(cm_ctx* ctx, cm_set& s, int it, const cm_options* o, hipEven
   // variant 2 = 512-record buffers + 8-bit tickets (larger K); 0 = single-consumer kernel.  Whichever kernel walks the chain,
   // every R_k sees its updates in sweep order: the variants give bit-identical results.
   const int par = cm_sweep_variant(s, s.B > 1 ? 1 : ctx->mb_n);
-  const int cap = (par == 2) ? 512 : CM_SEQ_CAP;
-  // Chain rows of up to pack_max trials travel as packed records (rows of more than 64 as several 64-entry segments); a longer row keeps its
-  // header only and is walked from the CSR arrays by the single-consumer kernel (the multi-wave kernel requires every row packed:
-  // cm_sweep_variant).  Chunking granule: a chunk spans < gran + 1 + pack_max <= cap records.
-  const int pack_max = std::max(CM_WAVE, std::min(s.max_row_len_max, cm_pack_limit(cap)));
-  const int gran = cap - pack_max - 1;
+  int cap, pack_max, gran;
+  cm_sweep_chunking(s, par, &cap, &pack_max, &gran);
   const size_t lds_par = (par == 2) ? (size_t)p->K * 9 + 16 : (size_t)p->K * 12;
   static const bool split = getenv("CAVIAR_HIP_SPLIT_PRESWEEP") != nullptr;     // diagnostic: one launch per role (profiling only)
   int v_max = 0;
@@ -1045,14 +1011,22 @@ int cm_launch_sweep(cm_ctx* ctx, cm_set& s, int it, const cm_options* o, hipEven
     nbL = (int)(((est + 1) / 2 + 63) / 64);                         // two listed trials per 16-lane segment
     nbCk = nbL + (p->K + 1023) / 1024;
   }
+  static const bool bad_ticket = getenv("CAVIAR_HIP_TEST_BAD_TICKET") != nullptr;   // test hook: exercises the bounded wait + error report of the ticketed chain
+  static const bool no_fused_pack = getenv("CAVIAR_HIP_NO_FUSED_PACK") != nullptr;  // diagnostic: the scan in the pre-sweep and k_seq_pack as its own launch, always
+  const int turns = par ? (bad_ticket ? 2 : 1) : 0;
+  // fused_pack: the k_iter_mid before this sweep left the chain's tables (every circuit took its in-LDS solve: chains of at most small_cap rows) --
+  // the records are packed by a few more blocks of the pre-sweep (16 rows each) instead of a launch of their own
+  const bool fused = fused_pack && !split && !no_fused_pack && table_it < 0;
+  const int nbP = fused ? (std::min(N, std::max(1, s.na_max)) + 15) / 16 : 0;       // (a wavefront per chain row of the largest active set; the stride takes what a non-zero prior mean adds)
   for (int pass = 0; pass < (split ? 3 : 1); ++pass) {
-    if (lean) CM_LAUNCH_SET_T(k_presweep, (true), s, nbIq + nbCk + 1, 1024, 0, st, (table_it < 0 ? it : table_it), gated, msrmp, min_count, nbIq, nbCk, split ? (1 << pass) : 7, gran, quiescent, nbL, list_it, pack_max);
-    else CM_LAUNCH_SET_T(k_presweep, (false), s, nbIq + nbCk + 1, 1024, 0, st, (table_it < 0 ? it : table_it), gated, msrmp, min_count, nbIq, nbCk, split ? (1 << pass) : 7, gran, quiescent, nbL, list_it, pack_max);
+    if (lean) CM_LAUNCH_SET_T(k_presweep, (true), s, nbIq + nbCk + 1 + nbP, 1024, 0, st, (table_it < 0 ? it : table_it), gated, msrmp, min_count, nbIq, nbCk, split ? (1 << pass) : 7, gran, quiescent, nbL, list_it, pack_max, fused ? 1 : 0, turns);
+    else CM_LAUNCH_SET_T(k_presweep, (false), s, nbIq + nbCk + 1 + nbP, 1024, 0, st, (table_it < 0 ? it : table_it), gated, msrmp, min_count, nbIq, nbCk, split ? (1 << pass) : 7, gran, quiescent, nbL, list_it, pack_max, fused ? 1 : 0, turns);
   }
   s.tlist_sweep_it = list_it;
-  static const bool bad_ticket = getenv("CAVIAR_HIP_TEST_BAD_TICKET") != nullptr;   // test hook: exercises the bounded wait + error report of the ticketed chain
-  const int pack_rows = s.B > 1 ? std::min(N, std::max(64, 2 * s.na_max)) : N;      // (one circuit: the N / 4 workgroups are not what its 5 us are made of)
-  CM_LAUNCH_SET(k_seq_pack, s, (pack_rows + 3) / 4, 256, 0, st, gated, msrmp, min_count, par ? (bad_ticket ? 2 : 1) : 0, pack_max);
+  if (!fused) {
+    const int pack_rows = s.B > 1 ? std::min(N, std::max(64, 2 * s.na_max)) : N;      // (one circuit: the N / 4 workgroups are not what its 5 us are made of)
+    CM_LAUNCH_SET(k_seq_pack, s, (pack_rows + 3) / 4, 256, 0, st, gated, msrmp, min_count, turns, pack_max);
+  }
   if (mid) CM_HIP(hipEventRecord(mid, st));
   const size_t lds = (size_t)p->K * sizeof(double);
   const long long nrec = (long long)p->N + s.nnz_min;          // smallest allocation of `packed` (records) and of the chunk table in the set
