@@ -256,6 +256,7 @@ __global__ __launch_bounds__(CM_ITER_THREADS, (BATCH && !FULLMC) ? 4 : 1) void k
   if (blockIdx.x <= 1) {
     if (!(a.roles & 1)) return;
     if (threadIdx.x >= CM_POST_THREADS) return;
+    if (BATCH && blockIdx.y != 0) a.dbg = nullptr;     // (diagnostic stamps: circuit 0 only)
     if (blockIdx.x == 1) {                               // soft threshold + spont_rate: its own workgroup, beside block 0
       if (a.do_sigma)
         post_single_body(p.y, p.R, p.colany, p.mask, p.mu, p.beta, p.rs, p.sum_y, p.N, p.K, a.it, a.max_iters, a.penalty, a.scale_factor, a.tol,

@@ -4,7 +4,7 @@
 
 `fit_specs(specs)` is also what the parent runs in its own process for its side of the comparison, so both sides execute the same
 Python.  A spec: N, K, B, seed0, opts (fit options), batch (lock-step batch or one fit per circuit), and the prior variant:
-beta_seed (per-neuron beta prior 10^U(-0.7, 1); None: the Model default), phi / phi_cov_diag (prior mean and covariance diagonal); sim: further
+beta_seed (per-neuron beta prior 10^U(-0.7, 1); None: the Model default), mu_prior (constant prior mean), phi / phi_cov_diag (prior mean and covariance diagonal); sim: further
 keyword arguments of the device generator (powers, connection_prob, ...).
 Test infrastructure only: nothing here is imported by the product."""
 import json
@@ -24,6 +24,8 @@ def priors_of(spec):
     pri = default_priors(N)
     if spec.get("beta_seed") is not None:
         pri["beta"] = 10.0 ** np.random.default_rng(spec["beta_seed"]).uniform(-0.7, 1.0, N)
+    if spec.get("mu_prior") is not None:
+        pri["mu"] = np.full(N, float(spec["mu_prior"]))
     if spec.get("phi") is not None:
         pri["phi"] = np.tile(np.asarray(spec["phi"], dtype=float), (N, 1))
     if spec.get("phi_cov_diag") is not None:

@@ -1166,6 +1166,28 @@ def test_long_rows_par_chain_equals_single_consumer(tmp_path):
     assert np.count_nonzero(ours["0_0_mu"]) > 0 and np.count_nonzero(ours["2_0_mu"]) > 0        # real fits: connections were found
 
 
+def test_chain_tables_from_iter_mid_equal_presweep_scan(tmp_path):
+    """Once every circuit of a set takes the in-LDS solve of k_iter_mid, block 0 of that kernel leaves the chain tables of the next sweep
+    (ordered compaction of the rows with mu != 0, record offsets, chunk table: update_lam's sweep order, caviar.py:196-229) and the pre-sweep
+    packs the records in a fourth role; iterations with a tiled solve keep the scan in the pre-sweep and k_seq_pack.  Same tables, same
+    records: whole trajectories bitwise those of CAVIAR_HIP_NO_FUSED_PACK=1 (child process) -- one circuit and batches, a non-zero prior mean
+    (every row a chain row: several scan rounds per workgroup, more rows than the packing role's grid), N not a multiple of the scan's four
+    rows per thread, explicit histories, rows of more than 64 trials."""
+    from child_fit import fit_specs, run_child
+    opts = dict(iters=14, seed=0, save_histories=True)
+    specs = [dict(N=300, K=1000, B=1, seed0=9600, batch=False, opts=opts),
+             dict(N=301, K=700, B=6, seed0=9610, batch=True, opts=opts),
+             dict(N=1000, K=2000, B=4, seed0=9620, batch=True, opts=dict(iters=12, seed=1)),
+             dict(N=1203, K=900, B=2, seed0=9630, batch=True, beta_seed=3, mu_prior=0.5, opts=dict(iters=8, seed=2)),
+             dict(N=200, K=3600, B=2, seed0=9640, batch=True, opts=dict(iters=10, seed=0), sim=dict(connection_prob=0.1))]
+    ours = fit_specs(specs)
+    theirs = run_child(specs, {"CAVIAR_HIP_NO_FUSED_PACK": "1"}, tmp_path)
+    assert sorted(ours) == sorted(theirs)
+    for k in ours:
+        np.testing.assert_array_equal(ours[k], theirs[k], err_msg=k)
+    assert np.count_nonzero(ours["0_0_mu"]) > 0 and np.count_nonzero(ours["2_0_mu"]) > 0
+
+
 def test_inverse_supertiles_bitwise_equal_one_tile(tmp_path):
     """The inverse of the Cholesky factor runs its recursive-doubling products (T = L21 X11, X21 = -X22 T; block_update_mu, caviar.py:170) on
     64 x 64 super-tiles from level b = 2 on.  Every 16 x 16 block accumulates the same products in the same order as in the one-tile kernels, so
