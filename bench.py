@@ -825,7 +825,7 @@ PMC_FAMILIES = {   # bench kernel / family -> (kernels whose traffic counts, the
     "k_chol_panel": (("k_chol_first", "k_chol_panel"), ("k_chol_panel",)),
     "k_chol_bulk+k_chol_trsm": (("k_chol_first", "k_chol_bulk", "k_chol_trsm"), ("k_chol_bulk<false, true>", "k_chol_bulk<true, true>")),   # one pair step per rank-64 pass
     "tiled solve (k_build_precision, k_chol_*, k_inv_*, column sums)": (
-        ("k_fill_prior", "k_build_precision", "k_chol_first", "k_chol_panel", "k_chol_bulk", "k_chol_trsm", "k_chol_diag", "k_chol_gpanel", "k_chol_wide", "k_inv_seed", "k_inv_T", "k_inv_X21",
+        ("k_fill_prior", "k_build_precision", "k_chol_first", "k_chol_panel", "k_chol_bulk", "k_chol_trsm", "k_chol_diag", "k_chol_gpanel", "k_chol_wide", "k_inv_seed", "k_inv_T", "k_inv_X21", "k_inv_T2", "k_inv_X212",
          "k_bp_prepare", "k_mu_beta_rows", "k_tri_matvec", "k_colsum_partial", "k_colsum_final"), ("k_mu_beta_rows", "k_tri_matvec")),   # (one k_mu_beta_rows -- round 3: k_tri_matvec -- per solve; k_build_precision runs in row bands)
 }
 
