@@ -314,7 +314,7 @@ static void carve_a(cm_problem* p, cm_carver& c) {           // sizes known from
 static void carve_b(cm_problem* p, cm_carver& c) {           // sizes that need nnz
   const size_t N = p->N, K = p->K, nnz = p->nnz > 0 ? (size_t)p->nnz : 1;
   c.take(&p->col, nnz); c.take(&p->grp, nnz); c.take(&p->csc_row, nnz); c.take(&p->csc_pos, nnz); c.take(&p->csc_grp, nnz);
-  c.take(&p->ye, nnz + 1); c.take(&p->me, nnz + 1); c.take(&p->slab, 2 * N + K + nnz);
+  c.take(&p->ye, nnz + 1); c.take(&p->me, nnz + 1); c.take(&p->turn8, nnz + 1); c.take(&p->slab, 2 * N + K + nnz);
   c.take(&p->chunk_first, (N + nnz) / 256 + 8);
   char* pk = nullptr; c.take(&pk, (N + nnz) * 32); if (c.base) p->packed = pk;
 }
@@ -652,7 +652,7 @@ void cm_fill_pdev(const cm_problem* p, const cm_problem* r, int* mailbox, cm_pde
   d->lam = p->lam; d->mu = p->mu; d->beta = p->beta; d->phi = p->phi; d->phi_cov = p->phi_cov; d->scal = p->scal; d->R = p->R; d->z = p->z;
   d->mcE = p->mcE; d->rs = p->rs; d->phi_rep = p->phi_rep; d->phi_dead = p->phi_dead; d->phi_cov_dead = p->phi_dead ? p->phi_dead + 2 * (size_t)p->N : nullptr; d->phi_c_dead = p->phi_dead ? p->phi_dead + 6 * (size_t)p->N : nullptr; d->pslab = p->pslab; d->mu_prior = p->mu_prior; d->beta_prior = p->beta_prior; d->phi_prior = p->phi_prior;
   d->phi_cov_prior = p->phi_cov_prior; d->act_idx = p->act_idx; d->act_inv = p->act_inv; d->n_act = p->n_act; d->alive = p->alive; d->tstamp = p->tstamp; d->tlist_s = p->tlist_s; d->tlist_r = p->tlist_r; d->tcnt = p->tcnt; d->seq_n = p->seq_n;
-  d->seq_off = p->seq_off; d->seq_pos = p->seq_pos; d->chunk_first = p->chunk_first; d->seq_meta = p->seq_meta; d->packed = p->packed;
+  d->turn8 = p->turn8; d->seq_off = p->seq_off; d->seq_pos = p->seq_pos; d->chunk_first = p->chunk_first; d->seq_meta = p->seq_meta; d->packed = p->packed;
   d->A = p->A; d->X = p->X; d->Lf = p->Lf; d->Dinv = p->Dinv; d->rhs = p->rhs; d->mailbox = mailbox;
   d->orders_all = r->orders_all; d->inv_all = r->inv_all; d->wtab = r->wtab; d->wstat = r->wstat; d->uexp = r->uexp; d->keys = r->keys;
 }

@@ -89,6 +89,70 @@ __device__ __forceinline__ void cm_col_dot16x2(int t, int K, const double* __res
   cm_col_dot16x2_k(k0, ok0, k1, ok1, t & 15, K, mu, lam, col_ptr, csc_row, csc_pos, orth, R, colany);
 }
 
+// The tickets of the multi-wave chain (k_sweep_par), one trial column per 16-lane segment half as in cm_col_dot16x2: an entry's ticket is the
+// number of EARLIER chain rows (mu != 0, by sweep position pos[]) that touch its trial.  While every row is a chain row (the first iterations)
+// k_seq_pack spent most of its time finding them entry by entry (the column walked once per entry: 2 x 10 dependent gathers each); here the
+// column is gathered once for all its entries, next to the column sum that gathers the same indices.  turn8[CSR slot] <- ticket (chain rows only).
+template <int N_>
+__device__ __forceinline__ int cm_row_ror(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x120 + N_, 0xf, 0xf, true); }   // lane i <- lane (i - N_) mod 16 of its row
+__device__ __forceinline__ int cm_rank16(int key) {     // number of lanes of the 16-lane row whose key is below this lane's (INT_MAX: not a chain row)
+  int r = 0;
+#define CM_RK(n) r += (cm_row_ror<n>(key) < key);
+  CM_RK(1) CM_RK(2) CM_RK(3) CM_RK(4) CM_RK(5) CM_RK(6) CM_RK(7) CM_RK(8) CM_RK(9) CM_RK(10) CM_RK(11) CM_RK(12) CM_RK(13) CM_RK(14) CM_RK(15)
+#undef CM_RK
+  return r;
+}
+// a column of more than 16 entries: every entry counts over the whole column (rare: more than 16 targets per trial)
+__device__ __forceinline__ void cm_col_rank_long(int k, int j, const double* __restrict__ mu, const int* __restrict__ pos, const int* __restrict__ col_ptr,
+                                                 const int* __restrict__ csc_row, const int* __restrict__ csc_pos, uint8_t* __restrict__ turn8) {
+  const int beg = col_ptr[k], end = col_ptr[k + 1];
+  for (int ce = beg + j; ce < end; ce += 16) {
+    const int r = csc_row[ce];
+    if (mu[r] == 0.0) continue;
+    const int mine = pos[r];
+    int t = 0;
+    for (int c2 = beg; c2 < end; ++c2) { const int r2 = csc_row[c2]; t += (mu[r2] != 0.0 && pos[r2] < mine); }
+    turn8[csc_pos[ce]] = (uint8_t)t;
+  }
+}
+__device__ __forceinline__ void cm_col_rank16x2(int t, int K, const double* __restrict__ mu, const int* __restrict__ pos, const int* __restrict__ col_ptr,
+                                                const int* __restrict__ csc_row, const int* __restrict__ csc_pos, uint8_t* __restrict__ turn8) {
+  const int Kh = (K + 1) >> 1;
+  const int k0 = t >> 4, k1 = k0 + Kh, j = t & 15;
+  const bool ok0 = k0 < Kh, ok1 = ok0 && k1 < K;
+  const int beg0 = ok0 ? col_ptr[k0] : 0, end0 = ok0 ? col_ptr[k0 + 1] : 0;
+  const int beg1 = ok1 ? col_ptr[k1] : 0, end1 = ok1 ? col_ptr[k1 + 1] : 0;
+  if (end0 - beg0 > 16 || end1 - beg1 > 16) {        // (uniform over the segment)
+    if (ok0) cm_col_rank_long(k0, j, mu, pos, col_ptr, csc_row, csc_pos, turn8);
+    if (ok1) cm_col_rank_long(k1, j, mu, pos, col_ptr, csc_row, csc_pos, turn8);
+    return;
+  }
+  const int ce0 = beg0 + j, ce1 = beg1 + j;
+  const bool in0 = ce0 < end0, in1 = ce1 < end1;
+  const int p0 = in0 ? csc_pos[ce0] : 0, r0 = in0 ? csc_row[ce0] : 0;
+  const int p1 = in1 ? csc_pos[ce1] : 0, r1 = in1 ? csc_row[ce1] : 0;
+  const bool c0 = in0 && mu[r0] != 0.0, c1 = in1 && mu[r1] != 0.0;
+  const int key0 = c0 ? pos[r0] : 0x7fffffff, key1 = c1 ? pos[r1] : 0x7fffffff;
+  const int t0 = cm_rank16(key0), t1 = cm_rank16(key1);
+  if (c0) turn8[p0] = (uint8_t)t0;
+  if (c1) turn8[p1] = (uint8_t)t1;
+}
+// (one circuit: a column per 16-lane segment, cm_col_dot16's layout)
+__device__ __forceinline__ void cm_col_rank16(int t, int K, const double* __restrict__ mu, const int* __restrict__ pos, const int* __restrict__ col_ptr,
+                                              const int* __restrict__ csc_row, const int* __restrict__ csc_pos, uint8_t* __restrict__ turn8) {
+  const int k = t >> 4, j = t & 15;
+  const bool ok = k < K;
+  const int beg = ok ? col_ptr[k] : 0, end = ok ? col_ptr[k + 1] : 0;
+  if (end - beg > 16) { cm_col_rank_long(k, j, mu, pos, col_ptr, csc_row, csc_pos, turn8); return; }
+  const int ce = beg + j;
+  const bool in = ce < end;
+  const int pp = in ? csc_pos[ce] : 0, r = in ? csc_row[ce] : 0;
+  const bool c = in && mu[r] != 0.0;
+  const int key = c ? pos[r] : 0x7fffffff;
+  const int tt = cm_rank16(key);
+  if (c) turn8[pp] = (uint8_t)tt;
+}
+
 // LISTED trials (cm_pdev::tstamp ...): the column sums of the trials on the list(s) -- every listed column exactly as cm_col_dot16 sums it -- in a
 // stride loop over 16-lane segments; `seg` = this segment's index among `nseg` (both uniform over the segment).  ls / ns: the list k_stats left,
 // lr / nr: the trials of the rows the pre-sweep revived (nr = 0: none).

@@ -151,6 +151,7 @@ struct cm_problem {
   // --- CAVIaR state ---
   uint8_t* mask = nullptr;    // [K] lam_mask
   double* ye = nullptr;       // [nnz] y[col[e]]: per-entry copy of the trial's response (y is constant during a run) -- the row kernels
+  uint8_t* turn8 = nullptr;   // [nnz] the entry's ticket in the multi-wave chain (earlier chain rows on its trial), left by the pre-sweep's column role while every row is a chain row
   uint8_t* me = nullptr;      // [nnz] mask[col[e]]                 read it contiguously instead of gathering 8 (1) bytes per 64-byte line
   int32_t* qcnt = nullptr;    // [N*8] per power: unmasked trials << 16 | trials (compact copy for the closed-form gate of all-zero rows)
   int32_t* mcnt = nullptr;    // [N*CM_MAX_VALS] unmasked trials of row n at each stimulus value (per run: the mask depends on y_xcorr_thresh)
@@ -231,6 +232,7 @@ struct cm_pdev {
   const uint8_t* csc_grp;
   uint8_t *mask, *colany;
   const double* ye; const uint8_t* me;      // per-entry copies of y and mask (refreshed by k_init_state / cm_launch_entry_copies)
+  uint8_t* turn8;                           // per-entry tickets of the multi-wave chain (cm_col_rank16x2)
   const int* mcnt; uint8_t* touch;          // unmasked trials per (row, value); rows the pre-sweep revived this iteration
   const int* qcnt;                          // [N*8] power q of row n: unmasked trials << 16 | trials (quiescent_gate; valid for <= 8 powers, rows < 65536 trials)
   double *lam, *mu, *beta, *phi, *phi_cov, *scal, *R, *z, *mcE, *rs;

@@ -491,9 +491,10 @@ __device__ __forceinline__ void seq_pack_body(const cm_pdev& p, const SweepArgs&
       SeqRec r;
       r.a = (uint32_t)k | ((uint32_t)g << 24) | ((uint32_t)(a.me[e] != 0) << 31);
       int turn = 0;
-      if (turns)     // (gathering four neurons at a time was measured slower than this plain loop: 28.3 vs 26.8 us at 128 circuits, 6.6 vs 5.4 us for one)
+      if (turns & 4) turn = p.turn8[e];                // (the pre-sweep's column role ranked the whole column: cm_col_rank16x2)
+      else if (turns)     // (gathering four neurons at a time was measured slower than this plain loop: 28.3 vs 26.8 us at 128 circuits, 6.6 vs 5.4 us for one)
         for (int ce = col_ptr[k]; ce < col_ptr[k + 1]; ++ce) { const int q = seq_pos[csc_row[ce]]; turn += (q >= 0 && q < j); }
-      if (turns == 2 && j == 1 && l == 0) turn = (turn + 1) & 0xFF;   // fault injection (CAVIAR_HIP_TEST_BAD_TICKET): a turn that never comes
+      if ((turns & 3) == 2 && j == 1 && l == 0) turn = (turn + 1) & 0xFF;   // fault injection (CAVIAR_HIP_TEST_BAD_TICKET): a turn that never comes
       r.b = e | (turn << 24);
       r.x = a.lam[e];
       r.y = a.mcE[(size_t)n * a.mld + g];
@@ -566,6 +567,11 @@ __global__ __launch_bounds__(1024, (BATCH && LEAN) ? 8 : 4) void k_presweep(cm_p
     }
     if (BATCH) cm_col_dot16x2((b - nbI) * 1024 + threadIdx.x, p.K, a.mu, a.lam, p.col_ptr, p.csc_row, p.csc_pos, 0.0, p.R, nullptr);
     else cm_col_dot16((b - nbI) * 1024 + threadIdx.x, p.K, a.mu, a.lam, p.col_ptr, p.csc_row, p.csc_pos, 0.0, p.R, nullptr);
+    if (turns & 4) {       // ... and the chain's tickets, column by column (k_seq_pack reads them: turns & 4 there too)
+      const int* __restrict__ pos = p.inv_all + (size_t)it * N;
+      if (BATCH) cm_col_rank16x2((b - nbI) * 1024 + threadIdx.x, p.K, a.mu, pos, p.col_ptr, p.csc_row, p.csc_pos, p.turn8);
+      else cm_col_rank16((b - nbI) * 1024 + threadIdx.x, p.K, a.mu, pos, p.col_ptr, p.csc_row, p.csc_pos, p.turn8);
+    }
   } else if (b == nbI + nbC) {
     if (!(roles & 4)) return;
     if (BATCH && threadIdx.x == 0) p.alive[0] = 0;     // list of rows with lam != 0 that k_stats rebuilds after the sweep
@@ -1017,15 +1023,19 @@ int cm_launch_sweep(cm_ctx* ctx, cm_set& s, int it, const cm_options* o, hipEven
   // fused_pack: the k_iter_mid before this sweep left the chain's tables (every circuit took its in-LDS solve: chains of at most small_cap rows) --
   // the records are packed by a few more blocks of the pre-sweep (16 rows each) instead of a launch of their own
   const bool fused = fused_pack && !split && !no_fused_pack && table_it < 0;
+  // the tickets from the pre-sweep's column role (one gather of a column for all its entries) when that role walks every column and the chain is long:
+  // the iterations with a tiled solve
+  static const bool no_col_rank = getenv("CAVIAR_HIP_NO_COLUMN_RANKS") != nullptr;   // diagnostic: k_seq_pack finds every ticket itself
+  const int turns_p = (turns && !fused && list_it < 0 && !split && !no_col_rank && table_it < 0) ? (turns | 4) : turns;
   const int nbP = fused ? (std::min(N, std::max(1, s.na_max)) + 15) / 16 : 0;       // (a wavefront per chain row of the largest active set; the stride takes what a non-zero prior mean adds)
   for (int pass = 0; pass < (split ? 3 : 1); ++pass) {
-    if (lean) CM_LAUNCH_SET_T(k_presweep, (true), s, nbIq + nbCk + 1 + nbP, 1024, 0, st, (table_it < 0 ? it : table_it), gated, msrmp, min_count, nbIq, nbCk, split ? (1 << pass) : 7, gran, quiescent, nbL, list_it, pack_max, fused ? 1 : 0, turns);
-    else CM_LAUNCH_SET_T(k_presweep, (false), s, nbIq + nbCk + 1 + nbP, 1024, 0, st, (table_it < 0 ? it : table_it), gated, msrmp, min_count, nbIq, nbCk, split ? (1 << pass) : 7, gran, quiescent, nbL, list_it, pack_max, fused ? 1 : 0, turns);
+    if (lean) CM_LAUNCH_SET_T(k_presweep, (true), s, nbIq + nbCk + 1 + nbP, 1024, 0, st, (table_it < 0 ? it : table_it), gated, msrmp, min_count, nbIq, nbCk, split ? (1 << pass) : 7, gran, quiescent, nbL, list_it, pack_max, fused ? 1 : 0, turns_p);
+    else CM_LAUNCH_SET_T(k_presweep, (false), s, nbIq + nbCk + 1 + nbP, 1024, 0, st, (table_it < 0 ? it : table_it), gated, msrmp, min_count, nbIq, nbCk, split ? (1 << pass) : 7, gran, quiescent, nbL, list_it, pack_max, fused ? 1 : 0, turns_p);
   }
   s.tlist_sweep_it = list_it;
   if (!fused) {
     const int pack_rows = s.B > 1 ? std::min(N, std::max(64, 2 * s.na_max)) : N;      // (one circuit: the N / 4 workgroups are not what its 5 us are made of)
-    CM_LAUNCH_SET(k_seq_pack, s, (pack_rows + 3) / 4, 256, 0, st, gated, msrmp, min_count, turns, pack_max);
+    CM_LAUNCH_SET(k_seq_pack, s, (pack_rows + 3) / 4, 256, 0, st, gated, msrmp, min_count, turns_p, pack_max);
   }
   if (mid) CM_HIP(hipEventRecord(mid, st));
   const size_t lds = (size_t)p->K * sizeof(double);

@@ -1186,6 +1186,11 @@ def test_chain_tables_from_iter_mid_equal_presweep_scan(tmp_path):
     for k in ours:
         np.testing.assert_array_equal(ours[k], theirs[k], err_msg=k)
     assert np.count_nonzero(ours["0_0_mu"]) > 0 and np.count_nonzero(ours["2_0_mu"]) > 0
+    # the tickets of the multi-wave chain: ranked column by column in the pre-sweep while the chain is long (cm_col_rank16x2), entry by entry in
+    # k_seq_pack otherwise (CAVIAR_HIP_NO_COLUMN_RANKS: always) -- a wrong ticket would reorder the updates of a trial's residual or stall the chain
+    plain = run_child(specs, {"CAVIAR_HIP_NO_COLUMN_RANKS": "1", "CAVIAR_HIP_NO_FUSED_PACK": "1"}, tmp_path)
+    for k in ours:
+        np.testing.assert_array_equal(ours[k], plain[k], err_msg=k)
 
 
 def test_inverse_supertiles_bitwise_equal_one_tile(tmp_path):
