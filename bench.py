@@ -372,7 +372,7 @@ def end_to_end(_lib, ctx, local_rank, wl, pri, a, B):
     res["host_arrays"] = {"ms": hbest, "value": B * a.iters / hbest * 1e3, "unit": "iterations/s", "upload_bytes": int(B * (K * T + N * K) * 8),
                           "same_mu_as_device_resident": bool(np.array_equal(bufs[0]["mu"], mu0)),
                           "note": "cm_caviar_fit_batch: upload of psc + stim (pageable host memory staged through pinned slots by four copy threads, PCIe-bound), "
-                                  "create, one lock-step batch, fetch (no dense lam), destroy; the context and its memory pool are kept between calls; best of 2"}
+                                  "create, fit, fetch (no dense lam), destroy -- as two halves, the second uploaded under the first's fit; the context and its memory pool are kept between calls; best of 2"}
     # (c) the same circuits as COMPACT host inputs (cm_caviar_fit_batch_ex): psc as float32, the stimulus matrix as its non-zero (trial, neuron, power)
     # entries -- built here, outside the clock, from float32-rounded traces (a caller that records in float32 holds them like this; the dense float64
     # call on the same rounded values is fitted once for the bitwise comparison)

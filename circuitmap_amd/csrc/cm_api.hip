@@ -862,6 +862,18 @@ extern "C" int cm_caviar_run(cm_ctx* ctx, cm_problem* p, const cm_priors* pr, co
   return run_guarded(ctx, s, pr, o, tm);
 }
 
+// the second context of a user-visible one (same device: its own stream, side stream, mailboxes, events; the parent's pool) and the thread that drives it
+static int ensure_twin(cm_ctx* ctx) {
+  if (!ctx->twin) {
+    CM_TRY(cm_ctx_create(ctx->device, nullptr, &ctx->twin));
+    ctx->twin->solve_group = ctx->solve_group; ctx->twin->xcd_mode = ctx->xcd_mode; ctx->twin->chol_family = ctx->chol_family;
+    ctx->twin->use_mailbox = ctx->use_mailbox;
+    ctx->twin->root = ctx;                                         // one pool per user-visible context
+  }
+  if (!ctx->helper) ctx->helper = new cm_helper();
+  return CM_OK;
+}
+
 // Lock-step batch (include/caviar_hip.h): circuits with the same launch configuration form a group and share every launch (the
 // circuit is the outer grid dimension); groups run one after the other.
 extern "C" int cm_caviar_run_batch(cm_ctx* ctx, int32_t n, cm_problem* const* problems, const cm_priors* priors, const cm_options* o,
@@ -907,13 +919,7 @@ extern "C" int cm_caviar_run_batch(cm_ctx* ctx, int32_t n, cm_problem* const* pr
     for (job& j : jobs)
       if ((rc = run_guarded(ctx, j.s, j.prs.data(), o, timings ? j.tms.data() : nullptr)) != CM_OK) return rc;
   } else {
-    if (!ctx->twin) {
-      CM_TRY(cm_ctx_create(ctx->device, nullptr, &ctx->twin));
-      ctx->twin->solve_group = ctx->solve_group; ctx->twin->xcd_mode = ctx->xcd_mode; ctx->twin->chol_family = ctx->chol_family;
-      ctx->twin->use_mailbox = ctx->use_mailbox;
-      ctx->twin->root = ctx;                                         // one pool per user-visible context
-    }
-    if (!ctx->helper) ctx->helper = new cm_helper();
+    CM_TRY(ensure_twin(ctx));
     cm_ctx* tw = ctx->twin;
     CM_HIP(hipEventRecord(ctx->ev[9], ctx->stream));                 // whatever the caller queued on the context's stream comes first on both
     CM_HIP(hipStreamWaitEvent(tw->stream, ctx->ev[9], 0));
@@ -1471,25 +1477,63 @@ static int fit_batch_impl(int32_t n, const int32_t* N, const int32_t* K, const i
       prs.push_back(priors[c]);
       res_[i] = results[c];
     }
-    if (!mine.empty()) rc = cm_problem_create_batch_ex(ctx, (int)mine.size(), n_.data(), k_.data(), t_.data(), in_.data(), CM_MEM_HOST, ps.data());
-    if (rc) ps.clear();
-    stamp();
     std::vector<cm_timings> tms(mine.size());
-    if (!rc && !ps.empty()) rc = cm_caviar_run_batch(ctx, (int)ps.size(), ps.data(), prs.data(), o, timings ? tms.data() : nullptr);
-    stamp();
-    if (!rc && !ps.empty()) rc = cm_caviar_fetch_batch(ctx, (int)ps.size(), ps.data(), res_.data());
-    stamp();
+    // From 2 x 64 circuits on, the call is a two-stage pipeline: the first half is created (upload + encoding) on the context and fitted by the
+    // context's helper thread while this thread creates the second half on the twin context -- its bytes cross PCIe under the first half's fit --
+    // and fits it there: the two halves are the two lock-step batches cm_caviar_run_batch would have in flight anyway (cm_options.interleave).
+    static const bool no_pipe = getenv("CAVIAR_HIP_FIT_BATCH_NO_PIPELINE") != nullptr;
+    const bool pipe = !no_pipe && mine.size() >= 2 * (size_t)CM_CREATE_CHUNK && o->verbose == 0;
+    if (!pipe) {
+      rc = cm_problem_create_batch_ex(ctx, (int)mine.size(), n_.data(), k_.data(), t_.data(), in_.data(), CM_MEM_HOST, ps.data());
+      stamp();
+      if (!rc) rc = cm_caviar_run_batch(ctx, (int)ps.size(), ps.data(), prs.data(), o, timings ? tms.data() : nullptr);
+      stamp();
+      if (!rc) rc = cm_caviar_fetch_batch(ctx, (int)ps.size(), ps.data(), res_.data());
+      stamp();
+    } else {
+      const int nA = (int)(((mine.size() / 2 + CM_CREATE_CHUNK - 1) / CM_CREATE_CHUNK) * CM_CREATE_CHUNK), nB = (int)mine.size() - nA;
+      cm_options oh = *o;
+      oh.interleave = 1;                                               // each half is one lock-step batch on its context's stream
+      std::string msgA;
+      int rcA = CM_OK, rcB = CM_OK;
+      bool started = false;
+      rc = ensure_twin(ctx);
+      if (!rc) rc = cm_problem_create_batch_ex(ctx, nA, n_.data(), k_.data(), t_.data(), in_.data(), CM_MEM_HOST, ps.data());
+      stamp();
+      if (!rc) {
+        cm_ctx* c0 = ctx;
+        ctx->helper->start([&, c0] {
+          if (hipSetDevice(c0->device) != hipSuccess) { rcA = CM_ERR_HIP; msgA = "hipSetDevice failed in the helper thread"; return; }
+          rcA = cm_caviar_run_batch(c0, nA, ps.data(), prs.data(), &oh, timings ? tms.data() : nullptr);
+          if (!rcA) rcA = cm_caviar_fetch_batch(c0, nA, ps.data(), res_.data());
+          if (rcA) msgA = cm_last_error();
+        });
+        started = true;
+        rcB = cm_problem_create_batch_ex(ctx->twin, nB, n_.data() + nA, k_.data() + nA, t_.data() + nA, in_.data() + nA, CM_MEM_HOST, ps.data() + nA);
+        stamp();
+        if (!rcB) rcB = cm_caviar_run_batch(ctx->twin, nB, ps.data() + nA, prs.data() + nA, &oh, timings ? tms.data() + nA : nullptr);
+        if (!rcB) rcB = cm_caviar_fetch_batch(ctx->twin, nB, ps.data() + nA, res_.data() + nA);
+      }
+      if (started) ctx->helper->wait();
+      stamp();
+      if (!rc && rcA) { rc = rcA; cm_set_error("%s", msgA.c_str()); }
+      else if (!rc && rcB) rc = rcB;                                   // (this thread's last error is the second half's)
+      stamp();
+    }
     for (size_t i = 0; !rc && i < mine.size(); ++i) {
       results[mine[i]].shape = res_[i].shape; results[mine[i]].rate = res_[i].rate;
       if (timings) timings[mine[i]] = tms[i];
     }
     if (rc) fail(rc);
-    for (cm_problem* q : ps) cm_problem_destroy(q);
+    for (cm_problem* q : ps) if (q) cm_problem_destroy(q);
     stamp();
     if (rc) cm_ctx_destroy(ctx); else fb_give(device_ids[d], ctx);
     stamp();
-    if (show) fprintf(stderr, "cm_caviar_fit_batch device %d: context %.1f ms, create (upload + encoding) %.1f, fit %.1f, fetch %.1f, destroy %.1f, context kept / destroyed %.1f\n",
-                      device_ids[d], tq[1] - tq[0], tq[2] - tq[1], tq[3] - tq[2], tq[4] - tq[3], tq[5] - tq[4], tq[6] - tq[5]);
+    if (show && !pipe) fprintf(stderr, "cm_caviar_fit_batch device %d: context %.1f ms, create (upload + encoding) %.1f, fit %.1f, fetch %.1f, destroy %.1f, context kept / destroyed %.1f\n",
+                               device_ids[d], tq[1] - tq[0], tq[2] - tq[1], tq[3] - tq[2], tq[4] - tq[3], tq[5] - tq[4], tq[6] - tq[5]);
+    if (show && pipe) fprintf(stderr, "cm_caviar_fit_batch device %d (two halves): context %.1f ms, create of the first half %.1f, of the second (under the first's fit) %.1f, "
+                                      "until both are fitted and fetched %.1f, destroy %.1f, context kept / destroyed %.1f\n",
+                              device_ids[d], tq[1] - tq[0], tq[2] - tq[1], tq[3] - tq[2], tq[4] - tq[3], tq[6] - tq[5], tq[7] - tq[6]);
   };
   if (n_devices == 1) work(0);
   else {

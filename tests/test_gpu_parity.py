@@ -851,6 +851,26 @@ def test_staged_upload_builds_the_same_circuits(ctx):
         mus.append(mu)
     for c in range(n):
         np.testing.assert_array_equal(mus[0][c], mus[1][c])
+    # from 2 x 64 circuits on the call is a two-stage pipeline (first half fitted by the helper thread on the context while the second is uploaded and
+    # then fitted on the twin context): 130 circuits -> halves of 128 and 2; every mu bitwise that of the same circuit in an ordinary batch
+    n = 130
+    big = [circuits[i % 69] for i in range(n)]
+    probs = Problem.create_batch(ctx, big)
+    run_batch(probs, [default_priors(40)] * n, **opts)
+    want = [q.fetch()[0] for q in probs]
+    for q in probs:
+        q.close()
+    prs = (_lib.CmPriors * n)(*[_priors_struct(40, *prior_args(default_priors(40)), keep) for _ in range(n)])
+    res = (_lib.CmResult * n)()
+    mu = [np.empty(40) for _ in range(n)]
+    zz = [np.empty(100) for _ in range(n)]
+    for c in range(n):
+        res[c].mu = _lib.dptr(mu[c]); res[c].z = _lib.dptr(zz[c])
+    _lib.check(lib.cm_caviar_fit_batch(n, i32([40] * n), i32([100] * n), i32([900] * n), dpp([c[0] for c in big]), dpp([c[1] for c in big]),
+                                       prs, C.byref(o), None, 0, res, None))
+    for c in range(n):
+        np.testing.assert_array_equal(mu[c], want[c], err_msg="pipelined fit_batch, circuit %d" % c)
+    assert all(res[c].shape == res[0].shape for c in range(n))
     assert lib.cm_caviar_fit_batch_release() == 0
     assert lib.cm_caviar_fit_batch_release() == 0                   # nothing kept: still fine
 
