@@ -538,7 +538,14 @@ extern "C" int cm_problem_create_batch_ex(cm_ctx* ctx, int32_t n, const int32_t*
   CM_HIP(hipSetDevice(ctx->device));
   auto undo = [&](int c0) { for (int c = 0; c < c0; ++c) { cm_problem_destroy(out[c]); out[c] = nullptr; } };
   static const bool plain_upload = getenv("CAVIAR_HIP_PLAIN_UPLOAD") != nullptr;      // diagnostic: hipMemcpyAsync straight from the caller's pages
-  if (mem_kind != CM_MEM_HOST || plain_upload) {
+  size_t host_bytes = 0;                                                              // (a few MB are not worth four threads: one small circuit)
+  if (mem_kind == CM_MEM_HOST)
+    for (int c = 0; c < n; ++c) {
+      const size_t n_stim = (size_t)N[c] * K[c];
+      host_bytes += (size_t)K[c] * T[c] * (in[c].psc_dtype == CM_DTYPE_F64 ? 8 : 4) +
+                    (in[c].stim_layout == CM_STIM_DENSE_F64 ? n_stim * 8 : in[c].stim_layout == CM_STIM_DENSE_F32 ? n_stim * 4 : (size_t)in[c].n_triples * sizeof(cm_stim_triple));
+    }
+  if (mem_kind != CM_MEM_HOST || plain_upload || host_bytes < 2 * CM_UPLOAD_SLOT) {
     for (int c0 = 0; c0 < n; c0 += CM_CREATE_CHUNK) {
       const int m = std::min(CM_CREATE_CHUNK, n - c0);
       const int rc = create_chunk(ctx, m, N + c0, K + c0, T + c0, in + c0, mem_kind, out + c0);
