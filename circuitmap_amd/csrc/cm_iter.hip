@@ -249,8 +249,14 @@ __global__ __launch_bounds__(256) void k_mc_dead(cm_parg<BATCH> pa, IterDyn a, i
 // LISTED (batches, steady state): the per-neuron role walks the list of rows with lam != 0 in a stride loop -- its own instantiation,
 // because the loop costs the role ~100 registers (232 against 126: two wavefronts per SIMD instead of three), which the early
 // iterations, where every row is alive and the role is one wavefront per row, must not pay.
+#ifndef CM_ITER_MINW_PLAIN
+#define CM_ITER_MINW_PLAIN 4       // wavefronts per SIMD the batch instantiations are compiled for (their VGPR budget: 512 / n)
+#endif
+#ifndef CM_ITER_MINW_LISTED
+#define CM_ITER_MINW_LISTED 4
+#endif
 template <bool BATCH, int SEG, bool FULLMC, bool LISTED = false>
-__global__ __launch_bounds__(CM_ITER_THREADS, (BATCH && !FULLMC) ? 4 : 1) void k_iter_mid(cm_parg<BATCH> pa, IterDyn a) {
+__global__ __launch_bounds__(CM_ITER_THREADS, (BATCH && !FULLMC) ? (LISTED ? CM_ITER_MINW_LISTED : CM_ITER_MINW_PLAIN) : 1) void k_iter_mid(cm_parg<BATCH> pa, IterDyn a) {
   extern __shared__ double sm[];
   const cm_pdev& p = pa.get();
   if (blockIdx.x <= 1) {
