@@ -6,7 +6,7 @@
 `--workload nwd` benchmarks the upstream NWD demixer forward pass instead (its own metric, traces/s; see bench_nwd).
 
 A "step" is one pass of the hot path over one batch of synthetic input: B independent circuits of the BASELINE shape (N=1000
-neurons, K=2000 trials, T=900 samples; default B = 256) fitted per GPU as ONE lock-step batch -- `iters` (50) CAVIaR iterations each plus
+neurons, K=2000 trials, T=900 samples; default B = 512) fitted per GPU as ONE lock-step batch -- `iters` (50) CAVIaR iterations each plus
 the false-negative scan and final phi update (reference circuitmap/optimise/caviar.py:79-98) -- through the C ABI's
 cm_caviar_run_batch: the circuit is the outer grid dimension of every kernel launch.  (The library's own default for a batch, cm_options.interleave = 0,
 runs it as two halves in flight on two streams, so that the serial phases of one overlap the wide phases of the other: ~5 % more
@@ -411,7 +411,8 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--circuits-per-gpu", type=int, default=None, help="B: every step fits B independent circuits per GPU as ONE lock-step batch "
                     "(cm_caviar_run_batch: the circuit is the outer grid dimension of every launch); value counts all of their iterations.  "
-                    "Default 256 (1 for cfg5: one N=5000 circuit already fills the GPU); 1 = one circuit at a time (the latency form)")
+                    "Default 512 for cfg3 (a step costs about 5 ms + 0.137 ms per circuit: 283 / 322 / 339 / 350 k it/s at 128 / 256 / 512 / 1024), 256 for cfg2 and demo, 1 for cfg5 "
+                    "(one N=5000 circuit already fills the GPU); 1 = one circuit at a time (the latency form)")
     ap.add_argument("--interleave", action="store_true", help="timed region with the library's default scheduling of a batch (cm_options.interleave = 0: two "
                     "half-batches at a time on two streams, ~5 %% more throughput) instead of one lock-step batch per step; per-kernel durations -- and "
                     "with them `roofline` -- are then those of kernels that share the GPU with the other half's")
@@ -479,7 +480,7 @@ def main():
     wl = WORKLOADS[a.workload]
     N, K, T, H = wl["N"], wl["K"], wl["T"], wl["H"]
     if a.circuits_per_gpu is None:
-        a.circuits_per_gpu = 1 if a.workload == "cfg5" else 256
+        a.circuits_per_gpu = 1 if a.workload == "cfg5" else (512 if a.workload == "cfg3" else 256)
     B = max(1, a.circuits_per_gpu)
     if a.streams_leg is None:
         a.streams_leg = 2 if (B >= 32 and a.batch_streams == 1 and not a.interleave) else 0
@@ -763,7 +764,7 @@ def main():
                                                "bitwise over mu, beta, lam, shape, rate, phi, phi_cov, z")
             del batch_res0, single_res0
         if world == 1 and B > 1 and not a.no_end_to_end and a.workload != "cfg5":
-            out["end_to_end"] = end_to_end(_lib, ctx, local_rank, wl, pri, a, B)
+            out["end_to_end"] = end_to_end(_lib, ctx, local_rank, wl, pri, a, min(B, 256))     # (256 circuits whatever the step's batch: 7.8 GB of dense host arrays)
         if world == 1 and B > 1 and a.streams_leg and G == 1:
             # the same B circuits with the library's default scheduling (cm_options.interleave = 0): two half-batches at a time, the second on the
             # context's twin stream from the library's helper thread

@@ -673,8 +673,8 @@ def _device_circuits(cx, N, K, B, seed0, T=900, host_copy_of=()):
     return probs, host
 
 
-@pytest.mark.parametrize("N,K,B,iters", [(200, 400, 16, 14), (200, 400, 33, 14), (200, 400, 128, 14), (1000, 2000, 16, 50), (1000, 2000, 256, 50),
-                                         (200, 3600, 16, 14), (5000, 10000, 8, 3)])
+@pytest.mark.parametrize("N,K,B,iters", [(200, 400, 16, 14), (200, 400, 33, 14), (200, 400, 128, 14), (200, 400, 520, 14), (1000, 2000, 16, 50), (1000, 2000, 256, 50),
+                                         (1000, 2000, 512, 50), (200, 3600, 16, 14), (5000, 10000, 8, 3)])
 def test_run_batch_many_per_xcd(ctx, N, K, B, iters):
     """cm_caviar_run_batch with 2 and 16 circuits per XCD (cm_xcd_remap mode 3 with per > 1, which needs gridDim.y % 8 == 0): every
     circuit bit-identical to its own cm_caviar_run; circuit 0 within 1e-6 of the running-residual oracle (the small shape; the
@@ -683,8 +683,8 @@ def test_run_batch_many_per_xcd(ctx, N, K, B, iters):
     three 64-entry record segments in the multi-wave chain kernel); N = 5000 / K = 10000 is BASELINE configs[4] as a batch (bench.py --workload cfg5
     --circuits-per-gpu 16 / 64): 157-tile-row matrices through the grouped Cholesky family against the single fits' pair family, the false-negative
     scan on the global arrays (eight circuits) against the single fits' host scan;
-    (1000, 2000, 256) is bench.py's default step: timed as one lock-step batch, and as the two interleaved half-batches that are the
-    library's default scheduling (cm_options.interleave) -- both forms are checked."""
+    (1000, 2000, 512) is bench.py's default step ((1000, 2000, 256) was, until round 4): timed as one lock-step batch, and as the two interleaved
+    half-batches that are the library's default scheduling (cm_options.interleave) -- both forms are checked; B = 520 is 65 circuits per XCD."""
     from circuitmap_amd.optimise.caviar import run_batch
     from oracle import caviar_oracle as co
     pri = default_priors(N)

@@ -5,6 +5,7 @@ out=${1:-gpurun_out/lines}; tag=${2:-rNN}
 mkdir -p "$out"
 run() { name=$1; shift; timeout -k 10 500 python bench.py "$@" > "$out/${tag}_$name.json" 2> "$out/${tag}_$name.err" || { echo "$name failed"; tail -3 "$out/${tag}_$name.err"; return 1; }; python tools/bench_summary.py "$out/${tag}_$name.json"; }
 run default_bench_with_cpu_baseline &&
+run bench_cfg3_B256 --circuits-per-gpu 256 --no-cpu-baseline &&
 run bench_cfg3_B1 --circuits-per-gpu 1 --no-cpu-baseline &&
 run bench_cfg2_B1 --workload cfg2 --circuits-per-gpu 1 --no-cpu-baseline &&
 run bench_cfg2_B256 --workload cfg2 --no-cpu-baseline &&

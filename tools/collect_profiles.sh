@@ -10,11 +10,12 @@ R=$(pwd)
 mkdir -p "$R/$out"
 export TMPDIR=/tmp
 cd /tmp
-A_ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-single-leg --streams-leg 0 --no-end-to-end"
+A_ARGS="--circuits-per-gpu 256 --steps 3 --warmup 1 --no-cpu-baseline --no-single-leg --streams-leg 0 --no-end-to-end"     # cfg3, 256 circuits per step (the default until round 4: the per-kernel analysis of DESIGN section 5 is on this leg)
+E_ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-single-leg --streams-leg 0 --no-end-to-end"                              # the default bench workload: cfg3, 512 circuits per step
 B_ARGS="--circuits-per-gpu 1 --batch-leg 0 --steps 3 --warmup 1 --no-cpu-baseline"
 C_ARGS="--workload cfg5 --circuits-per-gpu 32 --steps 2 --warmup 1 --no-cpu-baseline --no-single-leg --streams-leg 0"     # BASELINE configs[4] as a lock-step batch (round 3: one circuit per step)
 D_ARGS="--workload demo --steps 3 --warmup 1 --no-cpu-baseline --no-single-leg --streams-leg 0 --no-end-to-end"            # the reference's published workload (N = 200, K = 3600)
-legs=${3:-a b c d}
+legs=${3:-e a b c d}
 pass() {   # name, leg args, rocprof args...
   name=$1; legargs=$2; shift 2
   rm -rf /tmp/prof_$name
@@ -22,7 +23,7 @@ pass() {   # name, leg args, rocprof args...
   echo "pass $name done"
 }
 for leg in $legs; do
-  case $leg in a) args="$A_ARGS";; b) args="$B_ARGS";; c) args="$C_ARGS";; d) args="$D_ARGS";; *) echo "unknown leg $leg"; exit 1;; esac
+  case $leg in a) args="$A_ARGS";; b) args="$B_ARGS";; c) args="$C_ARGS";; d) args="$D_ARGS";; e) args="$E_ARGS";; *) echo "unknown leg $leg"; exit 1;; esac
   pass ${leg}_trace "$args" --stats && python3 "$R/tools/rocpd_stats.py" /tmp/prof_${leg}_trace/p_results.db > "$R/$out/${tag}_${leg}_kernel_stats.csv" || exit 1
   pass ${leg}_fetch "$args" --pmc FETCH_SIZE && python3 "$R/tools/rocpd_pmc.py" /tmp/prof_${leg}_fetch/p_results.db > "$R/$out/${tag}_${leg}_pmc_fetch_size.csv" || exit 1
   pass ${leg}_write "$args" --pmc WRITE_SIZE && python3 "$R/tools/rocpd_pmc.py" /tmp/prof_${leg}_write/p_results.db > "$R/$out/${tag}_${leg}_pmc_write_size.csv" || exit 1
