@@ -54,7 +54,9 @@ __device__ __forceinline__ void stats_row(const cm_pdev& p, const double* __rest
 // others (a few dozen per circuit in the steady state) are re-read, one wavefront each.
 // rows screened per workgroup in the quiescent regime: few enough that each of the four wavefronts re-reads (and lists the trials of) about one row --
 // with 256 rows per workgroup a wavefront walked three or four rows one after the other, five dependent round trips each
+#ifndef CM_STATS_QROWS
 #define CM_STATS_QROWS 64
+#endif
 template <bool BATCH>
 __global__ __launch_bounds__(256) void k_stats(cm_parg<BATCH> pa, int nbR, double orth, int quiescent, int nbL, int list_it, int mark_it) {
   const cm_pdev& p = pa.get();
