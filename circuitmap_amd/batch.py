@@ -52,7 +52,7 @@ def packed_length(N, K):
     return 8 * N + 2 + K
 
 
-def _fit_lockstep(circuits, mine, priors, fit_options, device_id, max_group, streams=1):
+def _fit_lockstep(circuits, mine, priors, fit_options, device_id, max_group, streams=1, compact=False):
     """This rank's circuits as lock-step batches on its GPU (cm_caviar_run_batch): the circuit is the outer grid dimension of every
     launch.  `streams` > 1: that many batches at a time, each on its own context (stream + mailboxes) from its own host thread --
     the latency-bound phases of one batch (its Gauss-Seidel chains, its Cholesky panels) then overlap the wide phases of the
@@ -83,7 +83,7 @@ def _fit_lockstep(circuits, mine, priors, fit_options, device_id, max_group, str
     def make_problems(ctx, idx):
         cs = [circuits[ci] for ci in idx]
         if len(cs[0]) == 2:
-            return Problem.create_batch(ctx, cs)                     # host arrays (psc, stim): one encoding pass for the group
+            return Problem.create_batch(ctx, cs, compact=compact)    # host arrays (psc, stim): one encoding pass for the group (compact: float32 traces + stimulus triples over PCIe)
         # ("device", float64 CUDA tensor [K*T + N*K], N, K, T): scattered circuits, never on this host
         return Problem.create_batch(ctx, [("device", N, K, T, t.data_ptr(), t.data_ptr() + K * T * 8) for _, t, N, K, T in cs])
 
@@ -159,7 +159,7 @@ def _scatter_circuits(circuits, n_total, shape, rank, world, device, group):
     return local
 
 
-def fit_batch(circuits, priors=None, fit_options=None, fit_fn=None, device=None, group=None, circuits_per_launch=256, streams=1, scatter=False):
+def fit_batch(circuits, priors=None, fit_options=None, fit_fn=None, device=None, group=None, circuits_per_launch=256, streams=1, scatter=False, compact=False):
     """Fit a list of circuits [(psc K x T, stim N x K), ...] across the ranks of the default process group.
 
     Rank 0's `priors` / `fit_options` are broadcast to every rank.  Returns, on rank 0, a list of result dicts
@@ -178,7 +178,8 @@ def fit_batch(circuits, priors=None, fit_options=None, fit_fn=None, device=None,
     of one overlapping the wide phases of the other; `streams` > 1 adds that many contexts with a host thread each on top, which has not
     paid since the chains, the false-negative scan and the tiled solve were shortened (round 3).  A single fit is a latency chain that
     occupies a few percent of an MI355X; a batch of 256 delivers ~20x its iteration rate.  Every result is bit-identical to the circuit's
-    own fit.
+    own fit.  `compact=True` (host circuits): the traces cross PCIe as float32 and the stimulus matrix as its non-zero entries
+    (cm_problem_create_batch_ex: a quarter of the bytes; bitwise the same circuits when the values are float32-representable).
     """
     import torch
     import torch.distributed as dist
@@ -219,7 +220,7 @@ def fit_batch(circuits, priors=None, fit_options=None, fit_fn=None, device=None,
     n_slots = (n_total + world - 1) // world                       # equal-size gather payloads
     local = torch.zeros((n_slots, L), dtype=torch.float64)
     if fit_fn is None:
-        for slot, res in enumerate(_fit_lockstep(circuits, mine, priors, fit_options, device_id, max(1, int(circuits_per_launch)), streams)):
+        for slot, res in enumerate(_fit_lockstep(circuits, mine, priors, fit_options, device_id, max(1, int(circuits_per_launch)), streams, compact=bool(compact) and not scatter)):
             local[slot] = torch.from_numpy(_pack(res, N, K))
     else:
         for slot, ci in enumerate(mine):

@@ -552,6 +552,13 @@ def test_fit_batch_baseline_config3():
             if nm != "lam":
                 np.testing.assert_array_equal(np.asarray(res[i], dtype=float), np.asarray(g[nm], dtype=float), err_msg=nm)
         assert np.count_nonzero(res[0]) > 10                              # a real fit: connections were found
+    # compact=True: float32 traces + stimulus triples over PCIe -- bitwise the dense float64 path on float32-representable traces
+    c32 = [(np.asarray(psc, dtype=np.float32).astype(np.float64), stim) for psc, stim in circuits[:2]]
+    dense = batch.fit_batch(c32, priors=pri, fit_options=opts)
+    comp = batch.fit_batch(c32, priors=pri, fit_options=opts, compact=True)
+    for d_, c_ in zip(dense, comp):
+        for nm in ("mu", "beta", "phi", "phi_cov", "z", "shape", "rate"):
+            np.testing.assert_array_equal(np.asarray(d_[nm], dtype=float), np.asarray(c_[nm], dtype=float), err_msg="compact " + nm)
 
 
 def test_fit_batch_c_entry_point(ctx):
