@@ -102,7 +102,7 @@ struct cm_ctx {
   int num_cus = 256;
   void* h_stage = nullptr;        // pinned staging buffer (priors upload, fn_scan round trip), grown on demand
   size_t h_stage_bytes = 0;
-  size_t lds_attr[72] = {};       // dynamic-LDS caps already raised for this context's device, by kernel slot (cm_raise_lds)
+  size_t lds_attr[80] = {};       // dynamic-LDS caps already raised for this context's device, by kernel slot (cm_raise_lds)
   long long* dbg_block0 = nullptr; // diagnostic buffer (CAVIAR_HIP_TRACE_BLOCK0): 64 launches x 8 device-clock stamps
   void* d_pdev = nullptr;         // descriptors of the current batch (device) and their pinned source
   void* h_pdev = nullptr;
@@ -466,8 +466,8 @@ inline void cm_threefry2x32(uint32_t k0, uint32_t k1, uint32_t& x0, uint32_t& x1
 enum cm_lds_slot { CM_LDS_ITER = 0 /* 7 x 2 x 2 template variants */, CM_LDS_SOLVE_SMALL = 28, CM_LDS_SWEEP_PAR, CM_LDS_SWEEP_PAR2, CM_LDS_SWEEP_SEQ,
                    CM_LDS_NWD, CM_LDS_SIM_SORT, CM_LDS_BUILD_PREC, CM_LDS_SWEEP_PAR_B, CM_LDS_SWEEP_PAR2_B, CM_LDS_SWEEP_SEQ_B,
                    CM_LDS_SOLVE_SMALL_B, CM_LDS_BUILD_PREC_B, CM_LDS_ITER_LISTED /* 7 SEG variants */, CM_LDS_MC_DEAD = 47, CM_LDS_MC_DEAD_B, CM_LDS_ITER_OVERFLOW /* 7 SEG variants */, CM_LDS_CHOL_DIAG = 56, CM_LDS_CHOL_GPANEL, CM_LDS_CHOL_WIDE,
-                   CM_LDS_CHOL_DIAG_B, CM_LDS_CHOL_GPANEL_B, CM_LDS_CHOL_WIDE_B, CM_LDS_FN_SCAN, CM_LDS_FN_SCAN_B, CM_LDS_FN_SCAN_G, CM_LDS_FN_SCAN_GB, CM_LDS_PHI_REP, CM_LDS_PHI_REP_B, CM_LDS_SLOTS = 68 };
-static_assert(CM_LDS_SLOTS <= 72, "cm_ctx::lds_attr");
+                   CM_LDS_CHOL_DIAG_B, CM_LDS_CHOL_GPANEL_B, CM_LDS_CHOL_WIDE_B, CM_LDS_FN_SCAN, CM_LDS_FN_SCAN_B, CM_LDS_FN_SCAN_G, CM_LDS_FN_SCAN_GB, CM_LDS_PHI_REP, CM_LDS_PHI_REP_B, CM_LDS_ITER_FLAT /* 7 SEG variants */ = 68, CM_LDS_SLOTS = 75 };
+static_assert(CM_LDS_SLOTS <= 80, "cm_ctx::lds_attr");
 // Table update AND runtime call under ONE lock: `set(fn, bytes, user)` is invoked while the table's mutex is held, and the table takes
 // the new value only after the setter succeeded -- two host threads (contexts on one GPU) can therefore never apply their values in
 // the opposite order of their table updates (the smaller request landing last would leave the attribute below what the table and both

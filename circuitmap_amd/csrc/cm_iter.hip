@@ -255,15 +255,15 @@ __global__ __launch_bounds__(256) void k_mc_dead(cm_parg<BATCH> pa, IterDyn a, i
 #ifndef CM_ITER_MINW_LISTED
 #define CM_ITER_MINW_LISTED 4
 #endif
-template <bool BATCH, int SEG, bool FULLMC, bool LISTED = false>
-__global__ __launch_bounds__(CM_ITER_THREADS, (BATCH && !FULLMC) ? (LISTED ? CM_ITER_MINW_LISTED : CM_ITER_MINW_PLAIN) : 1) void k_iter_mid(cm_parg<BATCH> pa, IterDyn a) {
-  extern __shared__ double sm[];
-  const cm_pdev& p = pa.get();
-  if (blockIdx.x <= 1) {
+// The body of k_iter_mid for workgroup `bx` of circuit `p` (first: the first circuit of its launch, which carries the diagnostic stamps).  Two
+// launch shapes call it: k_iter_mid (grid (blocks, circuits)) and, for the listed rows of a batch, k_iter_listed_flat (a flat grid sized per circuit).
+template <bool BATCH, int SEG, bool FULLMC, bool LISTED>
+__device__ __forceinline__ void iter_mid_body(const cm_pdev& p, IterDyn a, const int bx, const bool first, double* sm) {
+  if (bx <= 1) {
     if (!(a.roles & 1)) return;
     if (threadIdx.x >= CM_POST_THREADS) return;
-    if (BATCH && blockIdx.y != 0) a.dbg = nullptr;     // (diagnostic stamps: circuit 0 only)
-    if (blockIdx.x == 1) {                               // soft threshold + spont_rate: its own workgroup, beside block 0
+    if (BATCH && !first) a.dbg = nullptr;              // (diagnostic stamps: circuit 0 only)
+    if (bx == 1) {                                       // soft threshold + spont_rate: its own workgroup, beside block 0
       if (a.do_sigma)
         post_single_body(p.y, p.R, p.colany, p.mask, p.mu, p.beta, p.rs, p.sum_y, p.N, p.K, a.it, a.max_iters, a.penalty, a.scale_factor, a.tol,
                          a.do_sigma, a.seq, p.act_idx, p.act_inv, p.n_act, p.mailbox, p.z, p.scal, a.stage_ok ? sm : nullptr, a.dbg, 2);
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(CM_ITER_THREADS, (BATCH && !FULLMC) ? (LISTED ? CM_
     // (no loop here: one listed row per wavefront -- a stride loop around this body costs the kernel 100 registers, i.e. two
     // wavefronts per SIMD instead of four; rows beyond the grid, if the list ever outgrows it, are taken by k_iter_overflow)
     const int n_alive = min(p.alive[0], N);
-    const int i = a.rpw * (((int)blockIdx.x - 2) * (int)(blockDim.x / CM_WAVE) + wave) + (lane >> 5);   // rpw listed rows per wavefront, one per half (phi_pair)
+    const int i = a.rpw * ((bx - 2) * (int)(blockDim.x / CM_WAVE) + wave) + (lane >> 5);   // rpw listed rows per wavefront, one per half (phi_pair)
     const bool mine = i < n_alive && (lane >> 5) < a.rpw;
     if (__any(mine)) {
       const int n = mine ? p.alive[1 + i] : -1;
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(CM_ITER_THREADS, (BATCH && !FULLMC) ? (LISTED ? CM_
     return;
   }
   // two rows per wavefront, one per 32-lane half (phi_pair): rows 2 w and 2 w + 1
-  const int nrow = a.rpw * (((int)blockIdx.x - 2) * (int)(blockDim.x / CM_WAVE) + wave) + (lane >> 5);
+  const int nrow = a.rpw * ((bx - 2) * (int)(blockDim.x / CM_WAVE) + wave) + (lane >> 5);
   const bool mine = nrow < N && (lane >> 5) < a.rpw;
   if (!__any(mine)) return;
   int n = mine ? nrow : -1;                            // this half's row
@@ -340,11 +340,37 @@ __global__ __launch_bounds__(CM_ITER_THREADS, (BATCH && !FULLMC) ? (LISTED ? CM_
   if (a.do_mc) mc_logit_rows<FULLMC>(p, a, n, pc, dead_row, dc0, dc1, lane, wave, sm, etab);
 }
 
+template <bool BATCH, int SEG, bool FULLMC, bool LISTED = false>
+__global__ __launch_bounds__(CM_ITER_THREADS, (BATCH && !FULLMC) ? (LISTED ? CM_ITER_MINW_LISTED : CM_ITER_MINW_PLAIN) : 1) void k_iter_mid(cm_parg<BATCH> pa, IterDyn a) {
+  extern __shared__ double sm[];
+  iter_mid_body<BATCH, SEG, FULLMC, LISTED>(pa.get(), a, (int)blockIdx.x, !BATCH || blockIdx.y == 0, sm);
+}
+
+// The listed launch of a batch as a FLAT grid: workgroups [0, 2 B) are the two single-workgroup roles of every circuit, the rest the row blocks of
+// the circuits one after the other, as many per circuit as ITS active set asks for (pre: exclusive prefix of the per-circuit counts, made by the
+// host from the mailbox values) -- the (blocks, circuits) grid is sized for the largest active set of the batch, and at 512 circuits most of its
+// workgroups found nothing to do while occupying the slots of those that did.
+struct IterFlat { int B; unsigned short pre[CM_MAX_BATCH + 1]; };
+template <int SEG>
+__global__ __launch_bounds__(CM_ITER_THREADS, CM_ITER_MINW_LISTED) void k_iter_listed_flat(cm_parg<true> pa, IterDyn a, IterFlat f) {
+  extern __shared__ double sm[];
+  const int g = (int)blockIdx.x;
+  int c, bx;
+  if (g < 2 * f.B) { c = g >> 1; bx = g & 1; }
+  else {
+    const int r = g - 2 * f.B;
+    int lo = 0, hi = f.B;                              // pre[lo] <= r < pre[hi]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)f.pre[mid] <= r) lo = mid; else hi = mid; }
+    c = lo; bx = 2 + r - (int)f.pre[lo];
+  }
+  iter_mid_body<true, SEG, false, true>(pa.get(c), a, bx, c == 0, sm);
+}
+
 // Listed rows beyond the grid of the LISTED k_iter_mid (`first` = the rows that launch covers): a stride loop over whatever is left.
 // The list holds the rows with lam != 0 after the sweep; the host sizes the main grid for twice the active set the iteration began
 // with, so this kernel normally finds nothing and leaves at once -- it exists so that no growth of the list can lose a row.
 template <int SEG>
-__global__ __launch_bounds__(CM_ITER_THREADS) void k_iter_overflow(cm_parg<true> pa, IterDyn a, int first) {
+__global__ __launch_bounds__(CM_ITER_THREADS) void k_iter_overflow(cm_parg<true> pa, IterDyn a, int first_arg, IterFlat f) {
   extern __shared__ double sm[];
   __shared__ double etab[64], ltab[128];
   cm_exptab_init(etab);
@@ -355,6 +381,8 @@ __global__ __launch_bounds__(CM_ITER_THREADS) void k_iter_overflow(cm_parg<true>
   const int N = p.N;
   const int n_alive = min(p.alive[0], N);
   const int total = (int)gridDim.x * (int)(blockDim.x / CM_WAVE);
+  // (flat listed launch: the rows the circuit's own row blocks covered)
+  const int first = f.B > 0 ? ((int)f.pre[blockIdx.y + 1] - (int)f.pre[blockIdx.y]) * a.rpw * (int)(blockDim.x / CM_WAVE) : first_arg;
   for (int i0 = first + a.rpw * ((int)blockIdx.x * (int)(blockDim.x / CM_WAVE) + wave); i0 < n_alive; i0 += a.rpw * total) {
     const int i = i0 + (lane >> 5);                    // rpw listed rows per wavefront, one per half (phi_pair)
     const int n = (i < n_alive && (lane >> 5) < a.rpw) ? p.alive[1 + i] : -1;
@@ -393,12 +421,36 @@ static int launch_iter2(cm_ctx* ctx, cm_set& s, const IterDyn& a0, size_t lds, i
     // batches, steady state: the rows with lam != 0 from the list; the all-zero rows in their lean kernel (after the mailboxes are on their way)
     const int slot_l = CM_LDS_ITER_LISTED + (31 - __builtin_clz((unsigned)SEG));
     CM_TRY(cm_raise_lds(ctx, slot_l, reinterpret_cast<const void*>(k_iter_mid<true, SEG, false, true>), lds, 48 * 1024));
-    hipLaunchKernelGGL((k_iter_mid<true, SEG, false, true>), dim3(blocks, s.B), dim3(threads), lds, ctx->stream, cm_parg<true>{s.d_arr}, a0);
-    {
-      const int waves = threads / CM_WAVE, covered = (blocks - 2) * waves * a0.rpw;
+    // row blocks per circuit: twice ITS active set (rows can be revived; whatever outgrows it is k_iter_overflow's), as a flat grid when the
+    // prefix fits its 16-bit words; else -- and with the test hook's fixed grid -- the (blocks, circuits) grid sized for the largest active set
+    static const bool no_flat = getenv("CAVIAR_HIP_NO_FLAT_LISTED") != nullptr || getenv("CAVIAR_HIP_TEST_LISTED_ROWS") != nullptr;
+    IterFlat* f = nullptr;
+    thread_local IterFlat flat_tl;                       // (2 KB, filled per launch: one per driving thread -- the context's and its twin's)
+    const int waves = threads / CM_WAVE, N = s.lead->N, per_wg = waves * a0.rpw;
+    if (!no_flat && (int)s.na.size() == s.B) {
+      long long tot = 0;
+      flat_tl.B = s.B;
+      for (int c = 0; c < s.B; ++c) {
+        flat_tl.pre[c] = (unsigned short)tot;
+        const int want = std::min(N, std::max(16, 2 * s.na[c]));
+        tot += (want + per_wg - 1) / per_wg;
+        if (tot > 65535) break;
+      }
+      if (tot <= 65535) { flat_tl.pre[s.B] = (unsigned short)tot; f = &flat_tl; }
+    }
+    if (f) {
+      const int slot_f = CM_LDS_ITER_FLAT + (31 - __builtin_clz((unsigned)SEG));
+      CM_TRY(cm_raise_lds(ctx, slot_f, reinterpret_cast<const void*>(k_iter_listed_flat<SEG>), lds, 48 * 1024));
+      hipLaunchKernelGGL((k_iter_listed_flat<SEG>), dim3(2 * s.B + (unsigned)f->pre[s.B]), dim3(threads), lds, ctx->stream, cm_parg<true>{s.d_arr}, a0, *f);
+      CM_TRY(cm_raise_lds(ctx, CM_LDS_ITER_OVERFLOW + (31 - __builtin_clz((unsigned)SEG)), reinterpret_cast<const void*>(k_iter_overflow<SEG>), (size_t)waves * lds_waves, 48 * 1024));
+      hipLaunchKernelGGL((k_iter_overflow<SEG>), dim3(8, s.B), dim3(threads), (size_t)waves * lds_waves, ctx->stream, cm_parg<true>{s.d_arr}, a0, 0, *f);
+    } else {
+      hipLaunchKernelGGL((k_iter_mid<true, SEG, false, true>), dim3(blocks, s.B), dim3(threads), lds, ctx->stream, cm_parg<true>{s.d_arr}, a0);
+      const int covered = (blocks - 2) * waves * a0.rpw;
       if (covered < s.lead->N) {                         // (a grid that already covers N rows cannot be outgrown)
+        flat_tl.B = 0;
         CM_TRY(cm_raise_lds(ctx, CM_LDS_ITER_OVERFLOW + (31 - __builtin_clz((unsigned)SEG)), reinterpret_cast<const void*>(k_iter_overflow<SEG>), (size_t)waves * lds_waves, 48 * 1024));
-        hipLaunchKernelGGL((k_iter_overflow<SEG>), dim3(8, s.B), dim3(threads), (size_t)waves * lds_waves, ctx->stream, cm_parg<true>{s.d_arr}, a0, covered);
+        hipLaunchKernelGGL((k_iter_overflow<SEG>), dim3(8, s.B), dim3(threads), (size_t)waves * lds_waves, ctx->stream, cm_parg<true>{s.d_arr}, a0, covered, flat_tl);
       }
     }
     if (between) CM_HIP(hipEventRecord(between, ctx->stream));
