@@ -231,9 +231,19 @@ __device__ __forceinline__ int post_single_body(const double* __restrict__ y, co
   {
     const int lane = threadIdx.x % CM_WAVE, w = threadIdx.x / CM_WAVE;
     const int nthr = nthr_, nwv = nthr_ / CM_WAVE;
-    for (int n0 = 0; n0 < N; n0 += nthr) {
+    // (the rounds' flags are loaded together: four dependent round trips at N = 1000 were most of this phase's 4 us)
+    constexpr int PRE = 8;
+    bool pre[PRE];
+#pragma unroll
+    for (int q = 0; q < PRE; ++q) { const int n = q * nthr + (int)threadIdx.x; pre[q] = n < N && rs[(size_t)n * 4 + 3] >= 0.0; }
+    for (int n0 = 0, q = 0; n0 < N; n0 += nthr, ++q) {
       const int n = n0 + threadIdx.x;
-      const bool a = n < N && rs[(size_t)n * 4 + 3] >= 0.0;
+      bool a;
+      switch (q) {      // (static register indices)
+        case 0: a = pre[0]; break; case 1: a = pre[1]; break; case 2: a = pre[2]; break; case 3: a = pre[3]; break;
+        case 4: a = pre[4]; break; case 5: a = pre[5]; break; case 6: a = pre[6]; break; case 7: a = pre[7]; break;
+        default: a = n < N && rs[(size_t)n * 4 + 3] >= 0.0;
+      }
       const unsigned long long m = __ballot(a);
       if (lane == 0) wave_cnt[w] = __popcll(m);
       __syncthreads();
@@ -270,8 +280,11 @@ __device__ __forceinline__ int post_single_body(const double* __restrict__ y, co
   if (!do_sigma) return n_active;
   // ---- 2. update_sigma
   double a = 0.0;
+  // (unrolled for the loads' sake: the sums keep their order)
+#pragma unroll 8
   for (int k = threadIdx.x; k < K; k += nthr_) { const double r = y[k] - R[k]; a = fma(r, r, a); }
   double b = 0.0, c = 0.0;
+#pragma unroll 4
   for (int n = threadIdx.x; n < N; n += nthr_) {
     const double m = mu[n], be = beta[n];
     b = fma(m * m, rs[(size_t)n * 4 + 1], b);
@@ -871,6 +884,7 @@ __device__ __forceinline__ void solve_small_body(double* sm, const double* __res
   __shared__ int bad;
   const int tid = threadIdx.x;
   // inactive rows: mu = mu0, beta = beta0^2 exactly (their rows of the precision matrix are diagonal)
+#pragma unroll 4
   for (int i = tid; i < N; i += nthr) { mu[i] = mu_prior[i]; const double b0 = beta_prior[i]; beta[i] = b0 * b0; }
   if (tid == 0) bad = 0;
   // ---- 1. stage
